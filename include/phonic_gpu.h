@@ -1,0 +1,209 @@
+/*
+ * phonic_gpu.h — C ABI of the MI355X-native phonic DSP hot path.
+ *
+ * This is the drop-in boundary: a Rust shim (`impl Effect`, `impl Source`,
+ * see INTEGRATION.md) binds exactly these entry points. Every function cites the reference
+ * interface it replaces (paths relative to the reference repo, emuell/phonic v0.16.0).
+ *
+ * Conventions
+ *   - audio buffers are interleaved f32; all stock effects and the graph are stereo
+ *     (reference: `enforce_stereo_playback`, src/player.rs:134,179).
+ *   - handles are NOT thread safe; exactly one thread may call process/write on a handle at
+ *     a time (the reference passes `&mut self`, src/effect.rs:155, src/source.rs:95).
+ *   - all functions returning `int` return a pg_status; the message of the last failure
+ *     on the calling thread is available from pg_last_error_message().
+ *   - host/device allocations happen in create/initialize/add_* only; process/write
+ *     allocate nothing (reference: assert_no_alloc, src/output/cpal.rs:712-715).
+ */
+#ifndef PHONIC_GPU_H
+#define PHONIC_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error taxonomy: reference `Error` enum (src/error.rs:8-22) ------------------------- */
+typedef enum pg_status {
+  PG_OK = 0,
+  PG_ERR_PARAMETER = 1,   /* Error::ParameterError: unknown FourCC, non-stereo I/O, bad value */
+  PG_ERR_NOT_FOUND = 2,   /* Error::EffectNotFoundError / MixerNotFoundError / unknown voice  */
+  PG_ERR_QUEUE_FULL = 3,  /* Error::SendError: message queue of a mixer is full               */
+  PG_ERR_DEVICE = 4,      /* HIP failure; the handle becomes silent (GuardedSource semantics) */
+  PG_ERR_STATE = 5        /* call order violated (e.g. process before initialize)            */
+} pg_status;
+
+const char* pg_last_error_message(void);
+
+/* Number of HIP devices visible, or a negative pg_status. */
+int pg_device_count(void);
+
+/* ---- effect kinds: the ten stock effects (src/effect/ *.rs) ------------------------------ */
+typedef enum pg_effect_kind {
+  PG_FX_GAIN = 0,        /* src/effect/gain.rs        "Gain"       */
+  PG_FX_PANNING = 1,     /* src/effect/pan.rs         "Panning"    */
+  PG_FX_FILTER = 2,      /* src/effect/filter.rs      "Filter"     */
+  PG_FX_EQ5 = 3,         /* src/effect/eq5.rs         "Eq5"        */
+  PG_FX_DELAY = 4,       /* src/effect/delay.rs       "Delay"      */
+  PG_FX_REVERB = 5,      /* src/effect/reverb.rs      "Reverb"     */
+  PG_FX_CHORUS = 6,      /* src/effect/chorus.rs      "Chorus"     */
+  PG_FX_COMPRESSOR = 7,  /* src/effect/compressor.rs  "Compressor" */
+  PG_FX_GATE = 8,        /* src/effect/gate.rs        "Gate"       */
+  PG_FX_DISTORTION = 9,  /* src/effect/distortion.rs  "Distortion" */
+  PG_FX_KIND_COUNT = 10
+} pg_effect_kind;
+
+/* FourCC of a parameter id, e.g. PG_FOURCC('r','o','o','m') == FourCC(*b"room"). */
+#define PG_FOURCC(a, b, c, d) \
+  ((uint32_t)(uint8_t)(a) << 24 | (uint32_t)(uint8_t)(b) << 16 | (uint32_t)(uint8_t)(c) << 8 | (uint32_t)(uint8_t)(d))
+
+#define PG_MAX_INIT_PARAMS 16
+
+/*
+ * Construction-time values of an effect: the `with_parameters(..)` constructors of the
+ * reference (e.g. ReverbEffect::with_parameters, src/effect/reverb.rs:154-159). Values are
+ * raw (not normalized); enum parameters take the variant index, booleans 0/1. Parameters
+ * not listed keep the reference default. n_params == 0 is `Effect::new()`.
+ *
+ * The reverb draws fpd_l/fpd_r and the 16 vibrato phases from rand::rng()
+ * (src/effect/reverb.rs:95-103,532-538); here they are explicit so results are reproducible.
+ * vib_phase index = line * 2 + channel, lines in order a..h.
+ */
+typedef struct pg_effect_init {
+  uint32_t n_params;
+  uint32_t fourcc[PG_MAX_INIT_PARAMS];
+  float value[PG_MAX_INIT_PARAMS];
+  uint32_t has_reverb_seeds;
+  uint32_t reverb_fpd_l;
+  uint32_t reverb_fpd_r;
+  double reverb_vib_phase[16];
+} pg_effect_init;
+
+/* ---- parameter descriptors: `Effect::parameters()` (src/effect.rs:105-111) -------------- */
+typedef enum pg_param_type { PG_PARAM_FLOAT = 0, PG_PARAM_ENUM = 1, PG_PARAM_BOOL = 2 } pg_param_type;
+typedef enum pg_param_scaling {
+  PG_SCALE_LINEAR = 0,
+  PG_SCALE_EXPONENTIAL = 1, /* src/parameter/scaling.rs:21  arg0 = factor          */
+  PG_SCALE_DECIBEL = 2      /* src/parameter/scaling.rs:31  arg0/1 = min_db/max_db */
+} pg_param_scaling;
+
+typedef struct pg_param_desc {
+  uint32_t fourcc;
+  int32_t type;          /* pg_param_type */
+  float min, max;        /* float range; for enums 0 .. n_values-1 */
+  float default_value;   /* raw default */
+  int32_t scaling;       /* pg_param_scaling */
+  float scaling_arg0, scaling_arg1;
+  int32_t n_values;      /* enum variant count, else 0 */
+  const char* name;
+} pg_param_desc;
+
+const char* pg_effect_kind_name(int kind);                   /* Effect::name()   src/effect.rs:96 */
+int pg_effect_kind_weight(int kind);                         /* Effect::weight() src/effect.rs:101 */
+int pg_effect_kind_param_count(int kind);
+int pg_effect_kind_param(int kind, int index, pg_param_desc* out);
+
+/* ---- standalone effect: the `Effect` trait (src/effect.rs:86-215) ----------------------- */
+typedef struct pg_effect pg_effect;
+
+/* Effect::new()/with_parameters(); `device` = HIP device ordinal. NULL on failure. */
+pg_effect* pg_effect_create(int kind, const pg_effect_init* init, int device);
+/* Effect::initialize(sample_rate, channel_count, max_frames)  src/effect.rs:113-125 */
+int pg_effect_initialize(pg_effect* fx, uint32_t sample_rate, size_t channel_count, size_t max_frames);
+/* Effect::process_started / process_stopped  src/effect.rs:127-139 */
+int pg_effect_process_started(pg_effect* fx);
+int pg_effect_process_stopped(pg_effect* fx);
+/* Effect::process(&mut output, time): in place, host buffer, n_samples <= max_frames*channels
+ * and a multiple of the channel count (src/effect.rs:141-155). */
+int pg_effect_process(pg_effect* fx, float* interleaved, size_t n_samples, uint64_t pos_in_frames);
+/* Effect::process_tail(): -1 = None, INT64_MAX = Some(usize::MAX)  src/effect.rs:157-176 */
+int64_t pg_effect_tail(pg_effect* fx);
+/* Effect::process_parameter_update(id, Raw|Normalized)  src/effect.rs:178-195 */
+int pg_effect_set_parameter(pg_effect* fx, uint32_t fourcc, float value, int is_normalized);
+/* Effect::process_message(Reset) (ReverbEffectMessage::Reset etc., src/effect/reverb.rs:24-27) */
+int pg_effect_message_reset(pg_effect* fx);
+void pg_effect_destroy(pg_effect* fx);
+
+/* ---- batched mixer graph: `MixedSource` as a `Source` (src/source/mixed.rs, src/source.rs:80-110)
+ *
+ * Mixer 0 is the main mixer. Sub-mixers (Player::add_mixer, src/player.rs:773-822) hang off
+ * the main mixer; each owns its sources and its effect chain and is one GPU workgroup.
+ */
+typedef struct pg_graph pg_graph;
+
+#define PG_MAIN_MIXER 0
+#define PG_REPEAT_FOREVER UINT64_MAX
+
+/* FilePlaybackOptions (src/source/file.rs:34-75) for a preloaded source. */
+typedef struct pg_voice_options {
+  float volume;            /* default 1.0 */
+  float panning;           /* default 0.0, -1..1 */
+  double speed;            /* default 1.0 */
+  uint64_t repeat;         /* 0 = play once, PG_REPEAT_FOREVER; (Option<usize>: has_repeat) */
+  uint32_t has_repeat;     /* 0 = None: forever iff a loop range is set (preloaded.rs:89-95) */
+  uint32_t has_loop_range; /* loop_range override in source frames (preloaded.rs:101-104)   */
+  uint64_t loop_start, loop_end;
+  uint64_t start_time;     /* sample time in output frames at which the source starts       */
+  float fade_in_seconds;   /* < 0 or 0 = none                                               */
+  float fade_out_seconds;  /* default 0.05 (file.rs:106); < 0 = none                        */
+} pg_voice_options;
+
+void pg_voice_options_default(pg_voice_options* opt);
+
+/* MixedSource::new(channel_count, sample_rate) for the main mixer (src/source/mixed.rs:222-264).
+ * max_frames bounds the frames of one write() call chunk (<= 4096, MAX_MIX_BUFFER_SAMPLES/2). */
+pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, int device);
+void pg_graph_destroy(pg_graph* g);
+
+/* Player::add_mixer(parent = main) -> mixer id > 0 (src/player.rs:773-822). */
+int pg_graph_add_mixer(pg_graph* g);
+/* Player::add_effect(effect, mixer) -> effect id >= 0 (src/player.rs:893-939). */
+int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init);
+/* Player::play_file_source(PreloadedFileSource::from_shared_buffer(..), start_time)
+ * (src/player.rs:519-602, src/source/file/preloaded.rs:71-117). `pcm` is the decoded interleaved
+ * buffer INCLUDING the extra zero frame symphonia decoding appends (file/buffer.rs:103-104);
+ * it is copied to the device. Returns a voice (playback) id >= 0. */
+int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels,
+                       uint32_t src_rate, const pg_voice_options* opt);
+
+/* EffectHandle::set_parameter((id, update), sample_time) (src/player/handles/effect.rs:67-95) */
+int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized,
+                            uint64_t sample_time);
+/* EffectHandle::send_message(Reset, sample_time) */
+int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time);
+/* FilePlaybackHandle::set_volume / set_panning / stop (src/player/handles/file.rs) */
+int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time);
+int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time);
+int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time);
+
+/* Source::write(&mut output, &SourceTime{pos_in_frames}) of the main MixedSource
+ * (src/source/mixed.rs:659-719): returns the samples written == n_samples, or 0 when the
+ * graph is empty (or after a device failure: GuardedSource, src/source/guarded.rs:87-107).
+ * `out` is a host buffer. */
+size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in_frames);
+/* Same, output left in device memory (`d_out` = device pointer, >= n_samples floats), enqueued
+ * on `hip_stream` (a hipStream_t, NULL = the graph's own stream); asynchronous when a stream is
+ * given. Used for the multi-GPU master-bus reduce and by bench.py. */
+size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos_in_frames, void* hip_stream);
+/* Multi-GPU: when set, bus effects are skipped in write*(): the caller reduces the partial bus of
+ * all ranks (RCCL) and then runs them once on the root with pg_graph_process_bus_device(). */
+int pg_graph_set_defer_bus(pg_graph* g, int defer);
+int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream);
+/* Block until all work of the graph's stream has finished. */
+int pg_graph_synchronize(pg_graph* g);
+
+/* Introspection used by the harness */
+int pg_graph_voice_count(pg_graph* g);
+int pg_graph_is_voice_playing(pg_graph* g, int voice_id);
+/* Average device time (ms) of the dominant kernel (voice/sub-mixer chain kernel) over the launches
+ * since the last call with reset != 0, measured with hipEvents on the graph's stream; launches = count. */
+double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
+/* 0 = exact serial filters, 1 = time-parallel (blocked) evaluation of linear filters (default) */
+int pg_graph_set_fast_math(pg_graph* g, int level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHONIC_GPU_H */
