@@ -1,0 +1,224 @@
+// Device-resident state of the phonic DSP hot path (HBM layout). Plain-old-data, shared by the host
+// side (graph construction, C ABI) and the gfx950 kernels. All delay lines keep the reference's f64
+// ring layout and index arithmetic (reference src/utils/dsp/delay.rs) so state is comparable with the
+// CPU oracle after every block.
+#pragma once
+#include <stdint.h>
+
+#define PG_USIZE_MAX 0xFFFFFFFFFFFFFFFFull
+#define PG_MAX_FRAMES 4096  // MixedSource::MAX_MIX_BUFFER_SAMPLES / 2 (src/source/mixed.rs:216)
+
+enum PgSmoothKind { SM_EXP = 0, SM_LIN = 1, SM_SPRING = 2 };
+
+// ExponentialSmoothedValue / LinearSmoothedValue / SpringSmoothedValue (src/utils/smoothing.rs)
+struct PgSmooth {
+  int32_t kind;
+  float current, target;
+  float a;      // inertia | step | omega
+  float b;      // -       | current_step | velocity
+  float comp;   // 44100 / sample_rate
+  uint32_t pending;  // linear: num_pending_steps
+};
+
+// BiquadFilterCoefficients (src/utils/dsp/filters/biquad.rs:31-43)
+struct PgBiquadCoef {
+  int32_t type;
+  uint32_t sample_rate;
+  float cutoff, q, gain;
+  int32_t pad;
+  double a1, a2, a3, m0, m1, m2;
+};
+// SvfFilterCoefficients (src/utils/dsp/filters/svf.rs:30-41)
+struct PgSvfCoef {
+  int32_t type;
+  uint32_t sample_rate;
+  float cutoff, resonance;
+  double g, k, a1, a2, a3;
+};
+struct PgState2 { double ic1eq, ic2eq; };      // BiquadFilter / SvfFilter state
+struct PgDc { double y1, x1, r; };             // DcFilter (src/utils/dsp/filters/dc.rs:35-39)
+struct PgLfo { float phase, phase_inc; int32_t waveform; };  // Lfo (src/utils/dsp/lfo.rs:52-60), deterministic shapes
+
+struct PgGain {  // GainEffect (src/effect/gain.rs:47-55)
+  PgSmooth gain;
+  int32_t dc_mode;  // 0 Off, 1 Slow, 2 Default, 3 Fast
+  PgDc dc[2];
+};
+struct PgPan {  // PanningEffect (src/effect/pan.rs)
+  PgSmooth pan, width;
+  int32_t invert_l, invert_r;
+};
+struct PgFilter {  // FilterEffect (src/effect/filter.rs:47-56)
+  PgBiquadCoef coef;
+  PgState2 st[2];
+  int32_t type;  // FilterEffectType
+  PgSmooth cutoff, q;
+};
+struct PgEq5 {  // Eq5Effect (src/effect/eq5.rs:18-28)
+  PgSmooth gains[5], freqs[5], bws[5];
+  PgBiquadCoef coef[5];
+  PgState2 st[2][5];
+};
+struct PgDelay {  // DelayEffect (src/effect/delay.rs:88-116)
+  int32_t mode, filter_type, lfo_shape;
+  PgSmooth delay_time, feedback, cutoff, drive, wet, width, lfo_rate, d_time, d_feedback, d_filter;
+  double* line[2];  // InterpolatedDelayLine<1> left/right
+  uint32_t mask, write_pos[2];
+  PgLfo lfo;
+  PgSvfCoef coef;
+  PgState2 flt[2];
+  PgDc dc[2];
+  float fb[2];
+};
+struct PgReverbLine {  // ReverbDelayLine<2> (src/effect/reverb.rs:518-529)
+  double* buf;         // [(size+1)][2]
+  uint32_t frames, count, delay, pad;
+  double feedback[2];
+  double depth;
+  double vib_phase[2];
+};
+struct PgAllpass {  // AllpassDelayLine<2> (src/utils/dsp/delay.rs:283-287)
+  double* buf;      // [size][2]
+  uint32_t frames, delay, write_pos, pad;
+};
+struct PgReverb {  // ReverbEffect (src/effect/reverb.rs:41-73)
+  PgSmooth room, wet;
+  PgBiquadCoef ca, cb, cc;
+  PgState2 sa[2], sb[2], sc[2];
+  uint32_t fpd_l, fpd_r;
+  PgReverbLine line[8];
+  PgAllpass ap[4];
+  double* pre;  // DelayLine<2>, pow2 4096 frames
+  uint32_t pre_mask, pre_write_pos;
+};
+struct PgChorus {  // ChorusEffect (src/effect/chorus.rs:47-75)
+  PgSmooth rate, phase, depth, feedback, delay, wet, freq, res;
+  int32_t filter_type;
+  float lfo_range;
+  double current_phase;
+  PgLfo osc[2];
+  double* line[2];
+  uint32_t mask, write_pos[2];
+  PgSvfCoef coef;
+  PgState2 flt[2];
+};
+struct PgComp {  // CompressorEffect (src/effect/compressor.rs:24-38)
+  float threshold, ratio, knee, attack, release, lookahead;
+  PgSmooth makeup;
+  float env_current, env_attack, env_release;
+  double* line;  // LookupDelayLine<2>
+  uint32_t line_frames;  // allocated frames (pow2 >= ceil(0.2*sr))
+  uint32_t mask, delay_frames, write_pos, peak_pos;
+  double peak_value;
+};
+struct PgGate {  // GateEffect (src/effect/gate.rs)
+  float threshold, attack, hold, release, range;
+  float env_current, env_attack, env_release;
+  uint32_t hold_counter;
+  float gate_gain_db, attack_coeff, release_coeff;
+};
+struct PgDist {  // DistortionEffect (src/effect/distortion.rs:194-204)
+  int32_t type;
+  PgSmooth drive, mix;
+  const float* luts;  // [5][256], shared, built on the host at create
+};
+
+struct PgFx {
+  int32_t kind;
+  uint32_t sample_rate;
+  // EffectProcessor (src/source/mixed/effect.rs:12-17)
+  int32_t bypassed;
+  int32_t standalone;  // 1: plain Effect::process without the processor's bypass logic
+  uint64_t tail_counter, silence_counter;
+  union {
+    PgGain gain; PgPan pan; PgFilter filter; PgEq5 eq5; PgDelay delay; PgReverb reverb; PgChorus chorus; PgComp comp; PgGate gate; PgDist dist;
+  } u;
+};
+
+// PreloadedFileSource + ChannelMapped + Amplified + Panned + PlayingSource (one "voice")
+struct PgVoice {
+  const float* pcm;        // device copy of AudioFileBuffer (+1 zero frame)
+  uint64_t n_samples;      // buffer.len()
+  uint32_t channels;       // file channels (1 or 2)
+  uint32_t src_rate, out_rate;
+  // CubicInterpolator per channel (src/utils/resampler/cubic.rs:10-15)
+  float input[2][4];
+  float sub_pos[2];
+  float ratio;
+  int32_t initialized[2];
+  // PreloadedFileSource (src/source/file/preloaded.rs:29-37)
+  uint64_t playback_pos, repeat, repeat_count;
+  int32_t pos_eof, finished;
+  int32_t has_loop;
+  uint64_t loop_start, loop_end;  // frames
+  // VolumeFader (src/utils/fader.rs:27-34)
+  int32_t fader_state;  // 0 Stopped 1 Running 2 Finished
+  float fader_current, fader_target, fader_inertia;
+  float fade_out_seconds;
+  // AmplifiedSource / PannedSource smoothers
+  PgSmooth volume, panning;
+  // PlayingSource (src/source/mixed.rs:34-42)
+  uint64_t start_time, stop_time;
+  int32_t has_stop, active;
+};
+
+// Parameter indices per effect kind = order of `Effect::parameters()` in the reference.
+enum { P_GAIN_GAIN = 0, P_GAIN_DCFM };
+enum { P_PAN_PAN = 0, P_PAN_WIDTH, P_PAN_INVL, P_PAN_INVR };
+enum { P_FILTER_TYPE = 0, P_FILTER_CUTOFF, P_FILTER_Q };
+// Eq5: index = band * 3 + {0 gain, 1 frequency, 2 bandwidth}
+enum { P_DELAY_MODE = 0, P_DELAY_TIME, P_DELAY_FEEDBACK, P_DELAY_FTYPE, P_DELAY_CUTOFF, P_DELAY_DRIVE, P_DELAY_WET, P_DELAY_WIDTH,
+       P_DELAY_LFO_RATE, P_DELAY_LFO_SHAPE, P_DELAY_D_TIME, P_DELAY_D_FEEDBACK, P_DELAY_D_FILTER };
+enum { P_REVERB_ROOM = 0, P_REVERB_WET };
+enum { P_CHORUS_RATE = 0, P_CHORUS_DEPTH, P_CHORUS_FEEDBACK, P_CHORUS_DELAY, P_CHORUS_WET, P_CHORUS_PHASE, P_CHORUS_FTYPE, P_CHORUS_FREQ,
+       P_CHORUS_RES };
+enum { P_COMP_THRESHOLD = 0, P_COMP_RATIO, P_COMP_KNEE, P_COMP_ATTACK, P_COMP_RELEASE, P_COMP_MAKEUP, P_COMP_LOOKAHEAD };
+enum { P_GATE_THRESHOLD = 0, P_GATE_ATTACK, P_GATE_HOLD, P_GATE_RELEASE, P_GATE_RANGE };
+enum { P_DIST_TYPE = 0, P_DIST_DRIVE, P_DIST_MIX };
+
+enum PgUnitKind { UNIT_SUBMIXER = 0, UNIT_SOURCE = 1, UNIT_BUS = 2, UNIT_EFFECT = 3 };
+
+struct PgUnit {
+  int32_t kind;
+  int32_t n_voices, voice_off;  // into the voice index table
+  int32_t n_fx, fx_off;         // into the fx index table
+  int32_t effects_bypassed;     // MixedSource::effects_bypassed (src/source/mixed.rs:202)
+  uint64_t silence_counter;     // SubMixerProcessor (src/source/mixed/submixer.rs:23)
+  int32_t audible;              // result of the last chunk: contributes to the parent's `audible_input`
+  int32_t pad;
+};
+
+enum PgCmdType {
+  CMD_FX_PARAM = 0,     // target = fx index, param = parameter index, value = raw (already denormalized/clamped) value
+  CMD_FX_RESET = 1,
+  CMD_VOICE_VOLUME = 2, // target = voice index
+  CMD_VOICE_PAN = 3,
+  CMD_VOICE_STOP = 4,   // sets stop_time = value64
+};
+struct PgCmd {
+  int32_t type, unit, target, param;
+  uint32_t frame;  // offset in frames from the start of this launch at which the command applies
+  float value;
+  uint64_t value64;
+};
+
+struct PgLaunch {
+  PgUnit* units;
+  PgVoice* voices;
+  PgFx* fx;
+  const int32_t* voice_index;
+  const int32_t* fx_index;
+  const PgCmd* cmds;
+  int32_t n_cmds;
+  int32_t n_units;
+  int32_t unit_base;      // first unit slot this launch processes (when unit_order == nullptr)
+  const int32_t* unit_order;  // block b processes unit slot unit_order[b] and writes row b of unit_out
+  uint32_t n_frames;      // frames of this launch (<= PG_MAX_FRAMES)
+  uint64_t pos;           // SourceTime.pos_in_frames of the first frame
+  uint32_t sample_rate;
+  int32_t fast;           // 1: time-parallel paths enabled
+  float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
+  uint32_t out_stride;    // floats per unit row
+  float* bus;             // bus / external signal for UNIT_BUS and UNIT_EFFECT (in place)
+  int32_t* bus_audible;   // input flag for UNIT_BUS (1 = audible input)
+};

@@ -1,0 +1,251 @@
+// gfx950 device primitives: smoothers, filter coefficients, filters, LFO, dB helpers.
+// Arithmetic follows the reference statement by statement (same f32/f64 widths, same operation
+// order; the TU is compiled with -ffp-contract=off). Reference file:line cited per function.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pg_dev.h"
+
+#define DEV __host__ __device__ __forceinline__
+#define DEVO __device__ __forceinline__
+#define DEVN __device__ __noinline__
+
+namespace pgd {
+
+constexpr float F32_EPS100 = 1.1920929e-07f * 100.0f;
+constexpr float F32_PI = 3.14159274101257324f;
+constexpr float F32_TAU = 6.28318548202514648f;
+constexpr double F64_PI = 3.14159265358979323846;
+constexpr double F64_TAU = 6.28318530717958647692;
+
+// Rust float semantics -------------------------------------------------------------------------
+DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }   // f32::clamp (NaN passes)
+DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+DEV uint32_t f2u32(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)x); }    // `as u32`
+DEV uint64_t d2u64(double x) { return !(x > 0.0) ? 0ull : (x >= 18446744073709551615.0 ? PG_USIZE_MAX : (uint64_t)x); }  // `as usize`
+DEV uint64_t f2u64(float x) { return d2u64((double)x); }
+
+// src/utils.rs:41-51
+DEV float db_to_linear(float value) {
+  const float DB_TO_LIN_FACTOR = 2.30258509299404568402f / 20.0f;
+  if (value != value) return value;
+  if (value == 0.0f) return 1.0f;
+  if (value > -200.0f) return expf(value * DB_TO_LIN_FACTOR);
+  return 0.0f;
+}
+// src/utils.rs:56-62
+DEV void panning_factors(float pan, float& l, float& r) {
+  const float POWER = 0.707106781186547524400844362104849039f;
+  float normalized = (clampf(pan, -1.0f, 1.0f) + 1.0f) / 2.0f;
+  l = sqrtf(1.0f - normalized) / POWER;
+  r = sqrtf(normalized) / POWER;
+}
+
+// src/utils/smoothing.rs -------------------------------------------------------------------------
+DEV bool sm_need_ramp(const PgSmooth& s) {
+  if (s.kind == SM_EXP) {  // :198-206
+    float inertia_add = (s.target - s.current) * s.a * s.comp;
+    return fabsf(inertia_add) > F32_EPS100;
+  } else if (s.kind == SM_LIN) {  // :360-368
+    return s.pending > 0;
+  }
+  return fabsf(s.b) > F32_EPS100 || fabsf(s.target - s.current) > F32_EPS100;  // :499-506
+}
+DEV void sm_ramp(PgSmooth& s) {
+  if (s.kind == SM_EXP) {  // :208-214
+    s.current += (s.target - s.current) * s.a * s.comp;
+  } else if (s.kind == SM_LIN) {  // :370-382
+    if (s.pending > 0) {
+      s.current += s.b;
+      s.pending -= 1;
+      if (s.pending == 0) s.current = s.target;
+    }
+  } else {  // :508-518
+    float omega = s.a * s.comp;
+    float k = omega * omega;
+    float d = 2.0f * omega;
+    s.b += (s.target - s.current) * k - s.b * d;
+    s.current += s.b;
+  }
+}
+DEV float sm_next(PgSmooth& s) {  // :21-28
+  if (sm_need_ramp(s)) { sm_ramp(s); return s.current; }
+  return s.target;
+}
+DEV void sm_init(PgSmooth& s, float v) {
+  s.target = v; s.current = v;
+  if (s.kind == SM_LIN) s.pending = 0;
+  if (s.kind == SM_SPRING) s.b = 0.0f;
+}
+DEV void sm_set_target(PgSmooth& s, float t) {
+  if (s.kind == SM_EXP) {  // :221-226
+    s.target = t;
+    if (!sm_need_ramp(s)) s.current = s.target;
+  } else if (s.kind == SM_LIN) {  // :312-341 (duration None)
+    s.target = t;
+    if (s.current == s.target) {
+      s.pending = 0;
+    } else {
+      s.b = (s.current > s.target) ? -s.a * s.comp : s.a * s.comp;
+      float pending_steps = (s.target - s.current) / s.b;
+      s.pending = f2u32(fmaxf(roundf(pending_steps), 0.0f));
+      if (s.pending == 0) s.current = s.target;
+    }
+  } else {  // :527-530
+    s.target = t;
+  }
+}
+
+// src/utils/dsp/filters/biquad.rs:153-271
+DEV bool biquad_apply(PgBiquadCoef& c) {
+  if (c.sample_rate == 0) return false;
+  if (c.q <= 0.0f) return false;
+  if (c.cutoff > (float)c.sample_rate / 2.0f) return false;
+  double g = tan(F64_PI * (double)c.cutoff / (double)c.sample_rate);
+  double k = 1.0 / (double)c.q;
+  double m0, m1, m2;
+  switch (c.type) {
+    case 0: m0 = 0.0; m1 = 0.0; m2 = 1.0; break;            // Lowpass
+    case 1: m0 = 1.0; m1 = -k; m2 = -1.0; break;            // Highpass
+    case 2: m0 = 0.0; m1 = 1.0; m2 = 0.0; break;            // Bandpass
+    case 3: m0 = 1.0; m1 = -k; m2 = 0.0; break;             // Notch
+    case 4: m0 = 1.0; m1 = -k; m2 = -2.0; break;            // Peak
+    case 5: m0 = 1.0; m1 = -2.0 * k; m2 = 0.0; break;       // Allpass
+    case 6: {                                               // Bell
+      double a = pow(10.0, (double)c.gain / 40.0);
+      k = 1.0 / ((double)c.q * a);
+      m0 = 1.0; m1 = k * (a * a - 1.0); m2 = 0.0;
+    } break;
+    case 7: {                                               // Lowshelf
+      double a = pow(10.0, (double)c.gain / 40.0);
+      g = g / sqrt(a);
+      m0 = 1.0; m1 = k * (a - 1.0); m2 = a * a - 1.0;
+    } break;
+    default: {                                              // Highshelf
+      double a = pow(10.0, (double)c.gain / 40.0);
+      g = g * sqrt(a);
+      m0 = a * a; m1 = k * (1.0 - a) * a; m2 = 1.0 - a * a;
+    } break;
+  }
+  c.a1 = 1.0 / (1.0 + g * (g + k));
+  c.a2 = g * c.a1;
+  c.a3 = g * c.a2;
+  c.m0 = m0; c.m1 = m1; c.m2 = m2;
+  return true;
+}
+// BiquadFilterCoefficients::set  :127-150
+DEV bool biquad_set(PgBiquadCoef& c, int type, uint32_t sr, float cutoff, float q, float gain) {
+  if (c.type != type || c.sample_rate != sr || c.cutoff != cutoff || c.q != q || c.gain != gain) {
+    c.type = type; c.sample_rate = sr; c.cutoff = cutoff; c.q = q; c.gain = gain;
+    return biquad_apply(c);
+  }
+  return true;
+}
+// BiquadFilter::process_sample :314-322
+DEV double biquad_tick(const PgBiquadCoef& c, double& ic1eq, double& ic2eq, double input) {
+  double v0 = input;
+  double v3 = v0 - ic2eq;
+  double v1 = c.a1 * ic1eq + c.a2 * v3;
+  double v2 = ic2eq + c.a2 * ic1eq + c.a3 * v3;
+  ic1eq = 2.0 * v1 - ic1eq;
+  ic2eq = 2.0 * v2 - ic2eq;
+  return c.m0 * v0 + c.m1 * v1 + c.m2 * v2;
+}
+
+// FilterEffectType {Lowpass, Bandpass, Bandstop, Highpass} -> BiquadFilterType  src/effect/filter.rs:33-41
+DEV int filter_to_biquad(int t) { return t == 0 ? 0 : (t == 1 ? 2 : (t == 2 ? 3 : 1)); }
+// DelayEffectFilterType / ChorusEffectFilterType are SvfFilterType {Lowpass, Highpass, Bandpass}
+DEV int delay_to_svf(int v) { return v == 0 ? 0 : (v == 1 ? 1 : 2); }
+
+// src/utils/dsp/filters/svf.rs:137-168
+DEV bool svf_apply(PgSvfCoef& c) {
+  if (c.sample_rate == 0) return false;
+  if (c.resonance < 0.0f || c.resonance > 1.0f) return false;
+  if (c.cutoff > (float)c.sample_rate / 2.0f) return false;
+  c.g = tan(F64_PI * (double)c.cutoff / (double)c.sample_rate);
+  c.k = fmax(2.0 * (1.0 - (double)c.resonance * 0.97), 0.03);
+  c.a1 = 1.0 / (1.0 + c.g * (c.g + c.k));
+  c.a2 = c.g * c.a1;
+  c.a3 = c.g * c.a2;
+  return true;
+}
+DEV bool svf_set(PgSvfCoef& c, int type, uint32_t sr, float cutoff, float res) {  // :115-134
+  if (c.type != type || c.sample_rate != sr || c.cutoff != cutoff || c.resonance != res) {
+    c.type = type; c.sample_rate = sr; c.cutoff = cutoff; c.resonance = res;
+    return svf_apply(c);
+  }
+  return true;
+}
+DEV double svf_tick(const PgSvfCoef& c, double& ic1eq, double& ic2eq, double input) {  // :211-222
+  double v3 = input - ic2eq;
+  double v1 = c.a1 * ic1eq + c.a2 * v3;
+  double v2 = ic2eq + c.a2 * ic1eq + c.a3 * v3;
+  ic1eq = 2.0 * v1 - ic1eq;
+  ic2eq = 2.0 * v2 - ic2eq;
+  if (c.type == 0) return v2;            // Lowpass
+  if (c.type == 2) return v1;            // Bandpass
+  return input - c.k * v1 - v2;          // Highpass
+}
+// src/utils/dsp/filters/dc.rs:84-88
+DEV double dc_tick(PgDc& d, double sample) {
+  d.y1 = sample - d.x1 + d.r * d.y1;
+  d.x1 = sample;
+  return d.y1;
+}
+DEV double dc_r(double hz, uint32_t sr) { return 1.0 - (F64_TAU * hz / (double)sr); }  // :54-61
+
+// src/utils/dsp/lfo.rs
+DEV float sine_approx(float x) {  // :9-19
+  const float B = 4.0f / F32_PI;
+  const float C = -4.0f / (F32_PI * F32_PI);
+  const float P = 0.225f;
+  float y = B * x + C * x * fabsf(x);
+  return P * (y * fabsf(y) - y) + y;
+}
+DEV float lfo_value(const PgLfo& l) {  // :122-152 (deterministic shapes)
+  float ph = l.phase;
+  switch (l.waveform) {
+    case 0: { float p = (ph < 0.5f) ? ph * F32_TAU : (ph - 1.0f) * F32_TAU; return sine_approx(p); }
+    case 1: return (ph < 0.25f) ? ph * 4.0f : ((ph < 0.75f) ? 2.0f - ph * 4.0f : ph * 4.0f - 4.0f);
+    case 2: return ph * 2.0f - 1.0f;
+    case 3: return 1.0f - ph * 2.0f;
+    case 4: return (ph < 0.5f) ? 1.0f : -1.0f;
+    default: return 0.0f;
+  }
+}
+DEV float lfo_run(PgLfo& l) {  // :122-169, :234-239
+  float v = lfo_value(l);
+  l.phase += l.phase_inc;
+  if (l.phase >= 1.0f) l.phase -= 1.0f;
+  return v;
+}
+DEV void lfo_set_rate(PgLfo& l, uint32_t sr, double rate) { l.phase_inc = (float)(rate / (double)sr); }  // :100-102
+DEV void lfo_set_phase_degrees(PgLfo& l, float p) {  // :105-114 (rem_euclid(1.0))
+  float q = p / F32_TAU;
+  float r = fmodf(q, 1.0f);
+  if (r < 0.0f) r += 1.0f;
+  l.phase = r;
+}
+// src/utils/dsp/envelope.rs:51-60
+DEV float env_run(float& current, float attack_coeff, float release_coeff, float input) {
+  if (input > current) current = input + attack_coeff * (current - input);
+  else current = input + release_coeff * (current - input);
+  return current;
+}
+DEV float env_coeff(float t, uint32_t sr) { return (t > 0.0f) ? expf(-1.0f / (t * (float)sr)) : 0.0f; }  // :27-42
+
+// workgroup max-reduction of |x| over an LDS buffer (max_abs_sample, src/utils/buffer.rs:150-173; order free)
+DEVO float wg_max_abs(const float* buf, int n, float* red /* LDS, >= blockDim.x/64 floats */) {
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(buf[i]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, red[w]);
+  __syncthreads();
+  return r;
+}
+
+}  // namespace pgd

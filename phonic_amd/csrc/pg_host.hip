@@ -1,0 +1,1057 @@
+// Host side of libphonic_gpu.so: the C ABI of include/phonic_gpu.h above the gfx950 kernels.
+//
+// Mirrors the reference's control plane only as far as the hot path needs it: graph construction as
+// `Player` does it (src/player.rs:519-602,773-822,893-939), the mixer's message/event bookkeeping
+// (src/source/mixed.rs:294-499,679-712, src/utils/event.rs) — all integer sample-time arithmetic, done
+// here on the host and handed to the kernels as per-launch command lists — and the parameter descriptor
+// logic (pg_params.h). All per-sample work happens in pg_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/phonic_gpu.h"
+#include "pg_dev.h"
+#include "pg_dsp_dev.h"
+#include "pg_params.h"
+
+using namespace pgd;
+using namespace pgh;
+
+size_t pg_unit_lds_bytes(uint32_t n_frames);
+hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream);
+hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
+                         const int32_t* order, int* audible_out, hipStream_t stream);
+
+// ---- errors ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                    \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) return set_error(PG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- device memory helpers ------------------------------------------------------------------------------
+template <class T>
+struct DeviceVec {  // grows by reallocation + device-to-device copy, so device-evolved state survives
+  T* d = nullptr;
+  size_t n = 0, cap = 0;
+  int ensure(size_t want) {
+    if (want <= cap) return PG_OK;
+    size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 16);
+    T* nd = nullptr;
+    HIP_TRY(hipMalloc((void**)&nd, ncap * sizeof(T)));
+    if (d && n) HIP_TRY(hipMemcpy(nd, d, n * sizeof(T), hipMemcpyDeviceToDevice));
+    if (d) (void)hipFree(d);
+    d = nd;
+    cap = ncap;
+    return PG_OK;
+  }
+  int push(const T& v, int* index) {
+    int rc = ensure(n + 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(d + n, &v, sizeof(T), hipMemcpyHostToDevice));
+    *index = (int)n++;
+    return PG_OK;
+  }
+  int upload(const std::vector<T>& h) {
+    int rc = ensure(h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    n = h.size();
+    return PG_OK;
+  }
+  void release() { if (d) (void)hipFree(d); d = nullptr; n = cap = 0; }
+};
+
+static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- smoother construction (constructors of src/utils/smoothing.rs + SmoothedParameterValue) --------------
+static PgSmooth make_smooth(const ParamSpec& p, float value, uint32_t sr) {
+  PgSmooth s;
+  memset(&s, 0, sizeof s);
+  s.comp = 44100.0f / (float)sr;  // set_sample_rate
+  s.current = s.target = value;
+  switch (p.smooth) {
+    case S_LIN:  // LinearSmoothedValue::default().with_step(step); init(v); set_sample_rate(sr)  :257-310,394-401
+      s.kind = SM_LIN; s.a = p.smooth_arg; s.b = s.a * s.comp; s.pending = 0; break;
+    case S_SPRING:  // SpringSmoothedValue::default().with_duration(d)  :434-474
+      s.kind = SM_SPRING; s.a = 5.5f / (float)(size_t)p.smooth_arg; s.b = 0.0f; break;
+    default:  // ExponentialSmoothedValue (inertia 1/256 unless stated)  :139,156-170
+      s.kind = SM_EXP; s.a = p.smooth_arg > 0.0f ? p.smooth_arg : 1.0f / 256.0f; break;
+  }
+  return s;
+}
+
+// distortion LUT (DistortionType::rms_compensation, src/effect/distortion.rs:88-122): pure function of the
+// shaper, built once per device on the host with the same f32 arithmetic as the reference's `new()`.
+static float h_dist_shape(int type, float sample, float drive) {
+  const float MAX_DRIVE = 4.0f, PI32 = 3.14159274101257324f;
+  float t = drive / MAX_DRIVE;
+  switch (type) {
+    case 0: { float gain = 1.0f + (t * t) * 14.0f; float x = sample * gain; if (x >= 1.0f) return 1.0f; if (x > -1.0f) { if (gain <= 1.0f) return sample; return (3.0f / 2.0f) * (x - (x * x * x) / 3.0f); } return -1.0f; }
+    case 1: { float gain = 1.0f + (t * t) * 24.0f; float th = 1.0f / gain; return h_clamp(sample, -th, th) * gain; }
+    case 2: { float curve = 0.6f * (t * t) + 0.4f * t; float gain = 1.0f + curve * 19.0f; float dc = std::exp((0.1f * sample) / (0.0253f * 1.68f)) - 1.0f; return 2.0f / PI32 * std::atan(dc * gain); }
+    case 3: { float gain = 1.0f + (1.0f - std::exp(-3.0f * t)) * 29.0f; float a = sample * gain; float s = (a < 0.0f) ? -1.0f * (1.0f - std::exp(-std::fabs(a))) : 1.0f * (1.0f - std::exp(-std::fabs(a))); return 1.5f * (s + std::fabs(s)); }
+    default: { float gain = 1.0f + (t * t) * 3.0f; float x = sample * gain; float th = 1.0f / gain; if (x > th || x < -th) return std::fabs(std::fmod(std::fabs(x - th), th * 4.0f) - th * 2.0f) - th; return x; }
+  }
+}
+static void build_dist_luts(float* luts /*[5][256]*/) {
+  const int N = 256;
+  static const float PARTIALS[5][2] = {{1.0f, 0.60f}, {2.7f, 0.25f}, {5.3f, 0.10f}, {9.1f, 0.03f}, {14.6f, 0.02f}};
+  float partials_peak = 0.0f;
+  for (int p = 0; p < 5; ++p) partials_peak += PARTIALS[p][1];
+  for (int type = 0; type < 5; ++type)
+    for (int li = 0; li < 256; ++li) {
+      float drive = (float)li / 255.0f * 4.0f;
+      float in_sq = 0.0f, out_sq = 0.0f;
+      for (int i = 0; i < N; ++i) {
+        float t = 6.28318548202514648f * ((float)i + 0.5f) / (float)N;
+        float s = 0.0f;
+        for (int p = 0; p < 5; ++p) s += PARTIALS[p][1] * std::sin(PARTIALS[p][0] * t);
+        float sample = s / partials_peak;
+        in_sq += sample * sample;
+        float o = h_dist_shape(type, sample, drive);
+        out_sq += o * o;
+      }
+      float in_rms = std::sqrt(in_sq / (float)N), out_rms = std::sqrt(out_sq / (float)N);
+      luts[type * 256 + li] = (out_rms > 1e-10f) ? in_rms / out_rms : 1.0f;
+    }
+}
+static std::map<int, float*> g_dist_luts;  // per device
+static int get_dist_luts(int device, const float** out) {
+  auto it = g_dist_luts.find(device);
+  if (it == g_dist_luts.end()) {
+    std::vector<float> h(5 * 256);
+    build_dist_luts(h.data());
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, h.size() * 4));
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    it = g_dist_luts.emplace(device, d).first;
+  }
+  *out = it->second;
+  return PG_OK;
+}
+
+// ---- effect instance: host mirror + construction of the device state ---------------------------------------
+struct HostFx {
+  int kind = 0;
+  std::vector<float> init_raw;   // raw value per parameter after `new()/with_parameters`
+  std::vector<float> target;     // shadow of the targets (for nothing on the hot path; introspection only)
+  bool with_params = false;
+  bool has_seeds = false;
+  uint32_t fpd_l = 16386, fpd_r = 16386;
+  double vib[16] = {0};
+  void* d_mem = nullptr;         // delay-line memory owned by this effect
+  size_t d_mem_bytes = 0;
+};
+
+static int host_fx_from_init(int kind, const pg_effect_init* init, HostFx& h) {
+  if (kind < 0 || kind >= PG_FX_KIND_COUNT) return set_error(PG_ERR_PARAMETER, "unknown effect kind %d", kind);
+  const KindInfo& k = KINDS[kind];
+  h.kind = kind;
+  h.init_raw.resize(k.n_params);
+  for (int i = 0; i < k.n_params; ++i) h.init_raw[i] = k.params[i].def;
+  if (init) {
+    if (init->n_params > PG_MAX_INIT_PARAMS) return set_error(PG_ERR_PARAMETER, "too many init parameters");
+    for (uint32_t i = 0; i < init->n_params; ++i) {
+      int pi = find_param(kind, init->fourcc[i]);
+      if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", init->fourcc[i], k.name);
+      const ParamSpec& p = k.params[pi];
+      float v = init->value[i];
+      if (p.type == PG_PARAM_FLOAT && !(v >= p.min && v <= p.max)) return set_error(PG_ERR_PARAMETER, "Value out of bounds for '%s'", p.name);
+      if (p.type == PG_PARAM_ENUM && !((int)v >= 0 && (int)v < p.n_values)) return set_error(PG_ERR_PARAMETER, "Invalid enum index for '%s'", p.name);
+      if (kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)v >= 5)
+        return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random draw from an OS-seeded RNG in the reference and are not supported");
+      h.init_raw[pi] = v;
+      h.with_params = true;
+    }
+    if (init->has_reverb_seeds) {
+      h.has_seeds = true;
+      h.fpd_l = init->reverb_fpd_l; h.fpd_r = init->reverb_fpd_r;
+      memcpy(h.vib, init->reverb_vib_phase, sizeof h.vib);
+    }
+  }
+  h.target = h.init_raw;
+  return PG_OK;
+}
+
+// State of the effect right after `Effect::initialize(sample_rate, 2, max_frames)`.
+static int build_fx_device_state(HostFx& h, uint32_t sr, int device, bool standalone, PgFx& fx) {
+  memset(&fx, 0, sizeof fx);
+  const KindInfo& k = KINDS[h.kind];
+  const ParamSpec* P = k.params;
+  const std::vector<float>& v = h.init_raw;
+  fx.kind = h.kind;
+  fx.sample_rate = sr;
+  fx.bypassed = 1;                         // EffectProcessor::new  effect.rs:26-33
+  fx.tail_counter = 0;
+  fx.silence_counter = PG_USIZE_MAX;
+  fx.standalone = standalone ? 1 : 0;
+  auto alloc = [&](size_t bytes) -> int {
+    h.d_mem_bytes = bytes;
+    HIP_TRY(hipMalloc(&h.d_mem, bytes));
+    HIP_TRY(hipMemset(h.d_mem, 0, bytes));
+    return PG_OK;
+  };
+  switch (h.kind) {
+    case PG_FX_GAIN: {  // gain.rs:123-141
+      PgGain& g = fx.u.gain;
+      g.gain = make_smooth(P[0], v[0], sr);
+      g.dc_mode = (int)v[1];
+      double hz = g.dc_mode == 1 ? 1.0 : (g.dc_mode == 3 ? 20.0 : 5.0);  // unwrap_or(Default)
+      for (int c = 0; c < 2; ++c) { g.dc[c].x1 = g.dc[c].y1 = 0.0; g.dc[c].r = dc_r(hz, sr); }
+    } break;
+    case PG_FX_PANNING: {
+      PgPan& p = fx.u.pan;
+      p.pan = make_smooth(P[0], v[0], sr);
+      p.width = make_smooth(P[1], v[1], sr);
+      p.invert_l = v[2] != 0.0f; p.invert_r = v[3] != 0.0f;
+    } break;
+    case PG_FX_FILTER: {  // filter.rs:87-115,141-164
+      PgFilter& f = fx.u.filter;
+      f.type = (int)v[0];
+      f.cutoff = make_smooth(P[1], v[1], sr);
+      f.q = make_smooth(P[2], v[2], sr);
+      memset(&f.coef, 0, sizeof f.coef);
+      biquad_set(f.coef, 0, 44100, 22050.0f, 0.707f, 0.0f);  // new(): coefficients for 44100 Hz (!)
+      if (h.with_params) {
+        float c = clampf(v[1], 20.0f, 44100.0f / 2.0f);
+        if (!biquad_set(f.coef, filter_to_biquad(f.type), 44100, c, v[2], 0.0f)) return set_error(PG_ERR_PARAMETER, "Invalid filter parameters");
+      }
+      float c = clampf(f.coef.cutoff, 20.0f, (float)sr / 2.0f);  // initialize(): set_cutoff only
+      if (f.coef.cutoff != c) { f.coef.cutoff = c; biquad_apply(f.coef); }
+    } break;
+    case PG_FX_EQ5: {  // eq5.rs:152-170,268-294
+      PgEq5& e = fx.u.eq5;
+      for (int i = 0; i < 5; ++i) {
+        e.gains[i] = make_smooth(P[i * 3], v[i * 3], sr);
+        e.freqs[i] = make_smooth(P[i * 3 + 1], v[i * 3 + 1], sr);
+        e.bws[i] = make_smooth(P[i * 3 + 2], v[i * 3 + 2], sr);
+        memset(&e.coef[i], 0, sizeof e.coef[i]);
+        float c = clampf(e.freqs[i].current, 20.0f, (float)sr / 2.0f);
+        int bt = i == 0 ? 7 : (i == 4 ? 8 : 6);
+        if (!biquad_set(e.coef[i], bt, sr, c, e.bws[i].current, e.gains[i].current)) return set_error(PG_ERR_PARAMETER, "Invalid EQ parameters");
+      }
+    } break;
+    case PG_FX_DELAY: {  // delay.rs:273-332
+      PgDelay& d = fx.u.delay;
+      d.mode = (int)v[P_DELAY_MODE]; d.filter_type = (int)v[P_DELAY_FTYPE]; d.lfo_shape = (int)v[P_DELAY_LFO_SHAPE];
+      d.delay_time = make_smooth(P[P_DELAY_TIME], v[P_DELAY_TIME], sr);
+      d.feedback = make_smooth(P[P_DELAY_FEEDBACK], v[P_DELAY_FEEDBACK], sr);
+      d.cutoff = make_smooth(P[P_DELAY_CUTOFF], v[P_DELAY_CUTOFF], sr);
+      d.drive = make_smooth(P[P_DELAY_DRIVE], v[P_DELAY_DRIVE], sr);
+      d.wet = make_smooth(P[P_DELAY_WET], v[P_DELAY_WET], sr);
+      d.width = make_smooth(P[P_DELAY_WIDTH], v[P_DELAY_WIDTH], sr);
+      d.lfo_rate = make_smooth(P[P_DELAY_LFO_RATE], v[P_DELAY_LFO_RATE], sr);
+      d.d_time = make_smooth(P[P_DELAY_D_TIME], v[P_DELAY_D_TIME], sr);
+      d.d_feedback = make_smooth(P[P_DELAY_D_FEEDBACK], v[P_DELAY_D_FEEDBACK], sr);
+      d.d_filter = make_smooth(P[P_DELAY_D_FILTER], v[P_DELAY_D_FILTER], sr);
+      size_t max_delay_samples = (size_t)std::ceil((4000.0f + 50.0f) * (float)sr / 1000.0f);
+      size_t frames = next_pow2(max_delay_samples + 4);
+      int rc = alloc(frames * 8 * 2);
+      if (rc) return rc;
+      d.line[0] = (double*)h.d_mem; d.line[1] = d.line[0] + frames;
+      d.mask = (uint32_t)(frames - 1);
+      memset(&d.coef, 0, sizeof d.coef);
+      if (!svf_set(d.coef, d.filter_type, sr, clampf(d.cutoff.target, 20.0f, (float)sr / 2.0f), 0.302f)) return set_error(PG_ERR_PARAMETER, "Invalid delay filter");
+      d.lfo.phase = 0.0f; d.lfo.phase_inc = (float)((double)d.lfo_rate.target / (double)sr); d.lfo.waveform = d.lfo_shape;
+      for (int c = 0; c < 2; ++c) { d.dc[c].x1 = d.dc[c].y1 = 0.0; d.dc[c].r = dc_r(5.0, sr); }
+    } break;
+    case PG_FX_REVERB: {  // reverb.rs:94-151,391-407
+      PgReverb& r = fx.u.reverb;
+      r.room = make_smooth(P[0], v[0], sr);
+      r.wet = make_smooth(P[1], v[1], sr);
+      r.fpd_l = h.fpd_l; r.fpd_r = h.fpd_r;
+      static const size_t sizes[8] = {8111, 7511, 7311, 6911, 6311, 6111, 5511, 4911};
+      static const double depths[8] = {0.003251, 0.002999, 0.002917, 0.002749, 0.002503, 0.002423, 0.002146, 0.002088};
+      static const size_t apsizes[4] = {4511, 4311, 3911, 3311};
+      size_t total = 0;
+      for (int i = 0; i < 8; ++i) total += (sizes[i] + 1) * 2;
+      for (int i = 0; i < 4; ++i) total += apsizes[i] * 2;
+      total += 4096 * 2;  // DelayLine::new(3111) -> next_power_of_two
+      int rc = alloc(total * 8);
+      if (rc) return rc;
+      double* p = (double*)h.d_mem;
+      for (int i = 0; i < 8; ++i) {
+        PgReverbLine& l = r.line[i];
+        l.buf = p; p += (sizes[i] + 1) * 2;
+        l.frames = (uint32_t)(sizes[i] + 1); l.count = 1; l.delay = 1;
+        l.depth = depths[i];
+        l.vib_phase[0] = h.vib[i * 2]; l.vib_phase[1] = h.vib[i * 2 + 1];
+      }
+      for (int i = 0; i < 4; ++i) { r.ap[i].buf = p; p += apsizes[i] * 2; r.ap[i].frames = (uint32_t)apsizes[i]; r.ap[i].delay = 0; r.ap[i].write_pos = 0; }
+      r.pre = p; r.pre_mask = 4095; r.pre_write_pos = 0;
+    } break;
+    case PG_FX_CHORUS: {  // chorus.rs:263-309
+      PgChorus& c = fx.u.chorus;
+      c.rate = make_smooth(P[P_CHORUS_RATE], v[P_CHORUS_RATE], sr);
+      c.depth = make_smooth(P[P_CHORUS_DEPTH], v[P_CHORUS_DEPTH], sr);
+      c.feedback = make_smooth(P[P_CHORUS_FEEDBACK], v[P_CHORUS_FEEDBACK], sr);
+      c.delay = make_smooth(P[P_CHORUS_DELAY], v[P_CHORUS_DELAY], sr);
+      c.wet = make_smooth(P[P_CHORUS_WET], v[P_CHORUS_WET], sr);
+      c.phase = make_smooth(P[P_CHORUS_PHASE], v[P_CHORUS_PHASE], sr);
+      c.filter_type = (int)v[P_CHORUS_FTYPE];
+      c.freq = make_smooth(P[P_CHORUS_FREQ], v[P_CHORUS_FREQ], sr);
+      c.res = make_smooth(P[P_CHORUS_RES], v[P_CHORUS_RES], sr);
+      c.lfo_range = 256.0f * ((float)sr / 44100.0f);
+      size_t max_depth = (size_t)std::ceil(c.lfo_range);
+      size_t max_delay = (size_t)std::ceil(100.0f * (float)sr / 1000.0f);
+      size_t frames = next_pow2(2 + max_delay + 2 * max_depth + 1);
+      int rc = alloc(frames * 8 * 2);
+      if (rc) return rc;
+      c.line[0] = (double*)h.d_mem; c.line[1] = c.line[0] + frames;
+      c.mask = (uint32_t)(frames - 1);
+      memset(&c.coef, 0, sizeof c.coef);
+      if (!svf_set(c.coef, c.filter_type, sr, clampf(c.freq.target, 20.0f, (float)sr / 2.0f), c.res.target)) return set_error(PG_ERR_PARAMETER, "Invalid chorus filter");
+      c.current_phase = 0.0;  // reset() :201-221
+      for (int i = 0; i < 2; ++i) { c.osc[i].phase = 0.0f; c.osc[i].waveform = 0; lfo_set_rate(c.osc[i], sr, (double)c.rate.current); }
+      lfo_set_phase_degrees(c.osc[0], (float)c.current_phase);
+      lfo_set_phase_degrees(c.osc[1], (float)(c.current_phase + (double)c.phase.current));
+    } break;
+    case PG_FX_COMPRESSOR: {  // compressor.rs:196-228
+      PgComp& c = fx.u.comp;
+      c.threshold = v[0]; c.ratio = v[1]; c.knee = v[2]; c.attack = v[3]; c.release = v[4];
+      c.makeup = make_smooth(P[5], v[5], sr);
+      c.lookahead = v[6];
+      c.env_attack = env_coeff(c.attack, sr); c.env_release = env_coeff(c.release, sr);
+      c.env_current = c.ratio >= 20.0f ? -120.0f : 0.0f;
+      size_t maxf = next_pow2((size_t)std::ceil(0.2f * (float)sr) + 1);
+      int rc = alloc(maxf * 2 * 8);
+      if (rc) return rc;
+      c.line = (double*)h.d_mem; c.line_frames = (uint32_t)maxf;
+      c.delay_frames = (uint32_t)f2u64(std::ceil(c.lookahead * (float)sr));
+      c.mask = c.delay_frames > 0 ? (uint32_t)(next_pow2(c.delay_frames) - 1) : 0;
+      c.write_pos = 0; c.peak_pos = 0; c.peak_value = 0.0;
+    } break;
+    case PG_FX_GATE: {  // gate.rs:122-145
+      PgGate& g = fx.u.gate;
+      g.threshold = v[0]; g.attack = v[1]; g.hold = v[2]; g.release = v[3]; g.range = v[4];
+      g.env_attack = env_coeff(g.attack, sr); g.env_release = env_coeff(g.release, sr);
+      g.env_current = -120.0f; g.hold_counter = 0; g.gate_gain_db = g.range;
+      g.attack_coeff = std::exp(-1.0f / (g.attack * (float)sr));
+      g.release_coeff = std::exp(-1.0f / (g.release * (float)sr));
+    } break;
+    default: {  // distortion.rs:232-256,314-324
+      PgDist& d = fx.u.dist;
+      d.type = (int)v[0];
+      d.drive = make_smooth(P[1], v[1], sr);
+      d.mix = make_smooth(P[2], v[2], sr);
+      int rc = get_dist_luts(device, &d.luts);
+      if (rc) return rc;
+    } break;
+  }
+  return PG_OK;
+}
+
+// ---- the graph --------------------------------------------------------------------------------------------
+struct Event {  // MixerEvent (src/source/mixed.rs:47-109) resolved to a device command
+  uint64_t sample_time;
+  uint64_t seq;
+  PgCmd cmd;  // unit/frame filled per launch
+  int mixer;  // owning mixer (0 = main)
+};
+
+struct HostVoice { int mixer; int dev_index; uint64_t start_time; void* d_pcm; };
+struct HostMixer {
+  int unit_slot = -1;              // sub-mixer unit; for the main mixer: the bus unit
+  std::vector<int> voices;         // voice ids in playing order (sorted by start time, insert-before-equal)
+  std::vector<int> fx;             // effect ids in chain order
+  std::vector<Event> events;       // sorted by sample_time (stable: insert after equal, event.rs:31-38)
+  std::vector<PgCmd> messages;     // StopSource messages: applied at the start of the next write
+};
+
+struct pg_graph {
+  int device = 0;
+  uint32_t sample_rate = 48000, channels = 2;
+  size_t max_frames = 4096;
+  hipStream_t stream = nullptr;
+  bool failed = false;  // sticky: GuardedSource semantics
+  int fast = 1;
+  bool defer_bus = false;
+  // host mirrors
+  std::vector<HostMixer> mixers;        // [0] = main
+  std::vector<HostVoice> voices;
+  std::vector<std::unique_ptr<HostFx>> fx;
+  std::vector<int> fx_mixer;            // effect id -> mixer id
+  std::vector<int> source_unit_of_voice;  // main-mixer voices: unit slot
+  uint64_t event_seq = 0;
+  int main_active_voices = 0;           // feedback from the device (sync write only)
+  bool ever_had_main_voice = false;
+  // device tables
+  DeviceVec<PgUnit> d_units;
+  DeviceVec<PgVoice> d_voices;
+  DeviceVec<PgFx> d_fx;
+  DeviceVec<int32_t> d_voice_index, d_fx_index, d_order;
+  DeviceVec<PgCmd> d_cmds;
+  std::vector<PgUnit> h_units;          // topology part only (kind, offsets); state fields are device-owned
+  bool topo_dirty = true;
+  std::vector<int32_t> order;           // launch order: sub-mixer units, then main-mixer source units by start time
+  int n_graph_units = 0;                // units excluding bus
+  // buffers
+  float* d_unit_out = nullptr; size_t unit_out_rows = 0;
+  float* d_partial = nullptr; size_t partial_rows = 0;
+  float* d_bus = nullptr;               // [2*max_frames + 4]
+  int* d_audible = nullptr;
+  float* h_pinned = nullptr;
+  uint32_t stride = 0;
+  // timing of the dominant kernel
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+};
+
+static int graph_fail(pg_graph* g, int code) { g->failed = true; return code; }
+
+// topology tables: unit -> voices / effects. Unit slots are stable; PgUnit state fields live on the device and are
+// preserved: only (kind, n_voices, voice_off, n_fx, fx_off) are patched.
+__global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  units[i].kind = topo[i].kind;
+  units[i].n_voices = topo[i].n_voices; units[i].voice_off = topo[i].voice_off;
+  units[i].n_fx = topo[i].n_fx; units[i].fx_off = topo[i].fx_off;
+}
+__global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int active = 0;
+    for (int i = 0; i < n; ++i) active += voices[idx[i]].active ? 1 : 0;
+    ((int*)status)[0] = active;
+  }
+}
+
+static int new_unit(pg_graph* g, int kind) {
+  PgUnit u;
+  memset(&u, 0, sizeof u);
+  u.kind = kind;
+  u.effects_bypassed = 1;  // MixedSource::new: effects_bypassed = true (mixed.rs:230)
+  int idx = -1;
+  if (g->d_units.push(u, &idx)) return -1;
+  g->h_units.push_back(u);
+  g->topo_dirty = true;
+  return idx;
+}
+
+static int rebuild_topology(pg_graph* g) {
+  std::vector<int32_t> vidx, fidx;
+  std::vector<PgUnit> topo = g->h_units;
+  // sub-mixers and the bus
+  for (size_t m = 0; m < g->mixers.size(); ++m) {
+    HostMixer& mx = g->mixers[m];
+    PgUnit& u = topo[mx.unit_slot];
+    u.fx_off = (int)fidx.size(); u.n_fx = (int)mx.fx.size();
+    for (int f : mx.fx) fidx.push_back(f);
+    if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
+    u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
+    for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
+  }
+  // main-mixer sources: one unit each
+  g->order.clear();
+  for (size_t m = 1; m < g->mixers.size(); ++m) g->order.push_back(g->mixers[m].unit_slot);
+  for (int v : g->mixers[0].voices) {
+    int slot = g->source_unit_of_voice[v];
+    PgUnit& u = topo[slot];
+    u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
+    vidx.push_back(g->voices[v].dev_index);
+    g->order.push_back(slot);
+  }
+  g->n_graph_units = (int)g->order.size();
+  g->h_units = topo;
+  int rc;
+  if ((rc = g->d_voice_index.upload(vidx))) return rc;
+  if ((rc = g->d_fx_index.upload(fidx))) return rc;
+  if ((rc = g->d_order.upload(g->order))) return rc;
+  // patch topology fields
+  DeviceVec<PgUnit> tmp;
+  if ((rc = tmp.upload(topo))) return rc;
+  int n = (int)topo.size();
+  hipLaunchKernelGGL(pg_patch_units_kernel, dim3((n + 63) / 64), dim3(64), 0, g->stream, g->d_units.d, tmp.d, n);
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  tmp.release();
+  // per-unit output rows
+  size_t rows = std::max<size_t>(g->n_graph_units, 1);
+  if (rows > g->unit_out_rows) {
+    if (g->d_unit_out) (void)hipFree(g->d_unit_out);
+    size_t nr = std::max(rows, g->unit_out_rows * 2);
+    HIP_TRY(hipMalloc((void**)&g->d_unit_out, nr * g->stride * sizeof(float)));
+    g->unit_out_rows = nr;
+  }
+  size_t prow = (rows + 31) / 32;
+  if (prow > g->partial_rows) {
+    if (g->d_partial) (void)hipFree(g->d_partial);
+    HIP_TRY(hipMalloc((void**)&g->d_partial, prow * 2 * g->stride * sizeof(float)));
+    g->partial_rows = prow * 2;
+  }
+  g->topo_dirty = false;
+  return PG_OK;
+}
+
+extern "C" {
+
+const char* pg_last_error_message(void) { return g_last_error.c_str(); }
+int pg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -PG_ERR_DEVICE;
+  return n;
+}
+const char* pg_effect_kind_name(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].name : nullptr; }
+int pg_effect_kind_weight(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].weight : -1; }
+int pg_effect_kind_param_count(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].n_params : -1; }
+int pg_effect_kind_param(int kind, int index, pg_param_desc* out) {
+  if (kind < 0 || kind >= PG_FX_KIND_COUNT || index < 0 || index >= KINDS[kind].n_params) return set_error(PG_ERR_NOT_FOUND, "no such parameter");
+  const ParamSpec& p = KINDS[kind].params[index];
+  out->fourcc = p.fourcc; out->type = p.type; out->min = p.min; out->max = p.max; out->default_value = p.def;
+  out->scaling = p.scaling; out->scaling_arg0 = p.sa; out->scaling_arg1 = p.sb; out->n_values = p.n_values; out->name = p.name;
+  return PG_OK;
+}
+void pg_voice_options_default(pg_voice_options* o) {  // FilePlaybackOptions::default()  file.rs:94-112
+  memset(o, 0, sizeof *o);
+  o->volume = 1.0f; o->panning = 0.0f; o->speed = 1.0;
+  o->fade_in_seconds = 0.0f; o->fade_out_seconds = 0.05f;
+}
+
+// ---- graph --------------------------------------------------------------------------------------------------
+pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, int device) {
+  if (channel_count != 2) { set_error(PG_ERR_PARAMETER, "only stereo graphs are supported (reference default: enforce_stereo_playback)"); return nullptr; }
+  if (sample_rate == 0 || max_frames == 0 || max_frames > PG_MAX_FRAMES) { set_error(PG_ERR_PARAMETER, "max_frames must be in 1..=%d", PG_MAX_FRAMES); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipSetDevice(%d) failed — phonic_gpu needs an AMD GPU", device); return nullptr; }
+  std::unique_ptr<pg_graph> g(new pg_graph());
+  g->device = device; g->sample_rate = sample_rate; g->channels = 2; g->max_frames = max_frames;
+  g->stride = (uint32_t)(2 * max_frames);
+  if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
+  if (hipMalloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || hipMalloc((void**)&g->d_audible, 16) != hipSuccess ||
+      hipHostMalloc((void**)&g->h_pinned, (g->stride + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    set_error(PG_ERR_DEVICE, "device allocation failed");
+    return nullptr;
+  }
+  (void)hipMemset(g->d_audible, 0, 16);
+  g->mixers.emplace_back();
+  g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
+  if (g->mixers[0].unit_slot < 0) return nullptr;
+  return g.release();
+}
+
+void pg_graph_destroy(pg_graph* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  (void)hipStreamSynchronize(g->stream);
+  for (auto& v : g->voices) if (v.d_pcm) (void)hipFree(v.d_pcm);
+  for (auto& f : g->fx) if (f->d_mem) (void)hipFree(f->d_mem);
+  g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
+  g->d_cmds.release();
+  if (g->d_unit_out) (void)hipFree(g->d_unit_out);
+  if (g->d_partial) (void)hipFree(g->d_partial);
+  if (g->d_bus) (void)hipFree(g->d_bus);
+  if (g->d_audible) (void)hipFree(g->d_audible);
+  if (g->h_pinned) (void)hipHostFree(g->h_pinned);
+  for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+
+int pg_graph_add_mixer(pg_graph* g) {
+  (void)hipSetDevice(g->device);
+  int slot = new_unit(g, UNIT_SUBMIXER);
+  if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
+  g->mixers.emplace_back();
+  g->mixers.back().unit_slot = slot;
+  return (int)g->mixers.size() - 1;
+}
+
+int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init) {
+  (void)hipSetDevice(g->device);
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  std::unique_ptr<HostFx> h(new HostFx());
+  int rc = host_fx_from_init(kind, init, *h);
+  if (rc) return -rc;
+  PgFx fx;
+  rc = build_fx_device_state(*h, g->sample_rate, g->device, false, fx);
+  if (rc) return -rc;
+  int idx = -1;
+  rc = g->d_fx.push(fx, &idx);
+  if (rc) return -graph_fail(g, rc);
+  g->fx.push_back(std::move(h));
+  g->fx_mixer.push_back(mixer_id);
+  g->mixers[mixer_id].fx.push_back(idx);
+  g->topo_dirty = true;
+  return idx;
+}
+
+int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
+                       const pg_voice_options* opt) {
+  (void)hipSetDevice(g->device);
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  // AudioFileBuffer::new validation (file/buffer.rs:22-60)
+  if (src_rate == 0) return -set_error(PG_ERR_PARAMETER, "file buffer sample rate must be > 0");
+  if (src_channels != 1 && src_channels != 2) return -set_error(PG_ERR_PARAMETER, "only mono and stereo file buffers are supported");
+  if (n_frames == 0 || !pcm) return -set_error(PG_ERR_PARAMETER, "file buffer must not be empty");
+  pg_voice_options def;
+  if (!opt) { pg_voice_options_default(&def); opt = &def; }
+  if (!(opt->speed > 0.0)) return -set_error(PG_ERR_PARAMETER, "speed must be > 0");
+  if (opt->volume < 0.0f || opt->panning < -1.0f || opt->panning > 1.0f) return -set_error(PG_ERR_PARAMETER, "invalid volume or panning");
+  PgVoice v;
+  memset(&v, 0, sizeof v);
+  size_t n_samples = n_frames * src_channels;
+  void* d_pcm = nullptr;
+  if (hipMalloc(&d_pcm, n_samples * sizeof(float)) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "hipMalloc(pcm) failed"));
+  if (hipMemcpy(d_pcm, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pcm upload failed"));
+  v.pcm = (const float*)d_pcm;
+  v.n_samples = n_samples; v.channels = src_channels; v.src_rate = src_rate; v.out_rate = g->sample_rate;
+  // FileSourceImpl::new: resampler file_rate -> (out_rate / speed) as u32  (file/common.rs:78-86); ratio = (in/out as f64) as f32 (cubic.rs:164)
+  uint32_t res_out = (uint32_t)d2u64((double)g->sample_rate / opt->speed);
+  if (res_out == 0) return -set_error(PG_ERR_PARAMETER, "Invalid resampling ratio");
+  v.ratio = (float)((double)src_rate / (double)res_out);
+  if (!(v.ratio > 0.0f) || v.ratio > 64.0f) return -set_error(PG_ERR_PARAMETER, "Invalid resampling ratio");
+  // repeat / loop range (preloaded.rs:89-104): no embedded loop points (decoding is out of scope)
+  v.repeat = opt->has_repeat ? opt->repeat : 0;
+  v.repeat_count = v.repeat;
+  if (opt->has_loop_range) {
+    uint64_t fc = n_frames;
+    v.has_loop = 1;
+    v.loop_start = std::min<uint64_t>(opt->loop_start, fc > 0 ? fc - 1 : 0);
+    v.loop_end = std::min<uint64_t>(opt->loop_end, fc);
+    if (v.loop_start >= v.loop_end) return -set_error(PG_ERR_PARAMETER, "file buffer loop range is out of bounds");
+  }
+  // VolumeFader::new + optional fade-in (file/common.rs:69-75, fader.rs:36-91)
+  v.fader_state = 0; v.fader_current = 1.0f; v.fader_target = 1.0f; v.fader_inertia = 1.0f;
+  if (opt->fade_in_seconds > 0.0f) {
+    v.fader_state = 1; v.fader_current = 0.0f; v.fader_target = 1.0f;
+    float samples_duration = (float)g->sample_rate * opt->fade_in_seconds / 4.605f;
+    v.fader_inertia = 1.0f - std::exp(-1.0f / samples_duration);
+  }
+  v.fade_out_seconds = opt->fade_out_seconds;
+  // AmplifiedSource / PannedSource: ExponentialSmoothedValue::new(value, source.sample_rate())
+  ParamSpec exp_spec = {0, PG_PARAM_FLOAT, 0, 0, 0, 0, 0, 0, 0, "", S_EXP, 0};
+  v.volume = make_smooth(exp_spec, opt->volume, g->sample_rate);
+  v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
+  v.start_time = opt->start_time;
+  v.active = 1;
+  int dev_index = -1;
+  int rc = g->d_voices.push(v, &dev_index);
+  if (rc) return -graph_fail(g, rc);
+  int id = (int)g->voices.size();
+  g->voices.push_back(HostVoice{mixer_id, dev_index, opt->start_time, d_pcm});
+  g->source_unit_of_voice.push_back(-1);
+  // AddSource: sort by start time, insert BEFORE equal start times (mixed.rs:324-329)
+  HostMixer& mx = g->mixers[mixer_id];
+  size_t pos = 0;
+  while (pos < mx.voices.size() && g->voices[mx.voices[pos]].start_time < opt->start_time) ++pos;
+  mx.voices.insert(mx.voices.begin() + pos, id);
+  if (mixer_id == 0) {
+    int slot = new_unit(g, UNIT_SOURCE);
+    if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
+    g->source_unit_of_voice[id] = slot;
+    g->main_active_voices += 1;
+    g->ever_had_main_voice = true;
+  }
+  g->topo_dirty = true;
+  return id;
+}
+
+static int push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
+  HostMixer& mx = g->mixers[mixer];
+  if (mx.events.size() >= 4096) return set_error(PG_ERR_QUEUE_FULL, "mixer's event queue is full");  // EVENTS_CAPACITY mixed.rs:236
+  Event e{sample_time, g->event_seq++, cmd, mixer};
+  size_t pos = 0;  // partition_point(|e| e.sample_time <= sample_time)  event.rs:31-38
+  while (pos < mx.events.size() && mx.events[pos].sample_time <= sample_time) ++pos;
+  mx.events.insert(mx.events.begin() + pos, e);
+  return PG_OK;
+}
+
+int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
+  if (effect_id < 0 || effect_id >= (int)g->fx.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  HostFx& h = *g->fx[effect_id];
+  int pi = find_param(h.kind, fourcc);
+  if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[h.kind].name);
+  float raw;
+  if (!resolve_update(KINDS[h.kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;  // logged + ignored in the reference
+  if (h.kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
+    return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
+  h.target[pi] = raw;
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_FX_PARAM; c.target = effect_id; c.param = pi; c.value = raw;
+  return push_event(g, g->fx_mixer[effect_id], sample_time, c);
+}
+int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time) {
+  if (effect_id < 0 || effect_id >= (int)g->fx.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  int kind = g->fx[effect_id]->kind;
+  if (kind != PG_FX_DELAY && kind != PG_FX_REVERB && kind != PG_FX_CHORUS)
+    return set_error(PG_ERR_PARAMETER, "%sEffect: Invalid/unknown message payload", KINDS[kind].name);
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_FX_RESET; c.target = effect_id;
+  return push_event(g, g->fx_mixer[effect_id], sample_time, c);
+}
+static int voice_event(pg_graph* g, int voice_id, int type, float value, uint64_t sample_time) {
+  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = type; c.target = g->voices[voice_id].dev_index; c.value = value;
+  c.param = voice_id;
+  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+}
+int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_VOLUME, volume, sample_time); }
+int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_PAN, panning, sample_time); }
+int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // MixerMessage::StopSource (mixed.rs:389-400): not an event
+  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_VOICE_STOP; c.target = g->voices[voice_id].dev_index; c.value64 = sample_time; c.param = voice_id;
+  g->mixers[g->voices[voice_id].mixer].messages.push_back(c);
+  return PG_OK;
+}
+
+int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
+int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; return PG_OK; }
+int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
+int pg_graph_synchronize(pg_graph* g) {
+  (void)hipSetDevice(g->device);
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  return PG_OK;
+}
+int pg_graph_is_voice_playing(pg_graph* g, int voice_id) {
+  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return 0;
+  (void)hipSetDevice(g->device);
+  (void)hipStreamSynchronize(g->stream);
+  PgVoice v;
+  if (hipMemcpy(&v, g->d_voices.d + g->voices[voice_id].dev_index, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return v.active && !v.finished;
+}
+double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
+  (void)hipSetDevice(g->device);
+  (void)hipStreamSynchronize(g->stream);
+  double total = 0.0;
+  for (size_t i = 0; i < g->ev_used; ++i) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, g->ev_pool[i].first, g->ev_pool[i].second) == hipSuccess) total += ms;
+  }
+  if (launches) *launches = g->ev_used;
+  double avg = g->ev_used ? total / (double)g->ev_used : 0.0;
+  if (reset) g->ev_used = 0;
+  return avg;
+}
+
+// One launch round: all graph units for frames [t0, t0+n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
+static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds) {
+  int rc;
+  if (!cmds.empty()) {  // rare (parameter automation): drain the stream so the previous round no longer reads the command table
+    HIP_TRY(hipStreamSynchronize(stream));
+    if ((rc = g->d_cmds.upload(cmds))) return rc;
+  }
+  PgLaunch L;
+  memset(&L, 0, sizeof L);
+  L.units = g->d_units.d; L.voices = g->d_voices.d; L.fx = g->d_fx.d;
+  L.voice_index = g->d_voice_index.d; L.fx_index = g->d_fx_index.d;
+  L.cmds = g->d_cmds.d; L.n_cmds = (int)cmds.size();
+  L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
+  L.unit_out = g->d_unit_out; L.out_stride = g->stride;
+  L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
+  bool timed = g->ev_used < 8192 && L.n_units > 0;
+  if (timed && g->ev_used >= g->ev_pool.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g->ev_pool.emplace_back(a, b);
+  }
+  if (timed) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
+  HIP_TRY(pg_launch_units(L, stream));
+  if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+  HIP_TRY(pg_launch_mix(g->d_unit_out, g->stride, g->n_graph_units, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d, g->d_audible, stream));
+  if (run_bus && !g->mixers[0].fx.empty()) {
+    PgLaunch B = L;
+    B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
+    B.bus = d_dst; B.bus_audible = g->d_audible;
+    HIP_TRY(pg_launch_units(B, stream));
+  }
+  return PG_OK;
+}
+
+// MixedSource::write of the main mixer (src/source/mixed.rs:659-719)
+static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream) {
+  if (g->failed) return 0;
+  if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
+  (void)hipSetDevice(g->device);
+  if (g->topo_dirty && rebuild_topology(g)) { g->failed = true; return 0; }
+  // "Return early and avoid touching the buffer if there's nothing to do" (:664-670)
+  bool any_events = false;
+  for (auto& m : g->mixers) any_events |= !m.events.empty();
+  bool main_sources_empty = g->main_active_voices == 0;
+  if (main_sources_empty && g->mixers[0].fx.empty() && g->mixers.size() == 1 && g->mixers[0].events.empty()) return 0;
+  (void)any_events;
+  const uint64_t frames = n_samples / 2;
+  uint64_t done = 0;
+  bool first = true;
+  while (done < frames) {
+    const uint64_t now = pos + done;
+    // main-mixer events due now apply at frame 0 of this round; the next main event bounds the round (:679-693)
+    std::vector<PgCmd> cmds;
+    HostMixer& main = g->mixers[0];
+    while (!main.events.empty() && main.events.front().sample_time <= now) {
+      PgCmd c = main.events.front().cmd;
+      c.frame = 0;
+      c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET) ? main.unit_slot : g->source_unit_of_voice[c.param];
+      cmds.push_back(c);
+      main.events.erase(main.events.begin());
+    }
+    uint64_t n = std::min<uint64_t>(frames - done, g->max_frames);
+    if (!main.events.empty()) n = std::min<uint64_t>(n, main.events.front().sample_time - now);
+    if (n == 0) continue;
+    // StopSource messages: processed by process_messages at the start of write (:294-499)
+    if (first) {
+      for (size_t m = 0; m < g->mixers.size(); ++m) {
+        for (PgCmd c : g->mixers[m].messages) {
+          c.frame = 0;
+          c.unit = m == 0 ? g->source_unit_of_voice[c.param] : g->mixers[m].unit_slot;
+          cmds.push_back(c);
+        }
+        g->mixers[m].messages.clear();
+      }
+      first = false;
+    }
+    // sub-mixer events inside [now, now+n): each sub-mixer splits its own block on the device
+    for (size_t m = 1; m < g->mixers.size(); ++m) {
+      HostMixer& mx = g->mixers[m];
+      while (!mx.events.empty() && mx.events.front().sample_time < now + n) {
+        PgCmd c = mx.events.front().cmd;
+        uint64_t t = mx.events.front().sample_time;
+        c.frame = t <= now ? 0u : (uint32_t)(t - now);
+        c.unit = mx.unit_slot;
+        cmds.push_back(c);
+        mx.events.erase(mx.events.begin());
+      }
+    }
+    // bus commands run in the bus launch; everything is sorted by (unit, frame), stable
+    std::stable_sort(cmds.begin(), cmds.end(), [](const PgCmd& a, const PgCmd& b) { return a.unit != b.unit ? a.unit < b.unit : a.frame < b.frame; });
+    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds)) { g->failed = true; return 0; }
+    done += n;
+  }
+  return n_samples;
+}
+
+size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
+  size_t w = graph_write_impl(g, d_out, n_samples, pos_in_frames, s);
+  if (!hip_stream && w) { if (hipStreamSynchronize(g->stream) != hipSuccess) { g->failed = true; return 0; } }
+  return w;
+}
+
+size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in_frames) {
+  if (g->failed) return 0;
+  (void)hipSetDevice(g->device);
+  size_t total = 0;
+  // the staging bus holds one chunk of max_frames; larger writes are split exactly like the reference's mix_buffer loop
+  size_t chunk_samples = g->stride;
+  size_t off = 0;
+  uint64_t pos = pos_in_frames;
+  while (off < n_samples) {
+    size_t n = std::min(chunk_samples, n_samples - off);
+    size_t w = graph_write_impl(g, g->d_bus, n, pos, g->stream);
+    if (w == 0) { if (g->failed) return 0; if (off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
+    // device feedback: how many main-mixer sources are still alive (transient sources are dropped when exhausted, :715)
+    int n_main = (int)g->mixers[0].voices.size();  // the main-mixer voices are the last n_main entries of the voice index table
+    hipLaunchKernelGGL(pg_status_kernel, dim3(1), dim3(64), 0, g->stream, g->d_voices.d, g->d_voice_index.d + (g->d_voice_index.n - (size_t)n_main), n_main,
+                       g->d_bus + g->stride);
+    if (hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipMemcpyAsync(g->h_pinned + g->stride, g->d_bus + g->stride, 4 * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipStreamSynchronize(g->stream) != hipSuccess) {
+      g->failed = true;
+      set_error(PG_ERR_DEVICE, "device failure in write: %s", hipGetErrorString(hipGetLastError()));
+      return 0;
+    }
+    memcpy(out + off, g->h_pinned, n * sizeof(float));
+    g->main_active_voices = ((int*)(g->h_pinned + g->stride))[0];
+    off += n; pos += n / 2; total += n;
+  }
+  return total;
+}
+
+int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
+  if (g->failed) return PG_ERR_DEVICE;
+  (void)hipSetDevice(g->device);
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
+  if (g->mixers[0].fx.empty()) return PG_OK;
+  if (g->topo_dirty && rebuild_topology(g)) return graph_fail(g, PG_ERR_DEVICE);
+  size_t frames = n_samples / 2, done = 0;
+  while (done < frames) {
+    uint32_t n = (uint32_t)std::min<size_t>(frames - done, g->max_frames);
+    PgLaunch B;
+    memset(&B, 0, sizeof B);
+    B.units = g->d_units.d; B.voices = g->d_voices.d; B.fx = g->d_fx.d;
+    B.voice_index = g->d_voice_index.d; B.fx_index = g->d_fx_index.d;
+    B.n_frames = n; B.pos = pos_in_frames + done; B.sample_rate = g->sample_rate; B.fast = g->fast;
+    B.n_units = 1; B.unit_base = g->mixers[0].unit_slot;
+    B.bus = d_bus + done * 2; B.bus_audible = nullptr;
+    HIP_TRY(pg_launch_units(B, s));
+    done += n;
+  }
+  return PG_OK;
+}
+
+// ---- standalone effect: a one-unit graph whose unit is UNIT_EFFECT -------------------------------------------
+struct pg_effect {
+  int kind = 0, device = 0;
+  HostFx host;
+  bool initialized = false;
+  uint32_t sample_rate = 0;
+  size_t max_frames = 0;
+  hipStream_t stream = nullptr;
+  PgUnit* d_unit = nullptr;
+  PgFx* d_fx = nullptr;
+  int32_t* d_fx_index = nullptr;
+  PgCmd* d_cmds = nullptr;
+  float* d_buf = nullptr;
+  std::vector<PgCmd> pending;
+};
+
+pg_effect* pg_effect_create(int kind, const pg_effect_init* init, int device) {
+  std::unique_ptr<pg_effect> e(new pg_effect());
+  e->kind = kind; e->device = device;
+  if (host_fx_from_init(kind, init, e->host)) return nullptr;
+  return e.release();
+}
+void pg_effect_destroy(pg_effect* e) {
+  if (!e) return;
+  if (e->initialized) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->d_unit); (void)hipFree(e->d_fx); (void)hipFree(e->d_fx_index); (void)hipFree(e->d_cmds); (void)hipFree(e->d_buf);
+    if (e->host.d_mem) (void)hipFree(e->host.d_mem);
+    (void)hipStreamDestroy(e->stream);
+  }
+  delete e;
+}
+int pg_effect_initialize(pg_effect* e, uint32_t sample_rate, size_t channel_count, size_t max_frames) {
+  if (e->initialized) return set_error(PG_ERR_STATE, "effect is already initialized");
+  if (channel_count != 2) return set_error(PG_ERR_PARAMETER, "%sEffect only supports stereo I/O", KINDS[e->kind].name);
+  if (sample_rate == 0 || max_frames == 0 || max_frames > PG_MAX_FRAMES) return set_error(PG_ERR_PARAMETER, "max_frames must be in 1..=%d", PG_MAX_FRAMES);
+  HIP_TRY(hipSetDevice(e->device));
+  PgFx fx;
+  int rc = build_fx_device_state(e->host, sample_rate, e->device, true, fx);
+  if (rc) return rc;
+  HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  PgUnit u;
+  memset(&u, 0, sizeof u);
+  u.kind = UNIT_EFFECT; u.n_fx = 1; u.fx_off = 0; u.effects_bypassed = 0;
+  int32_t zero = 0;
+  HIP_TRY(hipMalloc((void**)&e->d_unit, sizeof u));
+  HIP_TRY(hipMalloc((void**)&e->d_fx, sizeof fx));
+  HIP_TRY(hipMalloc((void**)&e->d_fx_index, 4));
+  HIP_TRY(hipMalloc((void**)&e->d_cmds, sizeof(PgCmd) * 64));
+  HIP_TRY(hipMalloc((void**)&e->d_buf, max_frames * 2 * sizeof(float)));
+  HIP_TRY(hipMemcpy(e->d_unit, &u, sizeof u, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_fx, &fx, sizeof fx, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_fx_index, &zero, 4, hipMemcpyHostToDevice));
+  e->sample_rate = sample_rate; e->max_frames = max_frames; e->initialized = true;
+  return PG_OK;
+}
+int pg_effect_process_started(pg_effect*) { return PG_OK; }  // no-ops for all stock effects (src/effect.rs:127-139)
+int pg_effect_process_stopped(pg_effect*) { return PG_OK; }
+
+static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t pos) {
+  HIP_TRY(hipSetDevice(e->device));
+  if (n_samples) HIP_TRY(hipMemcpyAsync(e->d_buf, host_buf, n_samples * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (!e->pending.empty()) HIP_TRY(hipMemcpyAsync(e->d_cmds, e->pending.data(), e->pending.size() * sizeof(PgCmd), hipMemcpyHostToDevice, e->stream));
+  PgLaunch L;
+  memset(&L, 0, sizeof L);
+  L.units = e->d_unit; L.fx = e->d_fx; L.fx_index = e->d_fx_index;
+  L.cmds = e->d_cmds; L.n_cmds = (int)e->pending.size();
+  L.n_units = 1; L.unit_base = 0; L.n_frames = (uint32_t)(n_samples / 2); L.pos = pos; L.sample_rate = e->sample_rate; L.fast = 1;
+  L.bus = e->d_buf;
+  HIP_TRY(pg_launch_units(L, e->stream));
+  if (n_samples) HIP_TRY(hipMemcpyAsync(host_buf, e->d_buf, n_samples * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->pending.clear();
+  return PG_OK;
+}
+int pg_effect_process(pg_effect* e, float* interleaved, size_t n_samples, uint64_t pos_in_frames) {
+  if (!e->initialized) return set_error(PG_ERR_STATE, "effect is not initialized");
+  if (n_samples % 2 != 0 || n_samples / 2 > e->max_frames) return set_error(PG_ERR_PARAMETER, "buffer must hold <= max_frames stereo frames");
+  if (n_samples == 0 && e->pending.empty()) return PG_OK;
+  return effect_run(e, interleaved, n_samples, pos_in_frames);
+}
+int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_normalized) {
+  int pi = find_param(e->kind, fourcc);
+  if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[e->kind].name);
+  float raw;
+  if (!resolve_update(KINDS[e->kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;
+  if (e->kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
+    return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
+  e->host.target[pi] = raw;
+  if (!e->initialized) { e->host.init_raw[pi] = raw; return PG_OK; }  // before initialize: plain value update
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_FX_PARAM; c.unit = 0; c.target = 0; c.param = pi; c.value = raw; c.frame = 0;
+  if (e->pending.size() >= 64) { int rc = effect_run(e, nullptr, 0, 0); if (rc) return rc; }
+  e->pending.push_back(c);
+  return PG_OK;
+}
+int pg_effect_message_reset(pg_effect* e) {
+  if (e->kind != PG_FX_DELAY && e->kind != PG_FX_REVERB && e->kind != PG_FX_CHORUS)
+    return set_error(PG_ERR_PARAMETER, "%sEffect: Invalid/unknown message payload", KINDS[e->kind].name);
+  if (!e->initialized) return PG_OK;
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_FX_RESET; c.unit = 0; c.target = 0;
+  if (e->pending.size() >= 64) { int rc = effect_run(e, nullptr, 0, 0); if (rc) return rc; }
+  e->pending.push_back(c);
+  return PG_OK;
+}
+int64_t pg_effect_tail(pg_effect* e) {  // Effect::process_tail from the target values (host shadow)
+  const std::vector<float>& t = e->host.target;
+  double sr = (double)e->sample_rate;
+  switch (e->kind) {
+    case PG_FX_GAIN: { int m = (int)t[1]; return m == 0 ? 0 : (int64_t)((uint64_t)e->sample_rate / (uint64_t)(m == 1 ? 1 : (m == 2 ? 5 : 20))); }
+    case PG_FX_PANNING: return 0;
+    case PG_FX_FILTER: return e->sample_rate / 10;
+    case PG_FX_EQ5: return e->sample_rate / 5;
+    case PG_FX_DELAY: {
+      if (t[P_DELAY_DRIVE] > 0.0f) return -1;
+      double delay_ms = (double)(t[P_DELAY_TIME] + 50.0f);
+      double fb = (double)std::fabs(t[P_DELAY_FEEDBACK]);
+      if (fb >= 0.9999) return INT64_MAX;
+      if (fb < 0.001) return (int64_t)d2u64(std::ceil(delay_ms * sr / 1000.0));
+      double ds = delay_ms * sr / 1000.0;
+      return (int64_t)std::max<uint64_t>(d2u64(std::ceil(ds + ds * std::log10(0.001) / std::log10(fb))), 1);
+    }
+    case PG_FX_REVERB: {
+      double rs = (double)t[0];
+      double size = (rs * rs * 75.0) + 25.0;
+      uint64_t max_delay = d2u64(79.0 * size);
+      double tt = 1.0 - (0.82 - (((1.0 - rs) * 0.7) + (size * 0.002)));
+      double fb = 1.0 - (tt * tt) * (tt * tt);
+      if (fb >= 1.0) return INT64_MAX;
+      if (fb == 0.0) return (int64_t)max_delay;
+      return (int64_t)(max_delay + d2u64((double)max_delay * std::log10(0.001) / std::log10(fb)));
+    }
+    case PG_FX_CHORUS: {
+      float srf = (float)e->sample_rate;
+      float total_ms = t[P_CHORUS_DELAY] + 256.0f * 1000.0f / srf;
+      float fb = std::fabs(t[P_CHORUS_FEEDBACK]);
+      if (fb >= 1.0f) return INT64_MAX;
+      if (fb < 0.001f) return (int64_t)f2u64(std::ceil(total_ms * srf / 1000.0f));
+      float total = total_ms * srf / 1000.0f;
+      float decay = total + (float)((double)total * std::log10(0.001) / std::log10((double)fb));
+      return (int64_t)f2u64(std::ceil(decay));
+    }
+    case PG_FX_COMPRESSOR: return (int64_t)(f2u64(std::ceil(t[P_COMP_LOOKAHEAD] * (float)e->sample_rate)) + f2u64(std::ceil(t[P_COMP_RELEASE] * (float)e->sample_rate)));
+    case PG_FX_GATE: return (int64_t)(f2u64(std::ceil(t[P_GATE_HOLD] * (float)e->sample_rate)) + f2u64(std::ceil(t[P_GATE_RELEASE] * (float)e->sample_rate)));
+    default: return 0;
+  }
+}
+
+}  // extern "C"

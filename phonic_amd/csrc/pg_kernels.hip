@@ -1,0 +1,444 @@
+// gfx950 kernels of the phonic DSP hot path.
+//
+//   pg_unit_kernel   one workgroup per work unit — a sub-mixer (its sources + its effect chain), a lone
+//                    main-mixer source, the main mixer's bus chain, or a standalone effect. The unit's block
+//                    of interleaved stereo f32 frames lives in LDS from the source stage to the end of the
+//                    effect chain (no intermediate round trips to HBM); persistent state (delay lines,
+//                    filter state, smoothers, resampler history) lives in HBM.
+//   pg_mix_kernel_*  the mixer-graph sum (reference add_buffers per source, src/source/mixed.rs:606-608):
+//                    a deterministic two-stage tree over units, coalesced over the sample index.
+//
+// Written for CDNA4 only: 64-wide wavefronts, LDS-resident signal, f64 vector ALU for the filter/delay
+// arithmetic the reference does in f64. No MFMA: nothing on this path is a dense contraction.
+#include <hip/hip_runtime.h>
+
+#include "pg_dev.h"
+#include "pg_dsp_dev.h"
+#include "pg_fx_serial.h"
+#include "pg_source_dev.h"
+#include "pg_fx_fast.h"
+
+using namespace pgd;
+
+// ---- parameter updates (Effect::process_parameter_update of each effect), lane 0 --------------------
+// Returns 1 when the whole workgroup must flush state afterwards (compressor look-ahead line re-created).
+__device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value) {
+  uint32_t sr = fx.sample_rate;
+  switch (fx.kind) {
+    case 0: {  // gain.rs:177-205
+      PgGain& g = fx.u.gain;
+      if (param == P_GAIN_GAIN) sm_set_target(g.gain, value);
+      else {
+        g.dc_mode = (int)value;
+        if (g.dc_mode != 0) { double hz = g.dc_mode == 1 ? 1.0 : (g.dc_mode == 2 ? 5.0 : 20.0); g.dc[0].r = dc_r(hz, sr); g.dc[1].r = dc_r(hz, sr); }
+        else { g.dc[0].x1 = g.dc[0].y1 = 0.0; g.dc[1].x1 = g.dc[1].y1 = 0.0; }
+      }
+    } break;
+    case 1: {  // pan.rs:164-191
+      PgPan& p = fx.u.pan;
+      if (param == P_PAN_PAN) sm_set_target(p.pan, value);
+      else if (param == P_PAN_WIDTH) sm_set_target(p.width, value);
+      else if (param == P_PAN_INVL) p.invert_l = value != 0.0f;
+      else p.invert_r = value != 0.0f;
+    } break;
+    case 2: {  // filter.rs:209-237
+      PgFilter& f = fx.u.filter;
+      if (param == P_FILTER_TYPE) {
+        f.type = (int)value;
+        int bt = filter_to_biquad(f.type);
+        if (f.coef.type != bt) { f.coef.type = bt; biquad_apply(f.coef); }
+      } else if (param == P_FILTER_CUTOFF) sm_set_target(f.cutoff, value);
+      else sm_set_target(f.q, value);
+    } break;
+    case 3: {  // eq5.rs:334-363
+      PgEq5& e = fx.u.eq5;
+      int band = param / 3, which = param % 3;
+      if (which == 0) sm_set_target(e.gains[band], value);
+      else if (which == 1) sm_set_target(e.freqs[band], value);
+      else sm_set_target(e.bws[band], value);
+      eq5_update_filter_coefficients(fx);
+    } break;
+    case 4: {  // delay.rs:490-520
+      PgDelay& d = fx.u.delay;
+      switch (param) {
+        case P_DELAY_MODE: d.mode = (int)value; break;
+        case P_DELAY_TIME: sm_set_target(d.delay_time, value); break;
+        case P_DELAY_FEEDBACK: sm_set_target(d.feedback, value); break;
+        case P_DELAY_FTYPE: d.filter_type = (int)value; break;
+        case P_DELAY_CUTOFF: sm_set_target(d.cutoff, value); break;
+        case P_DELAY_DRIVE: sm_set_target(d.drive, value); break;
+        case P_DELAY_WET: sm_set_target(d.wet, value); break;
+        case P_DELAY_WIDTH: sm_set_target(d.width, value); break;
+        case P_DELAY_LFO_RATE: sm_set_target(d.lfo_rate, value); break;
+        case P_DELAY_LFO_SHAPE: d.lfo_shape = (int)value; d.lfo.waveform = (int)value; break;
+        case P_DELAY_D_TIME: sm_set_target(d.d_time, value); break;
+        case P_DELAY_D_FEEDBACK: sm_set_target(d.d_feedback, value); break;
+        default: sm_set_target(d.d_filter, value); break;
+      }
+    } break;
+    case 5: {  // reverb.rs:496-512
+      if (param == P_REVERB_ROOM) sm_set_target(fx.u.reverb.room, value);
+      else sm_set_target(fx.u.reverb.wet, value);
+    } break;
+    case 6: {  // chorus.rs:433-459
+      PgChorus& c = fx.u.chorus;
+      switch (param) {
+        case P_CHORUS_RATE: sm_set_target(c.rate, value); break;
+        case P_CHORUS_DEPTH: sm_set_target(c.depth, value); break;
+        case P_CHORUS_FEEDBACK: sm_set_target(c.feedback, value); break;
+        case P_CHORUS_DELAY: sm_set_target(c.delay, value); break;
+        case P_CHORUS_WET: sm_set_target(c.wet, value); break;
+        case P_CHORUS_PHASE: sm_set_target(c.phase, value); break;
+        case P_CHORUS_FTYPE: {
+          c.filter_type = (int)value;
+          int st = delay_to_svf(c.filter_type);
+          if (c.coef.type != st) { c.coef.type = st; svf_apply(c.coef); }
+        } break;
+        case P_CHORUS_FREQ: sm_set_target(c.freq, value); break;
+        default: sm_set_target(c.res, value); break;
+      }
+    } break;
+    case 7: {  // compressor.rs:304-330
+      PgComp& c = fx.u.comp;
+      float old_lookahead = c.lookahead;
+      switch (param) {
+        case P_COMP_THRESHOLD: c.threshold = value; break;
+        case P_COMP_RATIO: c.ratio = value; break;
+        case P_COMP_KNEE: c.knee = value; break;
+        case P_COMP_ATTACK: c.attack = value; break;
+        case P_COMP_RELEASE: c.release = value; break;
+        case P_COMP_MAKEUP: sm_set_target(c.makeup, value); break;
+        default: c.lookahead = value; break;
+      }
+      c.env_attack = env_coeff(c.attack, sr);
+      c.env_release = env_coeff(c.release, sr);
+      if (c.lookahead != old_lookahead) {  // LookupDelayLine::new  delay.rs:182-203
+        uint32_t df = (uint32_t)f2u64(ceilf(c.lookahead * (float)sr));
+        c.delay_frames = df;
+        uint32_t p = 1; while (p < df) p <<= 1;
+        c.mask = df > 0 ? p - 1 : 0;
+        c.write_pos = 0; c.peak_pos = 0; c.peak_value = 0.0;
+        return 1;
+      }
+    } break;
+    case 8: {  // gate.rs:203-223
+      PgGate& g = fx.u.gate;
+      switch (param) {
+        case P_GATE_THRESHOLD: g.threshold = value; break;
+        case P_GATE_ATTACK: g.attack = value; break;
+        case P_GATE_HOLD: g.hold = value; break;
+        case P_GATE_RELEASE: g.release = value; break;
+        default: g.range = value; break;
+      }
+      g.env_attack = env_coeff(g.attack, sr);
+      g.env_release = env_coeff(g.release, sr);
+      g.attack_coeff = expf(-1.0f / (g.attack * (float)sr));
+      g.release_coeff = expf(-1.0f / (g.release * (float)sr));
+    } break;
+    default: {  // distortion.rs:368-385
+      PgDist& d = fx.u.dist;
+      if (param == P_DIST_TYPE) d.type = (int)value;
+      else if (param == P_DIST_DRIVE) sm_set_target(d.drive, value);
+      else sm_set_target(d.mix, value);
+    } break;
+  }
+  return 0;
+}
+
+__device__ void wg_fill_zero(double* p, size_t n) {
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
+}
+
+// Reset messages (DelayEffectMessage::Reset, ReverbEffectMessage::Reset, ChorusEffectMessage::Reset) and the
+// compressor's look-ahead re-creation: flushes run on the whole workgroup.
+__device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
+  __syncthreads();
+  switch (fx.kind) {
+    case 4: {  // DelayEffect::reset  delay.rs:213-223
+      PgDelay& d = fx.u.delay;
+      wg_fill_zero(d.line[0], (size_t)d.mask + 1);
+      wg_fill_zero(d.line[1], (size_t)d.mask + 1);
+      if (threadIdx.x == 0) {
+        d.write_pos[0] = d.write_pos[1] = 0;
+        d.flt[0].ic1eq = d.flt[0].ic2eq = d.flt[1].ic1eq = d.flt[1].ic2eq = 0.0;
+        d.dc[0].x1 = d.dc[0].y1 = d.dc[1].x1 = d.dc[1].y1 = 0.0;
+        d.lfo.phase = 0.0f;
+        d.fb[0] = d.fb[1] = 0.0f;
+      }
+    } break;
+    case 5: {  // reverb.rs:469-487 (flush of all 13 lines; DelayLine/Allpass flush also resets write_pos)
+      PgReverb& r = fx.u.reverb;
+      for (int i = 0; i < 8; ++i) wg_fill_zero(r.line[i].buf, (size_t)r.line[i].frames * 2);
+      for (int i = 0; i < 4; ++i) wg_fill_zero(r.ap[i].buf, (size_t)r.ap[i].frames * 2);
+      wg_fill_zero(r.pre, ((size_t)r.pre_mask + 1) * 2);
+      if (threadIdx.x == 0) { for (int i = 0; i < 4; ++i) r.ap[i].write_pos = 0; r.pre_write_pos = 0; }
+    } break;
+    case 6: {  // ChorusEffect::reset  chorus.rs:201-210
+      PgChorus& c = fx.u.chorus;
+      wg_fill_zero(c.line[0], (size_t)c.mask + 1);
+      wg_fill_zero(c.line[1], (size_t)c.mask + 1);
+      if (threadIdx.x == 0) {
+        c.write_pos[0] = c.write_pos[1] = 0;
+        c.flt[0].ic1eq = c.flt[0].ic2eq = c.flt[1].ic1eq = c.flt[1].ic2eq = 0.0;
+        sm_init(c.rate, c.rate.target);
+        sm_init(c.phase, c.phase.target);
+        c.current_phase = 0.0;
+        chorus_reset_lfos(fx);
+      }
+    } break;
+    case 7: {
+      if (!reset_message) wg_fill_zero(fx.u.comp.line, (size_t)fx.u.comp.line_frames * 2);
+    } break;
+    default: break;
+  }
+  __syncthreads();
+}
+
+// ---- Effect::process dispatch: time-parallel steady-state path when eligible, exact serial path otherwise ----
+__device__ __noinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
+  if (fast && fx_fast_process(fx, sig, n, fc)) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    switch (fx.kind) {
+      case 0: gain_serial(fx, sig, n); break;
+      case 1: pan_serial(fx, sig, n); break;
+      case 2: filter_serial(fx, sig, n); break;
+      case 3: eq5_serial(fx, sig, n); break;
+      case 4: delay_serial(fx, sig, n); break;
+      case 5: reverb_serial(fx, sig, n); break;
+      case 6: chorus_serial(fx, sig, n); break;
+      case 7: comp_serial(fx, sig, n); break;
+      case 8: gate_serial(fx, sig, n); break;
+      default: dist_serial(fx, sig, n); break;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- EffectProcessor::process  src/source/mixed/effect.rs:56-145 -------------------------------------
+// ctl: LDS words for uniform decisions. Returns true when the effect processed output.
+__device__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
+                                     float* red) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool should_bypass = input_bypassed && fx.tail_counter == 0 && fx.silence_counter == PG_USIZE_MAX;  // :88-91
+    if (should_bypass && !fx.bypassed) fx.bypassed = 1;                                                // process_stopped: no-op for stock effects
+    else if (!should_bypass && fx.bypassed) { fx.bypassed = 0; fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0; }
+    ctl[0] = fx.bypassed;
+  }
+  __syncthreads();
+  if (ctl[0]) return false;
+  fx_process_wg(fx, sig, n, fc, fast);
+  if (input_bypassed) {  // update_tail_counters :111-145
+    if (threadIdx.x == 0) {
+      uint64_t tail_frames;
+      if (fx_process_tail(fx, tail_frames)) {
+        if (tail_frames == PG_USIZE_MAX) fx.tail_counter = tail_frames;
+        else if (fx.tail_counter == PG_USIZE_MAX) fx.tail_counter = tail_frames;
+        else { uint64_t fp = (uint64_t)(n / 2); fx.tail_counter = fx.tail_counter > fp ? fx.tail_counter - fp : 0; }
+        fx.silence_counter = PG_USIZE_MAX;
+        ctl[1] = 0;
+      } else ctl[1] = 1;
+    }
+    __syncthreads();
+    if (ctl[1]) {  // unknown tail: detect silence
+      float max_sample = wg_max_abs(sig, n, red);
+      if (threadIdx.x == 0) {
+        if (max_sample < 0.001f) {
+          uint64_t fp = (uint64_t)(n / 2);
+          fx.silence_counter = (fx.silence_counter > PG_USIZE_MAX - fp) ? PG_USIZE_MAX : fx.silence_counter + fp;
+          if (fx.silence_counter >= 2ull * (uint64_t)sample_rate) { fx.tail_counter = 0; fx.silence_counter = PG_USIZE_MAX; }
+        } else fx.silence_counter = 0;
+      }
+    }
+  } else if (threadIdx.x == 0) {
+    fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0;  // reset_tail_counters :148-152
+  }
+  __syncthreads();
+  return true;
+}
+
+// ---- the unit kernel ----------------------------------------------------------------------------------
+// dynamic LDS: [sig 2*n_frames f32][tmp 2*n_frames f32][scratch]
+extern __shared__ __attribute__((aligned(16))) char pg_smem[];
+
+__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units) return;
+  const int u = L.unit_order ? L.unit_order[blockIdx.x] : L.unit_base + (int)blockIdx.x;
+  PgUnit& unit = L.units[u];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = (int)L.n_frames;
+  float* sig = (float*)pg_smem;
+  float* tmp = sig + 2 * N;
+  char* scratch = (char*)(tmp + 2 * N);
+  // fixed small areas at the start of scratch
+  PgVoice* lv = (PgVoice*)scratch;                 scratch += (sizeof(PgVoice) + 15) & ~15ull;
+  int* ctl = (int*)scratch;                        scratch += 64;
+  float* red = (float*)scratch;                    scratch += 64;
+  SrcScratch S;
+  src_carve(scratch, S);
+  FastCtx fc;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red;
+
+  const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
+  float* ext = L.bus;
+  if (external) {
+    for (int i = tid; i < 2 * N; i += nt) sig[i] = ext[i];
+  } else {
+    for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
+  }
+  __syncthreads();
+
+  // ---- event-split loop of MixedSource::write (mixed.rs:679-712) for this unit ----
+  int ci = 0;  // command cursor (commands are sorted by (unit, frame))
+  while (ci < L.n_cmds && L.cmds[ci].unit < u) ++ci;
+  int frame0 = 0;
+  bool any_audible = false;
+  while (frame0 < N) {
+    // apply all commands due at frame0 (process_events, event.rs:41-50)
+    while (ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {
+      const PgCmd cmd = L.cmds[ci];
+      int flush = 0;
+      __syncthreads();
+      if (tid == 0) {
+        if (cmd.type == CMD_FX_PARAM) flush = fx_apply_param(L.fx[cmd.target], cmd.param, cmd.value);
+        else if (cmd.type == CMD_VOICE_VOLUME) sm_set_target(L.voices[cmd.target].volume, cmd.value);
+        else if (cmd.type == CMD_VOICE_PAN) sm_set_target(L.voices[cmd.target].panning, cmd.value);
+        else if (cmd.type == CMD_VOICE_STOP) { L.voices[cmd.target].has_stop = 1; L.voices[cmd.target].stop_time = cmd.value64; }
+        ctl[2] = flush;
+      }
+      __syncthreads();
+      if (cmd.type == CMD_FX_RESET) fx_flush_wg(L.fx[cmd.target], 1);
+      else if (ctl[2]) fx_flush_wg(L.fx[cmd.target], 0);
+      __threadfence_block();
+      ++ci;
+    }
+    int frame1 = N;
+    if (ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame < N) frame1 = (int)L.cmds[ci].frame;
+    const int seg = frame1 - frame0;
+    float* sseg = sig + 2 * frame0;
+    const uint64_t pos = L.pos + (uint64_t)frame0;
+    bool audible_input;
+    if (external) {
+      audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (*L.bus_audible != 0) : true);
+    } else {
+      audible_input = false;
+      for (int vi = 0; vi < unit.n_voices; ++vi) {
+        PgVoice* gv = &L.voices[L.voice_index[unit.voice_off + vi]];
+        audible_input |= voice_process(gv, lv, sseg, tmp, seg, pos, S);
+      }
+    }
+    // process_effects (mixed.rs:627-655)
+    if (unit.n_fx > 0) {
+      bool input_bypassed = !audible_input;
+      if (!(unit.effects_bypassed && input_bypassed)) {
+        bool all_bypassed = true;
+        for (int fi = 0; fi < unit.n_fx; ++fi) {
+          PgFx& fx = L.fx[L.fx_index[unit.fx_off + fi]];
+          bool is_active;
+          if (fx.standalone) { fx_process_wg(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
+          else is_active = fx_processor_process(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+          if (is_active) { input_bypassed = false; all_bypassed = false; }
+        }
+        __syncthreads();
+        if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
+      }
+    }
+    any_audible |= audible_input;
+    frame0 = frame1;
+    __syncthreads();
+  }
+
+  // ---- hand the block to the parent mixer ----
+  if (external) {
+    for (int i = tid; i < 2 * N; i += nt) ext[i] = sig[i];
+    return;
+  }
+  float* out = L.unit_out + (size_t)blockIdx.x * L.out_stride;
+  if (unit.kind == UNIT_SUBMIXER) {
+    // SubMixerProcessor::process  src/source/mixed/submixer.rs:47-77. (A sub-mixer without sources, effects or
+    // events returns 0 samples: max over an empty slice = 0 -> counts as silent.)
+    float max_sample = wg_max_abs(sig, 2 * N, red);
+    if (tid == 0) {
+      int audible;
+      if (max_sample < 0.001f) {
+        unit.silence_counter += (uint64_t)N;
+        audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
+      } else { unit.silence_counter = 0; audible = 1; }
+      unit.audible = audible;
+      ctl[3] = audible;
+    }
+    __syncthreads();
+    if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
+    else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
+  } else {
+    for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
+    if (tid == 0) unit.audible = any_audible ? 1 : 0;
+  }
+}
+
+// ---- mixer-graph sum -------------------------------------------------------------------------------------
+// Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
+// Stage 2: bus[s] = sum over groups (in order) of partial[g][s]; audible = OR over units.
+// Lanes run over the sample index s (coalesced float4); the f32 sum order is fixed (deterministic).
+__global__ void __launch_bounds__(256) pg_mix_kernel_1(const float* __restrict__ unit_out, uint32_t stride, int n_units, int group, float* __restrict__ partial,
+                                                       int n_vec4) {
+  int s4 = blockIdx.x * blockDim.x + threadIdx.x;
+  int g = blockIdx.y;
+  if (s4 >= n_vec4) return;
+  int u0 = g * group, u1 = u0 + group;
+  if (u1 > n_units) u1 = n_units;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = u0; u < u1; ++u) {
+    float4 v = *(const float4*)(unit_out + (size_t)u * stride + (size_t)s4 * 4);
+    acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+  }
+  *(float4*)(partial + (size_t)g * stride + (size_t)s4 * 4) = acc;
+}
+__global__ void __launch_bounds__(256) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_vec4,
+                                                       const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
+                                                       int* __restrict__ audible_out) {
+  int s4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && audible_out) {
+    int a = 0;
+    for (int u = 0; u < n_units; ++u) a |= units[order[u]].audible;
+    *audible_out = a;
+  }
+  if (s4 >= n_vec4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < n_groups; ++g) {
+    float4 v = *(const float4*)(partial + (size_t)g * stride + (size_t)s4 * 4);
+    acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+  }
+  *(float4*)(bus + (size_t)s4 * 4) = acc;
+}
+
+// ---- host-callable launchers (C++ linkage, used by pg_host.cpp) ------------------------------------------
+size_t pg_unit_lds_bytes(uint32_t n_frames) {
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + 64 + 64;
+  size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
+  return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
+}
+hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
+  if (L.n_units <= 0) return hipSuccess;
+  size_t lds = pg_unit_lds_bytes(L.n_frames);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)pg_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units), dim3(256), lds, stream, L);
+  return hipGetLastError();
+}
+hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
+                         const int32_t* order, int* audible_out, hipStream_t stream) {
+  int n_vec4 = (int)((n_samples + 3) / 4);
+  int group = 32;
+  int n_groups = (n_units + group - 1) / group;
+  if (n_groups < 1) n_groups = 1;
+  dim3 b(256), g1((n_vec4 + 255) / 256, n_groups), g2((n_vec4 + 255) / 256);
+  hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out, stride, n_units, group, partial, n_vec4);
+  hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, n_vec4, units, order, n_units, audible_out);
+  return hipGetLastError();
+}

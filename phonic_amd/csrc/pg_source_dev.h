@@ -1,0 +1,317 @@
+// Voice rendering on gfx950: PreloadedFileSource (embedded cubic resampler, loop/repeat, VolumeFader) ->
+// ChannelMappedSource -> AmplifiedSource -> PannedSource, i.e. the source chain `Player` builds for a
+// file (reference src/player.rs:540-558), evaluated by one workgroup with the block in LDS.
+//
+// The resampler's f32 `sub_pos` schedule (which input frame feeds which output frame) is replayed
+// sequentially by lane 0 exactly as CubicInterpolator::process does (src/utils/resampler/cubic.rs:72-111)
+// — it is rounding dependent and must be bit exact — and only the 4-tap Hermite evaluation, the gathers
+// from the PCM buffer in HBM and the gain/pan maths run on all lanes.
+#pragma once
+#include "pg_dsp_dev.h"
+
+namespace pgd {
+
+constexpr int SRC_OUT_CAP = 1024;  // output frames per resampling piece
+constexpr int SRC_WIN_CAP = 1040;  // consumed input frames per piece (+4 history)
+
+struct SrcScratch {            // carved from the unit's LDS scratch arena
+  uint16_t* sched_c;           // [SRC_OUT_CAP]   consumed-count at each output frame
+  float* sched_f;              // [SRC_OUT_CAP]   interpolation fraction
+  uint32_t* posmap;            // [SRC_WIN_CAP]   file frame index of each consumed frame
+  float* win;                  // [2][SRC_WIN_CAP + 4] input window per channel (4 history + consumed)
+  int32_t* ctl;                // [16] uniform control words written by lane 0
+};
+constexpr size_t SRC_SCRATCH_BYTES = SRC_OUT_CAP * 2 + SRC_OUT_CAP * 4 + SRC_WIN_CAP * 4 + 2 * (SRC_WIN_CAP + 4) * 4 + 16 * 4;
+
+DEVO void src_carve(char* base, SrcScratch& s) {
+  s.sched_f = (float*)base; base += SRC_OUT_CAP * 4;
+  s.posmap = (uint32_t*)base; base += SRC_WIN_CAP * 4;
+  s.win = (float*)base; base += 2 * (SRC_WIN_CAP + 4) * 4;
+  s.ctl = (int32_t*)base; base += 16 * 4;
+  s.sched_c = (uint16_t*)base;
+}
+
+// Hermite x-form  src/utils/resampler/cubic.rs:125-142
+DEVO float cubic_interp(float ym1, float y0, float y1, float y2, float fraction) {
+  float c0 = y0;
+  float c1 = (y1 - ym1) * 0.5f;
+  float c2 = ym1 - y0 * 2.5f + y1 * 2.0f - y2 * 0.5f;
+  float c3 = (y2 - ym1) * 0.5f + (y0 - y1) * 1.5f;
+  return ((c3 * fraction + c2) * fraction + c1) * fraction + c0;
+}
+
+// PreloadedFileSource::write_buffer (src/source/file/preloaded.rs:270-332) for `out_frames` frames of the file's
+// channel layout into `out` (LDS). `v` is the unit's LDS copy of the voice. Returns frames written (uniform).
+DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScratch& S) {
+  const int C = (int)v->channels;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // loop range in samples (:273-280)
+  uint64_t lr_start = 0, lr_end = v->n_samples;
+  if (v->repeat > 0 && v->has_loop) { lr_start = v->loop_start * C; lr_end = v->loop_end * C; }
+  int written = 0;  // frames
+  const bool bypass = fabsf(v->ratio - 1.0f) < 0.000001f;  // cubic.rs:53-58
+  while (written < out_frames) {
+    __syncthreads();
+    if (bypass) {
+      // whole-buffer copy branch: (min, min) consumed/produced
+      uint64_t pp = v->playback_pos;
+      uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
+      uint64_t want = (uint64_t)(out_frames - written) * C;
+      int nsm = (int)(remaining_in < want ? remaining_in : want);
+      for (int i = tid; i < nsm; i += nt) out[written * C + i] = v->pcm[pp + i];
+      __syncthreads();
+      if (tid == 0) {
+        v->playback_pos = pp + nsm;
+        if (v->playback_pos >= lr_end) {  // :317-326
+          if (v->repeat_count > 0) { if (v->repeat_count != PG_USIZE_MAX) v->repeat_count -= 1; v->playback_pos = lr_start; }
+          else v->pos_eof = 1;
+        }
+        S.ctl[0] = nsm / C;
+      }
+      __syncthreads();
+      int produced = S.ctl[0];
+      written += produced;
+      if (v->pos_eof && produced == 0) break;
+      continue;
+    }
+    // ---- one resampling piece: lane 0 replays the schedule ----
+    int piece = out_frames - written;
+    if (piece > SRC_OUT_CAP) piece = SRC_OUT_CAP;
+    {
+      int per_out = (int)ceilf(v->ratio) + 1;
+      int cap = (SRC_WIN_CAP - 8) / per_out;
+      if (cap < 1) cap = 1;
+      if (piece > cap) piece = cap;
+    }
+    if (tid == 0) {
+      float sub_pos = v->sub_pos[0];
+      const float ratio = v->ratio;
+      int initialized = v->initialized[0];
+      uint64_t pp = v->playback_pos;
+      uint64_t repeat_count = v->repeat_count;
+      int eof = v->pos_eof;
+      int c = 0;         // consumed frames in this piece
+      int produced = 0;  // produced frames in this piece
+      while (produced < piece) {  // write_buffer loop :286-331; each iteration = one resampler.process call
+        uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
+        int num_in = (int)((remaining_in / C) > 0x7fffffff ? 0x7fffffff : (remaining_in / C));
+        int num_out = piece - produced;
+        int consumed = 0, prod = 0;
+        uint32_t base_frame = (uint32_t)(pp / C);
+        if (!initialized && num_in >= 3) {  // cubic.rs:61-69
+          initialized = 1;
+          for (int f = 0; f < 3; ++f) { S.posmap[c] = base_frame + consumed; ++c; ++consumed; }
+        }
+        if (ratio < 1.0f) {  // cubic.rs:72-90
+          while (prod < num_out) {
+            if (sub_pos >= 1.0f) {
+              if (consumed >= num_in) break;
+              S.posmap[c] = base_frame + consumed; ++c; ++consumed;
+              sub_pos -= 1.0f;
+            }
+            S.sched_c[produced + prod] = (uint16_t)c;
+            S.sched_f[produced + prod] = sub_pos;
+            ++prod;
+            sub_pos += ratio;
+          }
+        } else {  // cubic.rs:92-111
+          bool brk = false;
+          while (prod < num_out) {
+            while (sub_pos < ratio) {
+              if (consumed >= num_in) { brk = true; break; }
+              S.posmap[c] = base_frame + consumed; ++c; ++consumed;
+              sub_pos += 1.0f;
+            }
+            if (brk) break;
+            sub_pos -= ratio;
+            S.sched_c[produced + prod] = (uint16_t)c;
+            S.sched_f[produced + prod] = 1.0f - sub_pos;
+            ++prod;
+          }
+        }
+        pp += (uint64_t)consumed * C;
+        produced += prod;
+        if (pp >= lr_end) {  // :317-326
+          if (repeat_count > 0) { if (repeat_count != PG_USIZE_MAX) repeat_count -= 1; pp = lr_start; }
+          else eof = 1;
+        }
+        if (eof && prod == 0) break;  // :327-330
+      }
+      v->sub_pos[0] = sub_pos; v->sub_pos[1] = sub_pos;
+      v->initialized[0] = initialized; v->initialized[1] = initialized;
+      v->playback_pos = pp; v->repeat_count = repeat_count; v->pos_eof = eof;
+      S.ctl[0] = produced; S.ctl[1] = c;
+    }
+    __syncthreads();
+    const int produced = S.ctl[0], c_total = S.ctl[1];
+    // ---- all lanes: gather the consumed frames (coalesced runs between loop wraps) and the history ----
+    for (int ch = 0; ch < C; ++ch) {
+      float* w = S.win + ch * (SRC_WIN_CAP + 4);
+      if (tid < 4) w[tid] = v->input[ch][3 - tid];  // oldest first: input[3], input[2], input[1], input[0]
+      for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(uint64_t)S.posmap[j] * C + ch];
+    }
+    __syncthreads();
+    // ---- all lanes: 4-tap Hermite per output frame and channel ----
+    for (int i = tid; i < produced * C; i += nt) {
+      int k = i / C, ch = i - k * C;
+      const float* w = S.win + ch * (SRC_WIN_CAP + 4);
+      int c = S.sched_c[k];
+      out[(written + k) * C + ch] = cubic_interp(w[c], w[c + 1], w[c + 2], w[c + 3], S.sched_f[k]);
+    }
+    __syncthreads();
+    if (tid == 0) {  // new history = the 4 newest window entries
+      for (int ch = 0; ch < C; ++ch) {
+        const float* w = S.win + ch * (SRC_WIN_CAP + 4);
+        float h0 = w[c_total + 3], h1 = w[c_total + 2], h2 = w[c_total + 1], h3 = w[c_total];
+        v->input[ch][0] = h0; v->input[ch][1] = h1; v->input[ch][2] = h2; v->input[ch][3] = h3;
+      }
+    }
+    __syncthreads();
+    written += produced;
+    if (v->pos_eof && produced == 0) break;
+    if (produced == 0 && c_total == 0) break;  // defensive: no progress possible
+  }
+  __syncthreads();
+  return written;
+}
+
+// PreloadedFileSource::write (preloaded.rs:396-475) + ChannelMappedSource::write (mapped.rs:61-99) +
+// AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
+// Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
+DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int C = (int)v->channels;
+  // process_messages: Stop (preloaded.rs:195-208)
+  if (tid == 0 && pending_stop && !v->finished) {
+    if (v->fade_out_seconds > 0.0f) {  // VolumeFader::start_fade_out  fader.rs:67-91
+      float from = (v->fader_state == 1) ? v->fader_current : 1.0f;
+      v->fader_state = 1; v->fader_current = from; v->fader_target = 0.0f;
+      const float LN100 = 4.605f;
+      float samples_duration = (float)v->out_rate * v->fade_out_seconds / LN100;
+      v->fader_inertia = 1.0f - expf(-1.0f / samples_duration);
+    } else {
+      v->finished = 1;
+    }
+  }
+  __syncthreads();
+  if (v->finished) return 0;
+  int wf = src_write_buffer(v, out, frames, S);  // frames of the file layout
+  int total = wf * C;
+  // VolumeFader::process  fader.rs:103-122
+  if (v->fader_state != 1) {
+    float tv = v->fader_target;
+    if (tv != 1.0f) for (int i = tid; i < total; i += nt) out[i] = out[i] * tv;
+  } else {
+    if (tid == 0) {
+      float cur = v->fader_current, tgt = v->fader_target, inertia = v->fader_inertia;
+      for (int f = 0; f < wf; ++f) {
+        cur += (tgt - cur) * inertia;
+        for (int c = 0; c < C; ++c) out[f * C + c] *= cur;
+      }
+      v->fader_current = cur;
+      if (fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // preloaded.rs:465-472
+    bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;
+    if (v->pos_eof || fade_out_completed) v->finished = 1;
+  }
+  // ChannelMappedSource: mono -> stereo (buffer.rs:209-217)
+  if (C == 1) {
+    // in-place expansion runs back to front, one tile of blockDim.x frames at a time, staged through registers
+    for (int base = wf > 0 ? ((wf - 1) / nt) * nt : -1; base >= 0; base -= nt) {
+      int f = base + tid;
+      float x = (f < wf) ? out[f] : 0.0f;
+      __syncthreads();
+      if (f < wf) { out[2 * f] = x; out[2 * f + 1] = x; }
+      __syncthreads();
+    }
+  }
+  int written = wf * 2;
+  __syncthreads();
+  // apply_smoothed_gain  smoothing.rs:60-71  (ramp path multiplies per SAMPLE)
+  if (sm_need_ramp(v->volume)) {
+    if (tid == 0) { PgSmooth s = v->volume; for (int i = 0; i < written; ++i) out[i] *= sm_next(s); v->volume = s; }
+  } else {
+    float gain = v->volume.target;
+    if (fabsf(1.0f - gain) > 0.000001f) for (int i = tid; i < written; i += nt) out[i] = out[i] * gain;
+  }
+  __syncthreads();
+  // apply_smoothed_panning  smoothing.rs:74-122
+  if (sm_need_ramp(v->panning)) {
+    if (tid == 0) {
+      PgSmooth s = v->panning;
+      for (int f = 0; f + 2 <= written; f += 2) { float l, r; panning_factors(sm_next(s), l, r); out[f] *= l; out[f + 1] *= r; }
+      v->panning = s;
+    }
+  } else {
+    float pan = v->panning.target;
+    if (fabsf(pan) > 0.000001f) {
+      float l, r;
+      panning_factors(pan, l, r);
+      for (int i = tid; i < written; i += nt) out[i] *= (i & 1) ? r : l;
+    }
+  }
+  __syncthreads();
+  return written;
+}
+
+// MixedSource::process_sources for ONE playing source (src/source/mixed.rs:558-624): renders into `tmp` and adds
+// into `sig`. Returns true when the source produced output.
+DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  __syncthreads();
+  {  // stage the voice state into LDS (uniform reads, lane-0 writes)
+    const uint32_t* src = (const uint32_t*)gv;
+    uint32_t* dst = (uint32_t*)lv;
+    for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (!lv->active) return false;
+  const int out_len = frames * 2;
+  int total_written = 0;
+  if (lv->start_time > pos) {
+    uint64_t fu = lv->start_time - pos;
+    if (fu >= (uint64_t)frames) return false;
+    total_written = (int)fu * 2;
+  }
+  bool produced_output = false;
+  while (total_written < out_len) {
+    uint64_t source_time = pos + (uint64_t)(total_written / 2);
+    uint64_t samples_until_stop = PG_USIZE_MAX;
+    if (lv->has_stop) {
+      uint64_t d = lv->stop_time > source_time ? lv->stop_time - source_time : 0;
+      samples_until_stop = d * 2;
+    }
+    int pending_stop = 0;
+    if (samples_until_stop == 0) {
+      pending_stop = 1;
+      __syncthreads();
+      if (tid == 0) lv->has_stop = 0;
+      samples_until_stop = PG_USIZE_MAX;
+    }
+    uint64_t remaining = (uint64_t)(out_len - total_written);
+    if (samples_until_stop < remaining) remaining = samples_until_stop;
+    int to_write = (int)(remaining < 8192 ? remaining : 8192);
+    int written = voice_write(lv, tmp, to_write / 2, pending_stop, S);
+    for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
+    __syncthreads();
+    total_written += written;
+    produced_output |= written > 0;
+    if (lv->finished) {  // is_transient && is_exhausted
+      if (tid == 0) lv->active = 0;
+      break;
+    } else if (written == 0) break;
+  }
+  __syncthreads();
+  {  // write the voice state back
+    uint32_t* dst = (uint32_t*)gv;
+    const uint32_t* src = (const uint32_t*)lv;
+    for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
+  }
+  __syncthreads();
+  return produced_output;
+}
+
+}  // namespace pgd

@@ -1,0 +1,57 @@
+"""GPU-resident mixer graph: Python mirror of the reference's `Player` calls that populate the main
+`MixedSource` (src/player.rs:519-602,773-822,893-939) and of `Source::write` (src/source.rs:95).
+Everything forwards to the C ABI of include/phonic_gpu.h; there is no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._wrap import GraphHandle, PhonicError
+
+
+class Graph(GraphHandle):
+    def __init__(self, sample_rate=48000, channels=2, max_frames=4096, device=0):
+        super().__init__(_capi.load(), "pg_", sample_rate, channels, max_frames, device)
+        self.max_frames = max_frames
+
+    # -- device-side output (multi-GPU master-bus reduce, bench.py) ------------------------------------
+    def write_device(self, d_out_ptr, n_samples, pos_in_frames, stream=None):
+        """`Source::write` into device memory (`d_out_ptr` = device pointer as int)."""
+        return self._lib.pg_graph_write_device(self._h, C.c_void_p(d_out_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0))
+
+    def set_defer_bus(self, defer):
+        self._check(self._lib.pg_graph_set_defer_bus(self._h, 1 if defer else 0))
+
+    def process_bus_device(self, d_bus_ptr, n_samples, pos_in_frames, stream=None):
+        self._check(self._lib.pg_graph_process_bus_device(self._h, C.c_void_p(d_bus_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        self._check(self._lib.pg_graph_synchronize(self._h))
+
+    def voice_count(self):
+        return self._lib.pg_graph_voice_count(self._h)
+
+    def is_voice_playing(self, voice):
+        return bool(self._lib.pg_graph_is_voice_playing(self._h, voice))
+
+    def kernel_ms(self, reset=True):
+        """(average ms of the unit kernel per launch, launches) since the last reset, from hipEvents on the graph's stream."""
+        n = C.c_uint64(0)
+        ms = self._lib.pg_graph_kernel_ms(self._h, 1 if reset else 0, C.byref(n))
+        return ms, n.value
+
+    def set_fast_math(self, level):
+        self._check(self._lib.pg_graph_set_fast_math(self._h, int(level)))
+
+
+def effect_parameters(kind):
+    """`Effect::parameters()` descriptors of an effect kind."""
+    lib = _capi.load()
+    out = []
+    for i in range(lib.pg_effect_kind_param_count(kind)):
+        d = _capi.ParamDesc()
+        if lib.pg_effect_kind_param(kind, i, C.byref(d)) != 0:
+            raise PhonicError(_capi.PG_ERR_NOT_FOUND, "parameter")
+        out.append(dict(fourcc=d.fourcc, type=d.type, min=d.min, max=d.max, default=d.default_value, scaling=d.scaling,
+                        scaling_args=(d.scaling_arg0, d.scaling_arg1), n_values=d.n_values, name=d.name.decode()))
+    return out

@@ -1,0 +1,200 @@
+"""Parity of the GPU mixer graph (`MixedSource::write` semantics through pg_graph_*) against the CPU oracle:
+resampler schedule, looping, start/stop times with fade-out, volume/panning events, sub-mixers with effect chains,
+bus effects, sample-accurate parameter events, and the benchmark workloads at reduced voice counts."""
+import numpy as np
+import pytest
+
+import oracle
+import workloads
+from phonic_amd import _capi
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def graphs(max_frames=4096):
+    from phonic_amd.graph import Graph
+
+    return Graph(SR, 2, max_frames, 0), oracle.OracleGraph(SR, 2, max_frames)
+
+
+def compare(a, b, rms_tol=1e-5, max_tol=1e-4):
+    assert np.isfinite(a).all()
+    d = a.astype(np.float64) - b.astype(np.float64)
+    rms = float(np.sqrt(np.mean(d * d)))
+    assert rms <= rms_tol, f"rms {rms}"
+    assert float(np.abs(d).max()) <= max_tol, f"max {np.abs(d).max()}"
+    return rms
+
+
+def both(build, n_blocks, block, actions=None, max_frames=4096):
+    """Build the same graph twice, render fixed blocks (the WavOutput pull loop); `actions` = {block: fn(graph)}."""
+    gg, gc = graphs(max_frames)
+    outs = []
+    for g in (gg, gc):
+        ids = build(g)
+        out = np.zeros((n_blocks, block * 2), np.float32)
+        pos = 0
+        for blk in range(n_blocks):
+            if actions and blk in actions:
+                actions[blk](g, ids, pos)
+            w = g.write(out[blk], pos)
+            assert w in (0, block * 2)
+            pos += block
+        outs.append(out.reshape(-1))
+    return outs
+
+
+def test_resampled_sources_bit_exact_schedule():
+    """Main-mixer sources only (no effects): 44.1k->48k cubic, gain+pan, sum. The f32 sub_pos schedule and the Hermite
+    taps are exact, so every voice must match the oracle bit for bit; the sum over voices is within f32 reassociation."""
+    def build(g):
+        return [g.add_voice(0, workloads.tone_buffer(i, 44100, 0.05), 2, 44100, volume=0.5, panning=workloads.voice_pan(i), has_repeat=1,
+                            repeat=_capi.PG_REPEAT_FOREVER) for i in range(1)]
+    a, b = both(build, 6, 1024)
+    assert np.array_equal(a, b)  # single voice: bit exact, across several loop wraps (0.05 s buffer)
+
+    def build8(g):
+        return [g.add_voice(0, workloads.tone_buffer(i, 44100, 0.05 + 0.01 * i), 2, 44100, volume=0.3, panning=workloads.voice_pan(i),
+                            has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER) for i in range(8)]
+    a, b = both(build8, 4, 1024)
+    compare(a, b, 1e-7, 1e-6)
+
+
+def test_mono_source_speed_and_one_shot():
+    """Mono file (ChannelMappedSource), speed 1.5 (ratio > 1 branch), plays once and ends (transient source removal):
+    after the end the mixer is empty and write() returns 0 without touching the buffer."""
+    def build(g):
+        return [g.add_voice(0, workloads.tone_buffer(3, 44100, 0.03, channels=1), 1, 44100, speed=1.5, volume=0.8, panning=-0.4)]
+    gg, gc = graphs()
+    res = []
+    for g in (gg, gc):
+        build(g)
+        outs, rets = [], []
+        pos = 0
+        for blk in range(4):
+            o = np.full(512 * 2, 7.0, np.float32)
+            rets.append(g.write(o, pos))
+            outs.append(o)
+            pos += 512
+        res.append((np.concatenate(outs), rets))
+    assert res[0][1] == res[1][1]
+    assert res[0][1][-1] == 0 and np.all(res[0][0][-1024:] == 7.0)
+    assert np.array_equal(res[0][0], res[1][0])
+
+
+def test_equal_rate_bypass_and_loop_range():
+    def build(g):
+        return [g.add_voice(0, workloads.tone_buffer(5, 48000, 0.02), 2, 48000, has_repeat=1, repeat=3, has_loop_range=1, loop_start=100,
+                            loop_end=700, volume=1.0)]
+    a, b = both(build, 5, 1000)
+    assert np.array_equal(a, b)
+
+
+def test_start_stop_fade_and_events():
+    """Delayed start inside a block, stop with the default 50 ms fade-out, volume and panning events mid-block."""
+    def build(g):
+        v0 = g.add_voice(0, workloads.tone_buffer(1, 44100, 0.5), 2, 44100, start_time=300, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        v1 = g.add_voice(0, workloads.tone_buffer(2, 48000, 0.5), 2, 48000, start_time=0, fade_in_seconds=0.01, has_repeat=1,
+                         repeat=_capi.PG_REPEAT_FOREVER)
+        return [v0, v1]
+
+    def act1(g, ids, pos):
+        g.set_voice_volume(ids[0], 0.3, pos + 100)
+        g.set_voice_panning(ids[1], 0.7, pos + 517)
+        g.stop_voice(ids[1], pos + 800)
+
+    a, b = both(build, 8, 1024, actions={1: act1})
+    compare(a, b, 1e-7, 1e-6)
+    assert np.abs(a[-2048:]).max() > 0  # voice 0 still plays
+
+
+def test_submixer_chain_and_bus_effects():
+    """Sub-mixers with per-voice chains + sources on the main mixer + bus chain; parameter events at sample times inside
+    blocks for a sub-mixer effect (device-side split) and a bus effect (host-side split)."""
+    def build(g):
+        ids = {}
+        for i in range(3):
+            m = g.add_mixer()
+            ids[f"f{i}"] = g.add_effect(m, _capi.FX_FILTER, params={"type": 0, "cuto": 1500.0 + 500 * i, "fltq": 0.9})
+            ids[f"c{i}"] = g.add_effect(m, _capi.FX_CHORUS)
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.3), 2, 44100, volume=0.4, panning=workloads.voice_pan(i), has_repeat=1,
+                        repeat=_capi.PG_REPEAT_FOREVER)
+            g.add_voice(m, workloads.tone_buffer(i + 20, 48000, 0.2, channels=1), 1, 48000, volume=0.2, start_time=700 * i, has_repeat=1,
+                        repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_voice(0, workloads.tone_buffer(9, 48000, 0.25), 2, 48000, volume=0.3, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        ids["eq"] = g.add_effect(0, _capi.FX_EQ5, params={"gan1": 4.0, "gan4": -5.0})
+        ids["lim"] = g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -20.0, "rato": 20.0, "knee": 0.0, "gain": 0.0, "look": 0.02})
+        return ids
+
+    def act(g, ids, pos):
+        g.schedule_param(ids["f1"], "cuto", 400.0, pos + 333)
+        g.schedule_param(ids["c2"], "dpth", 0.9, pos + 50)
+        g.schedule_param(ids["eq"], "gan2", 8.0, pos + 601)
+        g.schedule_reset(ids["c0"], pos + 900)
+
+    a, b = both(build, 6, 1024, actions={2: act})
+    compare(a, b)
+
+
+def test_auto_bypass_and_submixer_silence_gate():
+    """A one-shot voice into a sub-mixer with a Gain effect and a Delay: after the source ends the effects run their tails,
+    then bypass; the sub-mixer drops out of the sum after 2 s of silence (submixer.rs:47-77). 2.5 s at 48 kHz."""
+    def build(g):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.8})
+        g.add_effect(m, _capi.FX_DELAY, params={"dlay": 30.0, "fdbk": 0.3})
+        g.add_voice(m, workloads.tone_buffer(4, 48000, 0.05), 2, 48000)
+        g.add_effect(0, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(11))
+        return {}
+    a, b = both(build, 30, 4096)
+    compare(a, b)
+
+
+@pytest.mark.parametrize("name", ["headline", "c2", "c3", "c4", "c5"])
+def test_benchmark_workloads_reduced(name):
+    """The BASELINE.json configs at reduced voice counts (oracle finishes in seconds), 1024-frame blocks."""
+    builders = {
+        "headline": lambda g: workloads.build_headline(g, 6, seconds=0.2),
+        "c2": lambda g: workloads.build_c2(g, 8, seconds=0.2),
+        "c3": lambda g: workloads.build_c3(g, 8, seconds=0.2),
+        "c4": lambda g: workloads.build_c4(g, 8, seconds=0.2),
+        "c5": lambda g: workloads.build_c5(g, 4, seconds=0.2),
+    }
+    a, b = both(lambda g: builders[name](g) or {}, 6, 1024, max_frames=1024)
+    compare(a, b)
+    assert np.abs(a).max() > 1e-3
+
+
+def test_exact_mode_matches_fast_mode():
+    """pg_graph_set_fast_math(0) forces the exact serial evaluation: both modes must agree with the oracle."""
+    from phonic_amd.graph import Graph
+
+    outs = []
+    for fast in (0, 1):
+        g = Graph(SR, 2, 1024, 0)
+        g.set_fast_math(fast)
+        workloads.build_headline(g, 3, seconds=0.2)
+        outs.append(g.render(5, 1024))
+    gc = oracle.OracleGraph(SR, 2, 1024)
+    workloads.build_headline(gc, 3, seconds=0.2)
+    ref = gc.render(5, 1024)
+    compare(outs[0], ref)
+    compare(outs[1], ref)
+
+
+def test_write_device_matches_write():
+    import torch
+    from phonic_amd.graph import Graph
+
+    g1, g2 = Graph(SR, 2, 1024, 0), Graph(SR, 2, 1024, 0)
+    for g in (g1, g2):
+        workloads.build_headline(g, 4, seconds=0.1)
+    host = g1.render(3, 1024)
+    dev = torch.zeros(3, 2048, dtype=torch.float32, device="cuda:0")
+    pos = 0
+    for b in range(3):
+        assert g2.write_device(dev[b].data_ptr(), 2048, pos) == 2048
+        pos += 1024
+    g2.synchronize()
+    assert np.array_equal(dev.cpu().numpy().reshape(-1), host)
