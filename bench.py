@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the phonic DSP hot path on MI355X.
+
+A "step" is one 1024-frame block (the reference's offline block size, src/output/wav.rs:25) of the whole
+graph: every voice is resampled, run through its effect chain and summed into the master bus. Default
+workload = the configuration BASELINE.json's target is quoted on: "headline" = 1024 stereo 44.1 kHz voices
+-> cubic resampler -> gain/pan -> per-voice Reverb -> mixer sum (SURVEY.md §8d "H"), per GPU.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU: voices are sharded over ranks (weak scaling: --voices per GPU), each rank renders its partial master
+bus on its GPU, and the partial buses meet in one RCCL sum-reduce to rank 0 per block (the reference's caller-side
+sum of worker outputs, src/source/mixed.rs:522-536).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, hipEvent-timed) and `cpu_baseline` (the CPU
+oracle — a C++ port of the reference path, NOT the Rust binary — on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+# algorithmic bytes per voice-frame (derivation in DESIGN.md)
+B_ALG = {"headline": 423.4, "c2": 14.6, "c3": 36.0, "c4": 7.5, "c5": 456.0}
+DEFAULT_VOICES = {"headline": 1024, "c2": 64, "c3": 1024, "c4": 256, "c5": 1024}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(g, name, n_voices, first_voice, total_voices, seconds):
+    import workloads
+
+    if name == "headline":
+        workloads.build_headline(g, n_voices, first_voice, total_voices, seconds)
+    elif name == "c2":
+        workloads.build_c2(g, n_voices, seconds)
+    elif name == "c3":
+        workloads.build_c3(g, n_voices, first_voice, total_voices, seconds)
+    elif name == "c4":
+        workloads.build_c4(g, n_voices, seconds)
+    elif name == "c5":
+        workloads.build_c5(g, n_voices, first_voice, total_voices, seconds)
+    else:
+        raise ValueError(name)
+
+
+def cpu_baseline(name, block, seconds_budget=15.0):
+    """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core chunk)."""
+    import ctypes as C
+
+    import oracle
+
+    cores = os.cpu_count() or 1
+    threads = cores
+    lib = oracle.lib()
+    # calibrate with one small graph, then size the sample for ~seconds_budget of wall time
+    per_graph = {"headline": 4, "c2": 16, "c3": 8, "c4": 32, "c5": 2}[name]
+    gcal = oracle.OracleGraph(48000, 2, block)
+    build_workload(gcal, name, per_graph, 0, per_graph, 0.5)
+    t0 = time.perf_counter()
+    gcal.render(8, block)
+    t_cal = (time.perf_counter() - t0) / 8.0  # s per block per graph on one core
+    n_graphs = threads
+    n_blocks = int(max(8, min(2000, seconds_budget / max(t_cal, 1e-6))))
+    graphs = [oracle.OracleGraph(48000, 2, block) for _ in range(n_graphs)]
+    for i, g in enumerate(graphs):
+        build_workload(g, name, per_graph, i * per_graph, per_graph * n_graphs, 0.5)
+    handles = (C.c_void_p * n_graphs)(*[g._h for g in graphs])
+    outs = np.zeros(n_graphs * n_blocks * block * 2, np.float32)
+    t0 = time.perf_counter()
+    lib.po_graphs_render_parallel(handles, n_graphs, threads, outs.ctypes.data_as(C.POINTER(C.c_float)), block * 2, n_blocks, 0)
+    dt = time.perf_counter() - t0
+    vf = n_graphs * per_graph * n_blocks * block
+    return {
+        "value": vf / dt,
+        "unit": "voice-frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_graphs} oracle graphs x {per_graph} voices x {n_blocks} blocks of {block} frames, {threads} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="headline", choices=sorted(B_ALG))
+    ap.add_argument("--voices", type=int, default=0, help="voices PER GPU (default: the config's count)")
+    ap.add_argument("--block", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from phonic_amd.graph import Graph
+
+    name = args.workload
+    v_per_gpu = args.voices or DEFAULT_VOICES[name]
+    total_voices = v_per_gpu * world
+    block = args.block
+    g = Graph(48000, 2, block, local_rank)
+    if args.exact:
+        g.set_fast_math(0)
+    bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
+    if world > 1 and bus_on_root:
+        g.set_defer_bus(True)
+    build_workload(g, name, v_per_gpu, rank * v_per_gpu, total_voices, 2.0)
+
+    n_samples = block * 2
+    bus = torch.zeros(n_samples, dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+    pos = 0
+
+    def step():
+        nonlocal pos
+        w = g.write_device(bus.data_ptr(), n_samples, pos, stream)
+        if w != n_samples:
+            raise RuntimeError("graph write failed: " + str(w))
+        if world > 1:
+            dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM)
+            if bus_on_root and rank == 0:
+                g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
+        pos += block
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    g.kernel_ms(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = g.kernel_ms(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    peak = float(bus.abs().max().item())
+
+    if rank == 0:
+        vf_total = total_voices * block * args.steps
+        value = vf_total / dt
+        vf_per_launch = v_per_gpu * block
+        achieved = B_ALG[name] * vf_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample",
+            "value": value,
+            "unit": "voice-frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": {"headline": "H: 1024 stereo 44.1k voices -> cubic resampler -> gain/pan -> per-voice Reverb -> mixer sum",
+                             "c2": "C2: 64 stereo 48k voices, Eq5+Reverb on the bus", "c3": "C3: 1024 mono voices, per-voice Filter+Chorus",
+                             "c4": "C4: 256 stereo 44.1k voices -> cubic -> bus limiter", "c5": "C5: per-voice Filter->Eq5->Delay->Reverb"}[name],
+                "voices_per_gpu": v_per_gpu,
+                "total_voices": total_voices,
+                "block_frames": block,
+                "sample_rate": 48000,
+                "master_frames_per_s": value / total_voices,
+                "x_realtime": value / total_voices / 48000.0,
+                "sharding": f"voices/{world}" + (" + RCCL reduce(sum) of the master bus per block" if world > 1 else ""),
+                "exact_mode": bool(args.exact),
+                "bus_peak": peak,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "pg_unit_kernel",
+                "kernel_ms": kernel_ms,
+                "launches": launches,
+                "bytes_per_voice_frame": B_ALG[name],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name, block)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,29 @@ def declare(lib, prefix):
     return lib
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process. PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, the same
+    soname libphonic_gpu.so needs); if the system runtime from /opt/rocm were loaded first, a later `import torch`
+    would bring in a second runtime that sees no GPUs. So when torch is installed its runtime is loaded first
+    (RTLD_GLOBAL) and libphonic_gpu.so binds to it by soname. PHONIC_HIP_RUNTIME=system opts out (torch-free runs,
+    e.g. profiling the single-GPU bench against /opt/rocm)."""
+    import sys
+
+    if os.environ.get("PHONIC_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libphonic_gpu.so")
 
@@ -143,6 +166,7 @@ def load():
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). phonic_amd has no CPU fallback."
         )
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     declare(lib, "pg_")
     P = C.POINTER

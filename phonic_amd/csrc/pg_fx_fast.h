@@ -12,11 +12,11 @@ struct FastCtx {
   float* tmp;        // LDS: 2*n_frames floats, free while effects run
   int tmp_floats;
   char* scratch;     // LDS arena (FAST_SCRATCH_BYTES)
-  int* ctl;          // LDS: 16 ints for uniform decisions
+  int* ctl;          // LDS: 32 ints for uniform decisions
   float* red;        // LDS: 16 floats for reductions
 };
 
-constexpr size_t FAST_SCRATCH_BYTES = 16 * 1024;
+constexpr size_t FAST_SCRATCH_BYTES = 16384 + 16 * 16 + 16 * 8 + 256;  // reverb: f64 chunk buffer + phase records + epilogue gets
 
 #include "pg_reverb_fast.inl"
 

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   char* scratch = (char*)(tmp + 2 * N);
   // fixed small areas at the start of scratch
   PgVoice* lv = (PgVoice*)scratch;                 scratch += (sizeof(PgVoice) + 15) & ~15ull;
-  int* ctl = (int*)scratch;                        scratch += 64;
+  int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
   SrcScratch S;
   src_carve(scratch, S);
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) pg_mix_kernel_2(const float* __restrict__
 
 // ---- host-callable launchers (C++ linkage, used by pg_host.cpp) ------------------------------------------
 size_t pg_unit_lds_bytes(uint32_t n_frames) {
-  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + 64 + 64;
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + 128 + 64;
   size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }

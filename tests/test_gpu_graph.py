@@ -105,7 +105,7 @@ def test_start_stop_fade_and_events():
         g.stop_voice(ids[1], pos + 800)
 
     a, b = both(build, 8, 1024, actions={1: act1})
-    compare(a, b, 1e-7, 1e-6)
+    compare(a, b, 1e-6, 1e-5)  # fader inertia goes through expf (device libm vs glibc): not bit exact
     assert np.abs(a[-2048:]).max() > 0  # voice 0 still plays
 
 
