@@ -90,6 +90,7 @@ struct PgReverb {  // ReverbEffect (src/effect/reverb.rs:41-73)
   PgAllpass ap[4];
   double* pre;  // DelayLine<2>, pow2 4096 frames
   uint32_t pre_mask, pre_write_pos;
+  const double* vib_tab;  // [8][129][2]: cos(j*d_i), sin(j*d_i) of the per-frame vibrato increment d_i = depth_i * 0.1 (shared, read-only)
 };
 struct PgChorus {  // ChorusEffect (src/effect/chorus.rs:47-75)
   PgSmooth rate, phase, depth, feedback, delay, wet, freq, res;
@@ -160,6 +161,7 @@ struct PgVoice {
   // PlayingSource (src/source/mixed.rs:34-42)
   uint64_t start_time, stop_time;
   int32_t has_stop, active;
+  int32_t sched_class, sched_rep;  // resampler schedule cache: class of voices sharing a ratio; 1 = this voice publishes the schedule
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.
@@ -176,6 +178,20 @@ enum { P_COMP_THRESHOLD = 0, P_COMP_RATIO, P_COMP_KNEE, P_COMP_ATTACK, P_COMP_RE
 enum { P_GATE_THRESHOLD = 0, P_GATE_ATTACK, P_GATE_HOLD, P_GATE_RELEASE, P_GATE_RANGE };
 enum { P_DIST_TYPE = 0, P_DIST_DRIVE, P_DIST_MIX };
 
+// Resampler schedule cache. The f32 `sub_pos` recurrence of the cubic resampler depends only on (ratio, sub_pos, number of
+// output frames) — not on the audio — so voices that run in lock step (same ratio, same state) share one schedule: the
+// class representative computes the NEXT block's schedule at the end of its workgroup and every voice whose state
+// matches the key bit for bit copies it instead of replaying the serial recurrence (any mismatch -> own replay).
+#define PG_SCHED_CAP 1024
+struct PgSchedEntry {
+  uint32_t ratio_bits, subpos_in_bits;  // key
+  int32_t piece, valid;
+  uint32_t subpos_out_bits;             // state after the piece
+  int32_t c_total;                      // input frames consumed by the piece
+  uint16_t sched_c[PG_SCHED_CAP];
+  float sched_f[PG_SCHED_CAP];
+};
+
 enum PgUnitKind { UNIT_SUBMIXER = 0, UNIT_SOURCE = 1, UNIT_BUS = 2, UNIT_EFFECT = 3 };
 
 struct PgUnit {
@@ -185,7 +201,7 @@ struct PgUnit {
   int32_t effects_bypassed;     // MixedSource::effects_bypassed (src/source/mixed.rs:202)
   uint64_t silence_counter;     // SubMixerProcessor (src/source/mixed/submixer.rs:23)
   int32_t audible;              // result of the last chunk: contributes to the parent's `audible_input`
-  int32_t pad;
+  int32_t deferred;             // set by the fast kernel when the unit must be rendered by the generic kernel
 };
 
 enum PgCmdType {
@@ -217,8 +233,12 @@ struct PgLaunch {
   uint64_t pos;           // SourceTime.pos_in_frames of the first frame
   uint32_t sample_rate;
   int32_t fast;           // 1: time-parallel paths enabled
+  int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only
   float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
   uint32_t out_stride;    // floats per unit row
   float* bus;             // bus / external signal for UNIT_BUS and UNIT_EFFECT (in place)
   int32_t* bus_audible;   // input flag for UNIT_BUS (1 = audible input)
+  PgSchedEntry* sched;    // [n_classes][2 banks]; nullptr disables the schedule cache
+  int32_t sched_bank;     // bank read by this launch; the representatives write bank ^ 1
+  unsigned long long* diag;  // diagnostic builds (-DPG_DIAG): shader-clock stamps of workgroup 0, else unused
 };

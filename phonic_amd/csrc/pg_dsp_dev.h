@@ -10,6 +10,14 @@
 #define DEVO __device__ __forceinline__
 #define DEVN __device__ __noinline__
 
+#ifdef PG_DIAG
+#define PG_STAMP(ptr, k) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) (ptr)[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PG_STAMP_VAL(ptr, k, v) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) (ptr)[k] = (unsigned long long)(v); } while (0)
+#else
+#define PG_STAMP_VAL(ptr, k, v) do { } while (0)
+#define PG_STAMP(ptr, k) do { } while (0)
+#endif
+
 namespace pgd {
 
 constexpr float F32_EPS100 = 1.1920929e-07f * 100.0f;

@@ -14,11 +14,23 @@ struct FastCtx {
   char* scratch;     // LDS arena (FAST_SCRATCH_BYTES)
   int* ctl;          // LDS: 32 ints for uniform decisions
   float* red;        // LDS: 16 floats for reductions
+  unsigned long long* diag;
 };
 
-constexpr size_t FAST_SCRATCH_BYTES = 16384 + 16 * 16 + 16 * 8 + 256;  // reverb: f64 chunk buffer + phase records + epilogue gets
+constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 16 * 3 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
 
 #include "pg_reverb_fast.inl"
+
+// Must mirror the acceptance conditions of fx_fast_process exactly: the fast kernel has no serial code to fall back to.
+DEVO bool fx_fast_eligible(const PgFx& fx) {
+  switch (fx.kind) {
+    case 0: return fx.u.gain.dc_mode == 0 && !sm_need_ramp(fx.u.gain.gain);
+    case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
+    case 5: return reverb_fast_eligible(fx);
+    case 9: return !sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f);
+    default: return false;
+  }
+}
 
 // Memoryless / constant-gain cases: every sample is independent.
 DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {

@@ -133,6 +133,26 @@ static void build_dist_luts(float* luts /*[5][256]*/) {
       luts[type * 256 + li] = (out_rms > 1e-10f) ? in_rms / out_rms : 1.0f;
     }
 }
+// vibrato rotation table of the reverb fast path: cos/sin(j * depth_i * vib_speed), j = 0..128, for the eight lines
+// (depths: src/effect/reverb.rs:137-144; increment depth*speed: reverb.rs:601-603). Read-only, shared by all instances.
+static std::map<int, double*> g_vib_tabs;
+static int get_vib_tab(int device, const double** out) {
+  auto it = g_vib_tabs.find(device);
+  if (it == g_vib_tabs.end()) {
+    static const double depths[8] = {0.003251, 0.002999, 0.002917, 0.002749, 0.002503, 0.002423, 0.002146, 0.002088};
+    std::vector<double> h(8 * 129 * 2);
+    for (int i = 0; i < 8; ++i) {
+      const double d = depths[i] * 0.1;
+      for (int j = 0; j <= 128; ++j) { h[(i * 129 + j) * 2] = std::cos((double)j * d); h[(i * 129 + j) * 2 + 1] = std::sin((double)j * d); }
+    }
+    double* dp = nullptr;
+    HIP_TRY(hipMalloc((void**)&dp, h.size() * 8));
+    HIP_TRY(hipMemcpy(dp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    it = g_vib_tabs.emplace(device, dp).first;
+  }
+  *out = it->second;
+  return PG_OK;
+}
 static std::map<int, float*> g_dist_luts;  // per device
 static int get_dist_luts(int device, const float** out) {
   auto it = g_dist_luts.find(device);
@@ -297,6 +317,8 @@ static int build_fx_device_state(HostFx& h, uint32_t sr, int device, bool standa
       }
       for (int i = 0; i < 4; ++i) { r.ap[i].buf = p; p += apsizes[i] * 2; r.ap[i].frames = (uint32_t)apsizes[i]; r.ap[i].delay = 0; r.ap[i].write_pos = 0; }
       r.pre = p; r.pre_mask = 4095; r.pre_write_pos = 0;
+      rc = get_vib_tab(device, &r.vib_tab);
+      if (rc) return rc;
     } break;
     case PG_FX_CHORUS: {  // chorus.rs:263-309
       PgChorus& c = fx.u.chorus;
@@ -399,6 +421,9 @@ struct pg_graph {
   DeviceVec<PgFx> d_fx;
   DeviceVec<int32_t> d_voice_index, d_fx_index, d_order;
   DeviceVec<PgCmd> d_cmds;
+  DeviceVec<PgSchedEntry> d_sched;       // [classes][2 banks]
+  std::map<uint32_t, int> sched_class_of_ratio;
+  uint64_t launch_counter = 0;
   std::vector<PgUnit> h_units;          // topology part only (kind, offsets); state fields are device-owned
   bool topo_dirty = true;
   std::vector<int32_t> order;           // launch order: sub-mixer units, then main-mixer source units by start time
@@ -410,6 +435,7 @@ struct pg_graph {
   int* d_audible = nullptr;
   float* h_pinned = nullptr;
   uint32_t stride = 0;
+  unsigned long long* d_diag = nullptr;  // diagnostic builds
   // timing of the dominant kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -552,7 +578,7 @@ void pg_graph_destroy(pg_graph* g) {
   for (auto& v : g->voices) if (v.d_pcm) (void)hipFree(v.d_pcm);
   for (auto& f : g->fx) if (f->d_mem) (void)hipFree(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_cmds.release();
+  g->d_cmds.release(); g->d_sched.release();
   if (g->d_unit_out) (void)hipFree(g->d_unit_out);
   if (g->d_partial) (void)hipFree(g->d_partial);
   if (g->d_bus) (void)hipFree(g->d_bus);
@@ -640,6 +666,20 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
   v.start_time = opt->start_time;
   v.active = 1;
+  {  // resampler schedule cache class: voices sharing the f32 ratio; the first one publishes
+    uint32_t rb;
+    memcpy(&rb, &v.ratio, 4);
+    auto it = g->sched_class_of_ratio.find(rb);
+    if (it == g->sched_class_of_ratio.end()) {
+      PgSchedEntry blank;
+      memset(&blank, 0, sizeof blank);
+      int i0 = -1, i1 = -1;
+      if (g->d_sched.push(blank, &i0) || g->d_sched.push(blank, &i1)) return -graph_fail(g, PG_ERR_DEVICE);
+      it = g->sched_class_of_ratio.emplace(rb, i0 / 2).first;
+      v.sched_rep = 1;
+    }
+    v.sched_class = it->second;
+  }
   int dev_index = -1;
   int rc = g->d_voices.push(v, &dev_index);
   if (rc) return -graph_fail(g, rc);
@@ -716,6 +756,13 @@ int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // M
   return PG_OK;
 }
 
+int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic builds: shader-clock stamps of workgroup 0
+  (void)hipSetDevice(g->device);
+  if (!g->d_diag) { HIP_TRY(hipMalloc((void**)&g->d_diag, 64 * 8)); HIP_TRY(hipMemset(g->d_diag, 0, 64 * 8)); return PG_OK; }
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  HIP_TRY(hipMemcpy(out, g->d_diag, (size_t)(n > 64 ? 64 : n) * 8, hipMemcpyDeviceToHost));
+  return PG_OK;
+}
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
 int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
@@ -761,6 +808,9 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
   L.unit_out = g->d_unit_out; L.out_stride = g->stride;
   L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
+  L.diag = g->d_diag;
+  L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
+  g->launch_counter++;
   bool timed = g->ev_used < 8192 && L.n_units > 0;
   if (timed && g->ev_used >= g->ev_pool.size()) {
     hipEvent_t a, b;
@@ -769,8 +819,18 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     g->ev_pool.emplace_back(a, b);
   }
   if (timed) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
-  HIP_TRY(pg_launch_units(L, stream));
-  if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+  if (g->fast) {
+    L.mode = 1;  // lean fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+    HIP_TRY(pg_launch_units(L, stream));
+    if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+    L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit
+    HIP_TRY(pg_launch_units(L, stream));
+  } else {
+    L.mode = 0;
+    HIP_TRY(pg_launch_units(L, stream));
+    if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+  }
+  L.mode = 0;
   HIP_TRY(pg_launch_mix(g->d_unit_out, g->stride, g->n_graph_units, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d, g->d_audible, stream));
   if (run_bus && !g->mixers[0].fx.empty()) {
     PgLaunch B = L;

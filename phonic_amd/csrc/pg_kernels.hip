@@ -195,29 +195,37 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
 }
 
 // ---- Effect::process dispatch: time-parallel steady-state path when eligible, exact serial path otherwise ----
-__device__ __noinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
-  if (fast && fx_fast_process(fx, sig, n, fc)) return;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    switch (fx.kind) {
-      case 0: gain_serial(fx, sig, n); break;
-      case 1: pan_serial(fx, sig, n); break;
-      case 2: filter_serial(fx, sig, n); break;
-      case 3: eq5_serial(fx, sig, n); break;
-      case 4: delay_serial(fx, sig, n); break;
-      case 5: reverb_serial(fx, sig, n); break;
-      case 6: chorus_serial(fx, sig, n); break;
-      case 7: comp_serial(fx, sig, n); break;
-      case 8: gate_serial(fx, sig, n); break;
-      default: dist_serial(fx, sig, n); break;
+// FAST_ONLY kernels contain no serial effect code at all (register budget); eligibility was checked up front.
+template <bool FAST_ONLY>
+__device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
+  if (FAST_ONLY) {
+    (void)fx_fast_process(fx, sig, n, fc);
+    return;
+  } else {
+    if (fast && fx_fast_process(fx, sig, n, fc)) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      switch (fx.kind) {
+        case 0: gain_serial(fx, sig, n); break;
+        case 1: pan_serial(fx, sig, n); break;
+        case 2: filter_serial(fx, sig, n); break;
+        case 3: eq5_serial(fx, sig, n); break;
+        case 4: delay_serial(fx, sig, n); break;
+        case 5: reverb_serial(fx, sig, n); break;
+        case 6: chorus_serial(fx, sig, n); break;
+        case 7: comp_serial(fx, sig, n); break;
+        case 8: gate_serial(fx, sig, n); break;
+        default: dist_serial(fx, sig, n); break;
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 // ---- EffectProcessor::process  src/source/mixed/effect.rs:56-145 -------------------------------------
 // ctl: LDS words for uniform decisions. Returns true when the effect processed output.
-__device__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
+template <bool FAST_ONLY>
+__device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
                                      float* red) {
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -228,7 +236,8 @@ __device__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_byp
   }
   __syncthreads();
   if (ctl[0]) return false;
-  fx_process_wg(fx, sig, n, fc, fast);
+  PG_STAMP(fc.diag, 9);
+  fx_process_wg<FAST_ONLY>(fx, sig, n, fc, fast);
   if (input_bypassed) {  // update_tail_counters :111-145
     if (threadIdx.x == 0) {
       uint64_t tail_frames;
@@ -262,7 +271,8 @@ __device__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_byp
 // dynamic LDS: [sig 2*n_frames f32][tmp 2*n_frames f32][scratch]
 extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 
-__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
+template <bool FAST_ONLY>
+__device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
   if ((int)blockIdx.x >= L.n_units) return;
   const int u = L.unit_order ? L.unit_order[blockIdx.x] : L.unit_base + (int)blockIdx.x;
   PgUnit& unit = L.units[u];
@@ -273,13 +283,33 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   char* scratch = (char*)(tmp + 2 * N);
   // fixed small areas at the start of scratch
   PgVoice* lv = (PgVoice*)scratch;                 scratch += (sizeof(PgVoice) + 15) & ~15ull;
+  PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
   int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
   SrcScratch S;
   src_carve(scratch, S);
+  S.diag = L.diag;
+  S.sched_rd = nullptr;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag;
+  if (L.mode != 2) PG_STAMP(L.diag, 0);
 
+  // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
+  if (FAST_ONLY) {
+    if (tid == 0) {
+      int ok = 1;
+      for (int ci0 = 0; ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) { ok = 0; break; }  // parameter events: exact path
+      for (int fi = 0; ok && fi < unit.n_fx; ++fi) ok = fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]]) ? 1 : 0;
+      unit.deferred = ok ? 0 : 1;
+      ctl[5] = ok;
+    }
+    __syncthreads();
+    if (!ctl[5]) return;
+  } else if (L.mode == 2) {
+    if (tid == 0) { ctl[5] = unit.deferred; unit.deferred = 0; }
+    __syncthreads();
+    if (!ctl[5]) return;
+  }
   const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
   float* ext = L.bus;
   if (external) {
@@ -325,20 +355,30 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
       audible_input = false;
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[L.voice_index[unit.voice_off + vi]];
-        audible_input |= voice_process(gv, lv, sseg, tmp, seg, pos, S);
+        audible_input |= voice_process(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
       }
     }
+    PG_STAMP(L.diag, 1);
     // process_effects (mixed.rs:627-655)
     if (unit.n_fx > 0) {
       bool input_bypassed = !audible_input;
       if (!(unit.effects_bypassed && input_bypassed)) {
         bool all_bypassed = true;
         for (int fi = 0; fi < unit.n_fx; ++fi) {
-          PgFx& fx = L.fx[L.fx_index[unit.fx_off + fi]];
+          // stage the effect's state block in LDS: the per-block bookkeeping of lane 0 (smoother checks, coefficient and
+          // delay-length updates, ring positions) then costs LDS instead of HBM round trips; written back afterwards
+          PgFx& gfx = L.fx[L.fx_index[unit.fx_off + fi]];
+          __syncthreads();
+          for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
+          __syncthreads();
+          PgFx& fx = *lfx;
+          PG_STAMP(L.diag, 8);
           bool is_active;
-          if (fx.standalone) { fx_process_wg(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
-          else is_active = fx_processor_process(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+          if (fx.standalone) { fx_process_wg<FAST_ONLY>(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
+          else is_active = fx_processor_process<FAST_ONLY>(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
           if (is_active) { input_bypassed = false; all_bypassed = false; }
+          __syncthreads();
+          for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
         }
         __syncthreads();
         if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
@@ -349,6 +389,7 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
     __syncthreads();
   }
 
+  PG_STAMP(L.diag, 14);
   // ---- hand the block to the parent mixer ----
   if (external) {
     for (int i = tid; i < 2 * N; i += nt) ext[i] = sig[i];
@@ -375,7 +416,19 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
     for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
     if (tid == 0) unit.audible = any_audible ? 1 : 0;
   }
+  PG_STAMP(L.diag, 15);
+  // schedule cache: representatives replay the next block's resampler schedule (piece = this launch's length, capped)
+  if (L.sched && tid == 0) {
+    const int piece = N < SRC_OUT_CAP ? N : SRC_OUT_CAP;
+    for (int vi = 0; vi < unit.n_voices; ++vi) sched_publish(&L.voices[L.voice_index[unit.voice_off + vi]], L.sched, L.sched_bank, piece);
+  }
 }
+
+#ifndef PG_FAST_WAVES
+#define PG_FAST_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true>(L); }
+__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) { pg_unit_body<false>(L); }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
 // Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
@@ -415,7 +468,7 @@ __global__ void __launch_bounds__(256) pg_mix_kernel_2(const float* __restrict__
 
 // ---- host-callable launchers (C++ linkage, used by pg_host.cpp) ------------------------------------------
 size_t pg_unit_lds_bytes(uint32_t n_frames) {
-  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + 128 + 64;
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
   size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }
@@ -426,9 +479,12 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)pg_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)pg_unit_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units), dim3(256), lds, stream, L);
+  if (L.mode == 1) hipLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), lds, stream, L);
+  else hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units), dim3(256), lds, stream, L);
   return hipGetLastError();
 }
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,

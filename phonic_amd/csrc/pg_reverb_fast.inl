@@ -21,17 +21,54 @@
 // accumulator crosses a power of two inside it (a 1-frame chunk uses the plain hardware add), which makes the phase
 // stream bit-identical to the serial recurrence — no index flips from phase drift.
 
-struct RevRec {       // per (line, channel) vibrato phase record of the current chunk
-  double p0, du;      // phase at chunk start; per-frame increment valid inside the chunk (or the raw increment when T == 1)
+struct RevRec {       // per (line, channel) vibrato phase record of the current chunk: two closed-form pieces
+  double p0, du0;     // phase after n steps = p0 + n*du0            for n <= m0
+  double p1, du1;     //                     = p1 + (n-m0-1)*du1     for n >  m0   (p1 = fl(p_m0 + d): the binade-crossing step)
+  uint32_t m0, m1;    // steps each piece is valid for; the chunk is cut at m0 + 1 + m1
 };
 
-struct RevRing {      // generalized ring walk: position of frame i given the position at chunk start
+// Closed form of the f64 accumulator p += d around p: while p stays inside its binade, fl(p + d) = p + du exactly, where
+// du = d rounded to a multiple of ulp(p). Returns the number of steps for which that is provably true (0: not at all).
+DEVO uint32_t rev_phase_piece(double p, double d, double& du) {
+  du = d;
+  unsigned long long bits = (unsigned long long)__double_as_longlong(p);
+  int e = (int)((bits >> 52) & 0x7ff);
+  if (!(e > 52 && e < 0x7ff && p > 0.0)) return 0;
+  const int ie = 1023 + 52 - (e - 1023);
+  if (!(ie > 0 && ie < 0x7ff)) return 0;
+  const double inv_u = __longlong_as_double((long long)((unsigned long long)ie << 52));        // 1 / ulp(p)
+  const double u = __longlong_as_double((long long)((unsigned long long)(e - 52) << 52));      // ulp(p)
+  const double D = d * inv_u;  // exact (power-of-two scaling)
+  if (!(D < 4503599627370496.0 && D >= 1.0)) return 0;
+  const double Dr = rint(D);
+  if (D - floor(D) == 0.5) return 0;  // a tie would round to even: depends on the accumulator's parity
+  const unsigned long long S = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;  // p / ulp(p)
+  const double room = (double)(0x20000000000000ull - 1ull - S);                     // ulps left in the binade (exact)
+  // exactly floor(room / Dr) steps stay inside the binade. One f64 division plus an exact fma remainder correction
+  // (a 64-bit integer division is a ~150k-cycle software loop on this target).
+  double q = floor(room / Dr);
+  const double rem = fma(-q, Dr, room);  // exact: |room - q*Dr| < 2^53
+  if (rem < 0.0) q -= 1.0;
+  else if (rem >= Dr) q += 1.0;
+  if (!(q >= 1.0)) return 0;
+  du = Dr * u;
+  return q > 1048576.0 ? 1048576u : (uint32_t)q;
+}
+DEVO double rev_phase_at(const RevRec& rc, uint32_t n) {
+  return n <= rc.m0 ? rc.p0 + (double)n * rc.du0 : rc.p1 + (double)(n - rc.m0 - 1) * rc.du1;
+}
+
+typedef __attribute__((address_space(1))) double gdouble;  // global (HBM) address space: global_load/store, not flat
+
+struct RevDesc {      // one delay line for the current chunk: base pointer, ring position at chunk start, ring length - 1
+  double* buf;
   uint32_t p0, delay;
-  __device__ __forceinline__ uint32_t at(uint32_t i) const {  // write/set position of frame i (i >= 0)
-    if (p0 <= delay) { uint32_t v = p0 + i; uint32_t m = delay + 1; return v >= m ? v % m : v; }
-    return i == 0 ? p0 : (i - 1) % (delay + 1);  // stale position above a shrunk ring: first write lands there, then 0,1,2..
-  }
 };
+// generalized ring walk: position of frame i (i <= T + 1 <= delay + 1, so one conditional subtract replaces the modulo)
+DEVO uint32_t rev_at(const RevDesc& d, uint32_t i) {
+  if (d.p0 <= d.delay) { uint32_t v = d.p0 + i; uint32_t m = d.delay + 1; return v >= m ? v - m : v; }
+  return i == 0 ? d.p0 : i - 1;  // stale position above a shrunk ring: the first write lands there, then 0, 1, 2 ...
+}
 
 DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
   double v = (double)x;
@@ -40,8 +77,10 @@ DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
 }
 
 // one ReverbDelayLine::get for one channel at ring count `cnt` and vibrato phase `ph`  (reverb.rs:554-586)
-DEVO double rev_get(const double* __restrict__ buf, uint32_t cnt, uint32_t delay, int ch, double ph, double blend) {
-  double offset = (sin(ph) + 1.0) * 7.0;
+// `sn` = sin(vib_phase)
+DEVO double rev_get(const double* buf_generic, uint32_t cnt, uint32_t delay, int ch, double sn, double blend) {
+  const gdouble* buf = (const gdouble*)buf_generic;
+  double offset = (sn + 1.0) * 7.0;
   double working = (double)cnt + offset;
   double w_floor = floor(working);
   double w_frac = working - w_floor;
@@ -56,23 +95,94 @@ DEVO double rev_get(const double* __restrict__ buf, uint32_t cnt, uint32_t delay
   return (1.0 - blend) * interpol + (val1 * blend);
 }
 
-// serial biquad over an LDS f64 buffer laid out [frame][2]; lanes 0 and 1 take one channel each
-DEVO void rev_biquad_lanes(const PgBiquadCoef& c, PgState2* st, double* buf, int T) {
-  if (threadIdx.x < 2) {
-    const int ch = threadIdx.x;
-    double a = st[ch].ic1eq, b = st[ch].ic2eq;
-    const double a1 = c.a1, a2 = c.a2, a3 = c.a3, m0 = c.m0, m1 = c.m1, m2 = c.m2;
-    for (int n = 0; n < T; ++n) {
-      double v0 = buf[n * 2 + ch];
-      double v3 = v0 - b;
-      double v1 = a1 * a + a2 * v3;
-      double v2 = b + a2 * a + a3 * v3;
-      a = 2.0 * v1 - a;
-      b = 2.0 * v2 - b;
-      buf[n * 2 + ch] = m0 * v0 + m1 * v1 + m2 * v2;
-    }
-    st[ch].ic1eq = a; st[ch].ic2eq = b;
+// LDS chunk buffer: [frame][2] f64, skewed by one double per 8-frame segment so that both the linear (per sample)
+// accesses and the per-segment accesses of the blocked biquad are free of bank conflicts.
+#define REV_IDX(n, ch) ((n) * 2 + (ch) + ((n) >> 3))
+constexpr int REV_BUF_DOUBLES = 2 * 1024 + 128 + 8;
+
+struct Mat2 { double a, b, c, d; };
+DEVO Mat2 mat2_mul(const Mat2& x, const Mat2& y) { return Mat2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; }
+
+// Time-parallel evaluation of one TPT-SVF biquad (BiquadFilter::process_sample, src/utils/dsp/filters/biquad.rs:314-322)
+// over the chunk, both channels, in place. The filter is linear and its coefficients are constant inside the chunk:
+//   s' = A s + B x,  A = [[2*a1-1, -2*a2], [2*a2, 1-2*a3]],  B = [2*a2, 2*a3]
+// Blocked recurrence: 128 segments of 8 frames per channel (one lane each, channel = wave & 1):
+//   pass 1: zero-state response of each segment (segment 0 starts from the carried state);
+//   scan  : end state of every segment = Kogge-Stone scan of s -> A^8 s + z over the segments (wave shuffles; the upper
+//           wave of a channel is seeded with the lower wave's final state through LDS);
+//   pass 2: each segment re-run from its true start state, writing the outputs.
+// Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative).
+DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ch = wave & 1, half = wave >> 1;
+  const int seg = half * 64 + lane;
+  const int n0 = seg * 8;
+  const int len = n0 >= T ? 0 : (T - n0 < 8 ? T - n0 : 8);
+  const double a1 = c.a1, a2 = c.a2, a3 = c.a3, m0 = c.m0, m1 = c.m1, m2 = c.m2;
+  // pass 1
+  double s1 = 0.0, s2 = 0.0;
+  if (seg == 0) { s1 = st[ch].ic1eq; s2 = st[ch].ic2eq; }
+  for (int k = 0; k < len; ++k) {
+    double v0 = buf[REV_IDX(n0 + k, ch)];
+    double v3 = v0 - s2;
+    double v1 = a1 * s1 + a2 * v3;
+    double v2 = s2 + a2 * s1 + a3 * v3;
+    s1 = 2.0 * v1 - s1;
+    s2 = 2.0 * v2 - s2;
   }
+  // powers of the 8-frame transition matrix
+  Mat2 M{2.0 * a1 - 1.0, -2.0 * a2, 2.0 * a2, 1.0 - 2.0 * a3};
+  M = mat2_mul(M, M); M = mat2_mul(M, M); M = mat2_mul(M, M);  // A^8
+  const Mat2 M8 = M;
+  // scan inside the wave
+  auto wave_scan = [&](double& z1, double& z2) {
+    Mat2 P = M8;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      double y1 = __shfl_up(z1, off, 64), y2 = __shfl_up(z2, off, 64);
+      if (lane >= off) { z1 = z1 + (P.a * y1 + P.b * y2); z2 = z2 + (P.c * y1 + P.d * y2); }
+      P = mat2_mul(P, P);
+    }
+  };
+  if (half == 0) {
+    wave_scan(s1, s2);
+    if (lane == 63) { xchg[ch * 2] = s1; xchg[ch * 2 + 1] = s2; }
+  }
+  __syncthreads();
+  double e1 = s1, e2 = s2;  // end state of this lane's segment (valid for full segments below the chunk end)
+  if (half == 1) {
+    if (lane == 0) { double x1 = xchg[ch * 2], x2 = xchg[ch * 2 + 1]; s1 = s1 + (M8.a * x1 + M8.b * x2); s2 = s2 + (M8.c * x1 + M8.d * x2); }
+    wave_scan(s1, s2);
+    e1 = s1; e2 = s2;
+  }
+  // start state of each segment = end state of the previous one
+  double b1 = __shfl_up(e1, 1, 64), b2 = __shfl_up(e2, 1, 64);
+  if (lane == 0) {
+    if (half == 0) { b1 = st[ch].ic1eq; b2 = st[ch].ic2eq; }
+    else { b1 = xchg[ch * 2]; b2 = xchg[ch * 2 + 1]; }
+  }
+  // pass 2
+  for (int k = 0; k < len; ++k) {
+    double v0 = buf[REV_IDX(n0 + k, ch)];
+    double v3 = v0 - b2;
+    double v1 = a1 * b1 + a2 * v3;
+    double v2 = b2 + a2 * b1 + a3 * v3;
+    b1 = 2.0 * v1 - b1;
+    b2 = 2.0 * v2 - b2;
+    buf[REV_IDX(n0 + k, ch)] = m0 * v0 + m1 * v1 + m2 * v2;
+  }
+  __syncthreads();  // all lanes have read the carried state
+  if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
+}
+
+// steady state and a geometry whose shortest feedback lag leaves room for a chunk (always true for valid room sizes)
+DEVO bool reverb_fast_eligible(const PgFx& fx) {
+  const PgReverb& r = fx.u.reverb;
+  if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;
+  double rs = (double)r.room.target;
+  double size = (rs * rs * 75.0) + 25.0;
+  return d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17;
 }
 
 DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
@@ -81,14 +191,20 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int frames = n_samples / 2;
   if (frames == 0) return true;
-  double* bufA = (double*)fc.scratch;                       // [T_CAP][2] f64
-  RevRec* rec = (RevRec*)(fc.scratch + 16384);              // [16]
-  double* gl = (double*)(fc.scratch + 16384 + 16 * sizeof(RevRec));  // [16] epilogue gets
+  double* bufA = (double*)fc.scratch;                       // [T_CAP][2] f64, skewed (REV_IDX)
+  char* lp = fc.scratch + REV_BUF_DOUBLES * 8;
+  RevRec* rec = (RevRec*)lp;   lp += 16 * sizeof(RevRec);    // [16]
+  double* gl = (double*)lp;    lp += 16 * 8;                 // [16] epilogue gets
+  RevDesc* desc = (RevDesc*)lp; lp += 13 * sizeof(RevDesc);  // [13]
+  double* xchg = (double*)lp;  lp += 4 * 8;                  // biquad scan hand-over
+  double* anch = (double*)lp;  lp += 16 * 3 * 8;             // [16] {phase, sin, cos} at the sub-chunk's first item
+  double* vtab = (double*)lp;  lp += 8 * 129 * 2 * 8;        // vibrato rotation table (LDS copy)
   int* ctl = fc.ctl;
   constexpr int T_CAP = 1024;
 
   // ---- block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets ----
   __syncthreads();
+  for (int i = tid; i < 8 * 129 * 2; i += nt) vtab[i] = ((const gdouble*)r.vib_tab)[i];
   if (tid == 0) {
     ReverbBlock rb;
     reverb_params(fx, (double)r.room.target, (double)r.wet.target, rb);
@@ -96,6 +212,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     ctl[4] = (int)rb.predelay;
   }
   __syncthreads();
+  PG_STAMP(fc.diag, 10);
   const double blend = gl[0], regen = gl[1], wet = gl[2];
   const uint32_t predelay = (uint32_t)ctl[4];
   __syncthreads();
@@ -106,113 +223,142 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (t_max < 32) return false;  // degenerate geometry: serial path
   if (t_max > (uint32_t)T_CAP) t_max = T_CAP;
 
+  PG_STAMP(fc.diag, 11);
   int done = 0;
   while (done < frames) {
     // ---- chunk set-up: vibrato phase records + chunk length (16 lanes) ----
     if (tid < 16) {
       const PgReverbLine& l = r.line[tid >> 1];
-      const double p0 = l.vib_phase[tid & 1];
       const double d = l.depth * 0.1;
-      unsigned long long bits = (unsigned long long)__double_as_longlong(p0);
-      int e = (int)((bits >> 52) & 0x7ff);
-      unsigned long long m_valid = 1;
-      double du = d;
-      if (e > 0 && e < 0x7ff && p0 > 0.0) {
-        // u = ulp(p0) = 2^(e-1075+...); scale d by 1/u exactly
-        const double inv_u = __longlong_as_double((long long)((unsigned long long)(1023 + 52 - (e - 1023)) << 52));  // 2^(52-(e-1023))
-        const double u = __longlong_as_double((long long)((unsigned long long)(e - 52) << 52));                        // 2^((e-1023)-52)
-        if (e - 52 > 0 && (1023 + 52 - (e - 1023)) > 0 && (1023 + 52 - (e - 1023)) < 0x7ff) {
-          const double D = d * inv_u;  // exact (power-of-two scaling)
-          if (D < 4503599627370496.0 && D >= 1.0) {
-            const double Dr = rint(D);
-            const double fr = D - floor(D);
-            if (fr != 0.5) {
-              const unsigned long long S = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;  // p0 / u
-              const unsigned long long Di = (unsigned long long)Dr;
-              const unsigned long long room = 0x20000000000000ull - 1ull - S;                  // 2^53 - 1 - S
-              unsigned long long mv = Di > 0 ? room / Di : 1;
-              if (mv >= 2) { m_valid = mv; du = Dr * u; }
-            }
-          }
-        }
-      }
-      rec[tid].p0 = p0;
-      rec[tid].du = du;
-      ctl[8 + tid] = (int)(m_valid > 100000ull ? 100000ull : m_valid);
+      RevRec rc;
+      rc.p0 = l.vib_phase[tid & 1];
+      rc.m0 = rev_phase_piece(rc.p0, d, rc.du0);
+      rc.p1 = (rc.p0 + (double)rc.m0 * rc.du0) + d;  // the plain hardware add carries the phase across the binade edge
+      rc.m1 = rev_phase_piece(rc.p1, d, rc.du1);
+      rec[tid] = rc;
+      ctl[8 + tid] = (int)(rc.m0 + 1u + rc.m1);
     }
     __syncthreads();
+    PG_STAMP(fc.diag, 12);
+    PG_STAMP_VAL(fc.diag, 20 + (done > 0 ? 1 : 0), done);
+    PG_STAMP_VAL(fc.diag, 22, t_max);
+    for (int i = 0; i < 16; ++i) PG_STAMP_VAL(fc.diag, 24 + i, ctl[8 + i]);
     int T = frames - done;
     if ((uint32_t)T > t_max) T = (int)t_max;
     for (int i = 0; i < 16; ++i) T = T < ctl[8 + i] ? T : ctl[8 + i];
-    // when T == 1 `du` may be the raw increment of a lane whose closed form is invalid: p_1 = p0 + d is the plain add
-    const bool single = (T == 1);
     float* s0 = sig + 2 * done;
 
-    // ---- phase 1: predelay (DelayLine<2>::process, delay.rs:47-66) ----
-    RevRing pr{r.pre_write_pos & r.pre_mask, predelay};
-    for (int s = tid; s < 2 * T; s += nt) {
-      int n = s >> 1, ch = s & 1;
-      bufA[s] = r.pre[(size_t)pr.at(n + 1) * 2 + ch];
-    }
-    __syncthreads();
-    for (int s = tid; s < 2 * T; s += nt) {
-      int n = s >> 1, ch = s & 1;
-      r.pre[(size_t)pr.at(n) * 2 + ch] = rev_guard(s0[s], ch ? r.fpd_r : r.fpd_l);
-    }
-    // ---- phase A: biquad A ----
-    rev_biquad_lanes(r.ca, r.sa, bufA, T);
+    PG_STAMP(fc.diag, 2);
+    // ---- ring descriptors of the 13 delay lines for this chunk -> LDS (uniform data stays out of the VGPR budget) ----
+    if (tid < 8) desc[tid] = RevDesc{r.line[tid].buf, r.line[tid].count, r.line[tid].delay};
+    else if (tid < 12) desc[tid] = RevDesc{r.ap[tid - 8].buf, r.ap[tid - 8].write_pos, r.ap[tid - 8].delay};
+    else if (tid == 12) desc[12] = RevDesc{r.pre, r.pre_write_pos & r.pre_mask, predelay};
     __syncthreads();
 
+    // ---- phase 1: predelay (DelayLine<2>::process, delay.rs:47-66) ----
+    {
+      const RevDesc pd = desc[12];
+      for (int s = tid; s < 2 * T; s += nt) {
+        int n = s >> 1, ch = s & 1;
+        bufA[REV_IDX(n, ch)] = ((const gdouble*)pd.buf)[(size_t)rev_at(pd, n + 1) * 2 + ch];
+      }
+      __syncthreads();
+      for (int s = tid; s < 2 * T; s += nt) {
+        int n = s >> 1, ch = s & 1;
+        ((gdouble*)pd.buf)[(size_t)rev_at(pd, n) * 2 + ch] = rev_guard(s0[s], ch ? r.fpd_r : r.fpd_l);
+      }
+    }
+    PG_STAMP(fc.diag, 3);
+    // ---- phase A: biquad A ----
+    rev_biquad_scan(r.ca, r.sa, bufA, T, xchg);
+    __syncthreads();
+
+    PG_STAMP(fc.diag, 4);
     // ---- phase 3: allpasses + vibrato lines, sub-chunks of nt/2 frames ----
-    RevRing apr[4], lr[8];
-    for (int i = 0; i < 4; ++i) apr[i] = RevRing{r.ap[i].write_pos, r.ap[i].delay};
-    for (int i = 0; i < 8; ++i) lr[i] = RevRing{r.line[i].count, r.line[i].delay};
-    const int src[8] = {3, 2, 1, 0, 0, 1, 2, 3};  // set(): a<-l, b<-k, c<-j, d<-i, e<-i, f<-j, g<-k, h<-l  (reverb.rs:275-282)
     for (int base = 0; base < T; base += nt / 2) {
       const int n = base + (tid >> 1), ch = tid & 1;
       const bool active = n < T;
-      double x = 0.0, dl[4] = {0, 0, 0, 0}, F[8], o_prev = 0.0;
+      // vibrato anchors: exact phase of the sub-chunk's first item and its sin/cos (accurate libm), one lane per (line, ch).
+      // Inside the sub-chunk sin(phase_n) follows by the angle-addition rotation with the per-line table.
+      if (tid < 16) {
+        const double pb = rev_phase_at(rec[tid], (uint32_t)(base > 0 ? base : 1));
+        anch[tid * 3] = pb; anch[tid * 3 + 1] = sin(pb); anch[tid * 3 + 2] = cos(pb);
+      }
+      __syncthreads();
+      double sv[8];   // values the eight lines are `set` to (allpass tap + feedback), reverb.rs:275-282,588-594
+      double apw[4];  // values written into the four allpass rings
+      double o_prev = 0.0;
       if (active) {
-        x = sin(bufA[n * 2 + ch] * wet);  // reverb.rs:253-257
-        for (int i = 0; i < 4; ++i) dl[i] = r.ap[i].buf[(size_t)apr[i].at(n + 1) * 2 + ch];  // `delayed` (== new_delayed for delay >= 1)
+        // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
+        double apo[4];
+        double v = sin(bufA[REV_IDX(n, ch)] * wet);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const RevDesc a = desc[8 + i];
+          const double dl = ((const gdouble*)a.buf)[(size_t)rev_at(a, n + 1) * 2 + ch];  // `delayed` (== new_delayed for delay >= 1)
+          const double b = v - (dl * 0.5);
+          apw[i] = b;
+          v = b * 0.5 + dl;
+          apo[i] = v;
+        }
+        double F[8];
+#ifdef PG_EXP_NO_G
+        if (false) {
+#else
         if (n >= 1) {
-          // gets after the step of frame n-1: count = position of frame n, phase after n steps
-          double g[8];
-          for (int i = 0; i < 8; ++i) {
-            const RevRec rc = rec[i * 2 + ch];
-            const double ph = single ? rc.p0 + rc.du : rc.p0 + (double)n * rc.du;
-            g[i] = rev_get(r.line[i].buf, lr[i].at(n), lr[i].delay, ch, ph, blend);
+#endif
+          // gets after the step of frame n-1: count = position of frame n, phase after n steps. Left to the scheduler to
+          // interleave: the 16 tap loads depend on the sin results, so overlapping the eight lines hides their latency.
+          // sin(phase_n) = sin(pb + j*d + eps) with pb the anchor phase, j*d the tabulated rotation and eps the (tiny, exactly
+          // computed) difference between the reference's rounded accumulation and the ideal progression: first-order term kept.
+          const int jb = n - (base > 0 ? base : 1);
+#define REV_G(i) ({ const RevDesc ld = desc[i]; \
+                    const double* an = anch + ((i) * 2 + ch) * 3; \
+                    const double ph = rev_phase_at(rec[(i) * 2 + ch], (uint32_t)n); \
+                    const double dd = r.line[i].depth * 0.1; \
+                    const double eps = (ph - an[0]) - (double)jb * dd; \
+                    const double ct = vtab[((i) * 129 + jb) * 2], stn = vtab[((i) * 129 + jb) * 2 + 1]; \
+                    const double sn = (an[1] * ct + an[2] * stn) + eps * (an[2] * ct - an[1] * stn); \
+                    double gv = rev_get(ld.buf, rev_at(ld, n), ld.delay, ch, sn, blend); \
+                    gv; })
+          {
+            const double a = REV_G(0), b = REV_G(1), c = REV_G(2), d = REV_G(3);
+            F[0] = (a - (b + c + d)) * regen; F[1] = (b - (a + c + d)) * regen;   // reverb.rs:303-306
+            F[2] = (c - (a + b + d)) * regen; F[3] = (d - (a + b + c)) * regen;
+            o_prev = a + b + c + d;                                              // reverb.rs:321-329 (left-assoc sum)
           }
-          F[0] = (g[0] - (g[1] + g[2] + g[3])) * regen; F[1] = (g[1] - (g[0] + g[2] + g[3])) * regen;   // reverb.rs:303-319
-          F[2] = (g[2] - (g[0] + g[1] + g[3])) * regen; F[3] = (g[3] - (g[0] + g[1] + g[2])) * regen;
-          F[4] = (g[4] - (g[5] + g[6] + g[7])) * regen; F[5] = (g[5] - (g[4] + g[6] + g[7])) * regen;
-          F[6] = (g[6] - (g[4] + g[5] + g[7])) * regen; F[7] = (g[7] - (g[4] + g[5] + g[6])) * regen;
-          o_prev = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;                        // reverb.rs:321-338
+          {
+            const double e = REV_G(4), f = REV_G(5), g = REV_G(6), h = REV_G(7);
+            F[4] = (e - (f + g + h)) * regen; F[5] = (f - (e + g + h)) * regen;   // reverb.rs:307-310
+            F[6] = (g - (e + f + h)) * regen; F[7] = (h - (e + f + g)) * regen;
+            o_prev = (o_prev + e + f + g + h) / 8.0;
+          }
+#undef REV_G
         } else {
+#pragma unroll
           for (int i = 0; i < 8; ++i) F[i] = r.line[i].feedback[ch];  // handed over from the previous chunk
         }
+        // set(): a<-l, b<-k, c<-j, d<-i, e<-i, f<-j, g<-k, h<-l  (reverb.rs:275-282)
+        sv[0] = apo[3] + F[0]; sv[1] = apo[2] + F[1]; sv[2] = apo[1] + F[2]; sv[3] = apo[0] + F[3];
+        sv[4] = apo[0] + F[4]; sv[5] = apo[1] + F[5]; sv[6] = apo[2] + F[6]; sv[7] = apo[3] + F[7];
       }
       __syncthreads();  // every read of this sub-chunk has been issued and consumed
       if (active) {
-        if (n >= 1) bufA[(n - 1) * 2 + ch] = o_prev;
-        double apo[4];
-        double v = x;
-        for (int i = 0; i < 4; ++i) {  // AllpassDelayLine::process (delay.rs:314-350)
-          double b = v - (dl[i] * 0.5);
-          r.ap[i].buf[(size_t)apr[i].at(n) * 2 + ch] = b;
-          v = b * 0.5 + dl[i];
-          apo[i] = v;
-        }
-        for (int i = 0; i < 8; ++i) r.line[i].buf[(size_t)lr[i].at(n) * 2 + ch] = apo[src[i]] + F[i];  // set (reverb.rs:588-594)
+        if (n >= 1) bufA[REV_IDX(n - 1, ch)] = o_prev;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const RevDesc a = desc[8 + i]; ((gdouble*)a.buf)[(size_t)rev_at(a, n) * 2 + ch] = apw[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const RevDesc ld = desc[i]; ((gdouble*)ld.buf)[(size_t)rev_at(ld, n) * 2 + ch] = sv[i]; }
       }
       __syncthreads();
     }
+    PG_STAMP(fc.diag, 5);
     // ---- epilogue: gets after the step of the chunk's last frame (16 lanes: one (line, channel) each) ----
     if (tid < 16) {
       const int i = tid >> 1, ch = tid & 1;
-      const RevRec rc = rec[tid];
-      const double ph = single ? rc.p0 + rc.du : rc.p0 + (double)T * rc.du;
-      gl[tid] = rev_get(r.line[i].buf, lr[i].at(T), lr[i].delay, ch, ph, blend);
+      const RevDesc ld = desc[i];
+      const double ph = rev_phase_at(rec[tid], (uint32_t)T);
+      gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sin(ph), blend);
       r.line[i].vib_phase[ch] = ph;
     }
     __syncthreads();
@@ -224,27 +370,27 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       r.line[2].feedback[ch] = (g[2] - (g[0] + g[1] + g[3])) * regen; r.line[3].feedback[ch] = (g[3] - (g[0] + g[1] + g[2])) * regen;
       r.line[4].feedback[ch] = (g[4] - (g[5] + g[6] + g[7])) * regen; r.line[5].feedback[ch] = (g[5] - (g[4] + g[6] + g[7])) * regen;
       r.line[6].feedback[ch] = (g[6] - (g[4] + g[5] + g[7])) * regen; r.line[7].feedback[ch] = (g[7] - (g[4] + g[5] + g[6])) * regen;
-      bufA[(T - 1) * 2 + ch] = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;
+      bufA[REV_IDX(T - 1, ch)] = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;
     }
-    if (tid == 0) {  // advance ring positions (uniform integer bookkeeping)
-      r.pre_write_pos = pr.at(T);
-      for (int i = 0; i < 4; ++i) r.ap[i].write_pos = apr[i].at(T);
-      for (int i = 0; i < 8; ++i) r.line[i].count = lr[i].at(T);
-    }
+    if (tid < 8) r.line[tid].count = rev_at(desc[tid], T);  // advance ring positions (uniform integer bookkeeping)
+    else if (tid < 12) r.ap[tid - 8].write_pos = rev_at(desc[tid], T);
+    else if (tid == 12) r.pre_write_pos = rev_at(desc[12], T);
     __syncthreads();
+    PG_STAMP(fc.diag, 6);
     // ---- biquad B -> clamp -> asin -> biquad C -> dry mix (reverb.rs:340-368) ----
-    rev_biquad_lanes(r.cb, r.sb, bufA, T);
+    rev_biquad_scan(r.cb, r.sb, bufA, T, xchg);
     __syncthreads();
-    for (int s = tid; s < 2 * T; s += nt) bufA[s] = asin(clampd(bufA[s], -1.0, 1.0));
+    for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = asin(clampd(bufA[bi], -1.0, 1.0)); }
     __syncthreads();
-    rev_biquad_lanes(r.cc, r.sc, bufA, T);
+    rev_biquad_scan(r.cc, r.sc, bufA, T, xchg);
     __syncthreads();
     for (int s = tid; s < 2 * T; s += nt) {
-      double y = bufA[s];
+      double y = bufA[REV_IDX(s >> 1, s & 1)];
       if (wet != 1.0) y += rev_guard(s0[s], (s & 1) ? r.fpd_r : r.fpd_l) * (1.0 - wet);
       s0[s] = (float)y;
     }
     __syncthreads();
+    PG_STAMP(fc.diag, 7);
     done += T;
   }
   return true;

@@ -20,6 +20,8 @@ struct SrcScratch {            // carved from the unit's LDS scratch arena
   uint32_t* posmap;            // [SRC_WIN_CAP]   file frame index of each consumed frame
   float* win;                  // [2][SRC_WIN_CAP + 4] input window per channel (4 history + consumed)
   int32_t* ctl;                // [16] uniform control words written by lane 0
+  unsigned long long* diag;
+  const PgSchedEntry* sched_rd;  // this voice's class entry for the current launch (or nullptr)
 };
 constexpr size_t SRC_SCRATCH_BYTES = SRC_OUT_CAP * 2 + SRC_OUT_CAP * 4 + SRC_WIN_CAP * 4 + 2 * (SRC_WIN_CAP + 4) * 4 + 16 * 4;
 
@@ -78,7 +80,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
     int piece = out_frames - written;
     if (piece > SRC_OUT_CAP) piece = SRC_OUT_CAP;
     {
-      int per_out = (int)ceilf(v->ratio) + 1;
+      int per_out = v->ratio < 1.0f ? 1 : (int)ceilf(v->ratio) + 1;  // most input frames one output frame can consume (+3 preload: SRC_WIN_CAP margin)
       int cap = (SRC_WIN_CAP - 8) / per_out;
       if (cap < 1) cap = 1;
       if (piece > cap) piece = cap;
@@ -92,6 +94,60 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       int eof = v->pos_eof;
       int c = 0;         // consumed frames in this piece
       int produced = 0;  // produced frames in this piece
+      int linear = 0;
+      {
+        // Common case (steady playback, no loop wrap inside the piece): ONE resampler.process call covers the piece and
+        // the input cannot run out (at most one push per output when ratio < 1), so the `consumed >= num_in` exits of
+        // cubic.rs:75-77 are dead and the schedule is a branch-free f32 recurrence — the same operations in the same order.
+        uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
+        uint64_t num_in = remaining_in / C;
+        const PgSchedEntry* se = S.sched_rd;
+        if (ratio < 1.0f && initialized && num_in > (uint64_t)piece && se && se->valid && se->piece == piece &&
+            se->ratio_bits == __float_as_uint(ratio) && se->subpos_in_bits == __float_as_uint(sub_pos)) {
+          // schedule cache hit: the class representative replayed exactly this recurrence; lanes copy it below
+          S.ctl[3] = (int)(uint32_t)(pp / C);
+          c = se->c_total;
+          sub_pos = __uint_as_float(se->subpos_out_bits);
+          pp += (uint64_t)c * C;
+          produced = piece;
+          linear = 2;
+        } else if (ratio < 1.0f && initialized && num_in > (uint64_t)piece) {
+          // Keep the recurrence entirely in the vector ALU (the values are wave-uniform, and the compiler would otherwise
+          // bounce the compare result through the scalar unit every step): 3 dependent VALU ops per output frame.
+          float sp = sub_pos;
+          int cc = c;
+          asm volatile("" : "+v"(sp), "+v"(cc));
+          int k = 0;
+          for (; k + 4 <= piece; k += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool ge = sp >= 1.0f;
+              cc += ge ? 1 : 0;
+              sp = ge ? sp - 1.0f : sp;
+              S.sched_c[k + j] = (uint16_t)cc;
+              S.sched_f[k + j] = sp;
+              sp += ratio;
+            }
+          }
+          for (; k < piece; ++k) {
+            const bool ge = sp >= 1.0f;
+            cc += ge ? 1 : 0;
+            sp = ge ? sp - 1.0f : sp;
+            S.sched_c[k] = (uint16_t)cc;
+            S.sched_f[k] = sp;
+            sp += ratio;
+          }
+          sub_pos = sp;
+          c = cc;
+          S.ctl[3] = (int)(uint32_t)(pp / C);
+          pp += (uint64_t)c * C;  // num_in > piece >= c: the loop end cannot be reached
+          produced = piece;
+          linear = 1;
+        }
+      }
+      S.ctl[2] = linear;
+      PG_STAMP_VAL(S.diag, 40, linear); PG_STAMP_VAL(S.diag, 41, S.sched_rd != nullptr);
+      if (S.sched_rd) { PG_STAMP_VAL(S.diag, 42, S.sched_rd->valid); PG_STAMP_VAL(S.diag, 43, S.sched_rd->piece); PG_STAMP_VAL(S.diag, 44, piece); PG_STAMP_VAL(S.diag, 45, S.sched_rd->subpos_in_bits); PG_STAMP_VAL(S.diag, 46, __float_as_uint(v->sub_pos[0])); PG_STAMP_VAL(S.diag, 47, S.sched_rd->ratio_bits); PG_STAMP_VAL(S.diag, 48, __float_as_uint(ratio)); }
       while (produced < piece) {  // write_buffer loop :286-331; each iteration = one resampler.process call
         uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
         int num_in = (int)((remaining_in / C) > 0x7fffffff ? 0x7fffffff : (remaining_in / C));
@@ -143,14 +199,22 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       S.ctl[0] = produced; S.ctl[1] = c;
     }
     __syncthreads();
+    PG_STAMP(S.diag, 17);
     const int produced = S.ctl[0], c_total = S.ctl[1];
+    if (S.ctl[2] == 2) {  // cache hit: coalesced copy of the shared schedule (L2 resident) into LDS
+      const PgSchedEntry* se = S.sched_rd;
+      for (int k = tid; k < produced; k += nt) { S.sched_c[k] = se->sched_c[k]; S.sched_f[k] = se->sched_f[k]; }
+      __syncthreads();
+    }
     // ---- all lanes: gather the consumed frames (coalesced runs between loop wraps) and the history ----
     for (int ch = 0; ch < C; ++ch) {
       float* w = S.win + ch * (SRC_WIN_CAP + 4);
       if (tid < 4) w[tid] = v->input[ch][3 - tid];  // oldest first: input[3], input[2], input[1], input[0]
-      for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(uint64_t)S.posmap[j] * C + ch];
+      if (S.ctl[2]) { const uint64_t b = (uint64_t)(uint32_t)S.ctl[3]; for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(b + j) * C + ch]; }
+      else for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(uint64_t)S.posmap[j] * C + ch];
     }
     __syncthreads();
+    PG_STAMP(S.diag, 18);
     // ---- all lanes: 4-tap Hermite per output frame and channel ----
     for (int i = tid; i < produced * C; i += nt) {
       int k = i / C, ch = i - k * C;
@@ -159,6 +223,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       out[(written + k) * C + ch] = cubic_interp(w[c], w[c + 1], w[c + 2], w[c + 3], S.sched_f[k]);
     }
     __syncthreads();
+    PG_STAMP(S.diag, 19);
     if (tid == 0) {  // new history = the 4 newest window entries
       for (int ch = 0; ch < C; ++ch) {
         const float* w = S.win + ch * (SRC_WIN_CAP + 4);
@@ -259,7 +324,9 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 
 // MixedSource::process_sources for ONE playing source (src/source/mixed.rs:558-624): renders into `tmp` and adds
 // into `sig`. Returns true when the source produced output.
-DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S) {
+DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
+                        const PgSchedEntry* sched, int sched_bank) {
+  SrcScratch S = S0;
   const int tid = threadIdx.x, nt = blockDim.x;
   __syncthreads();
   {  // stage the voice state into LDS (uniform reads, lane-0 writes)
@@ -268,6 +335,8 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
   }
   __syncthreads();
+  S.sched_rd = (sched && lv->sched_class >= 0) ? sched + (size_t)lv->sched_class * 2 + sched_bank : nullptr;
+  PG_STAMP(S.diag, 16);
   if (!lv->active) return false;
   const int out_len = frames * 2;
   int total_written = 0;
@@ -312,6 +381,33 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
   }
   __syncthreads();
   return produced_output;
+}
+
+// Representative voices publish the schedule of the NEXT block (same piece length assumed) into the other bank.
+// Runs on lane 0 after the unit's audio has been written: off the critical path of every other workgroup.
+DEVO void sched_publish(const PgVoice* gv, PgSchedEntry* sched, int sched_bank, int piece) {
+  if (!sched || gv->sched_class < 0 || !gv->sched_rep) return;
+  PgSchedEntry* e = sched + (size_t)gv->sched_class * 2 + (sched_bank ^ 1);
+  const float ratio = gv->ratio;
+  const bool ok = gv->active && !gv->finished && gv->initialized[0] && ratio < 1.0f && fabsf(ratio - 1.0f) >= 0.000001f && piece >= 1 && piece <= PG_SCHED_CAP;
+  if (!ok) { e->valid = 0; return; }
+  float sp = gv->sub_pos[0];
+  int cc = 0;
+  e->ratio_bits = __float_as_uint(ratio);
+  e->subpos_in_bits = __float_as_uint(sp);
+  e->piece = piece;
+  asm volatile("" : "+v"(sp), "+v"(cc));
+  for (int k = 0; k < piece; ++k) {  // identical operations to the replay in src_write_buffer (cubic.rs:72-90)
+    const bool ge = sp >= 1.0f;
+    cc += ge ? 1 : 0;
+    sp = ge ? sp - 1.0f : sp;
+    e->sched_c[k] = (uint16_t)cc;
+    e->sched_f[k] = sp;
+    sp += ratio;
+  }
+  e->subpos_out_bits = __float_as_uint(sp);
+  e->c_total = cc;
+  e->valid = 1;
 }
 
 }  // namespace pgd

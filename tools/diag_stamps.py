@@ -1,0 +1,27 @@
+import sys, ctypes as C
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+import numpy as np, torch
+from phonic_amd.graph import Graph
+from phonic_amd import _capi
+import workloads
+V=int(sys.argv[1]) if len(sys.argv)>1 else 1024
+g=Graph(48000,2,1024,0)
+workloads.build_headline(g,V,0,V,2.0)
+lib=_capi.load()
+lib.pg_graph_diag.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.c_int]
+buf=(C.c_uint64*64)()
+lib.pg_graph_diag(g._h,buf,64)
+bus=torch.zeros(2048,device='cuda:0')
+pos=0
+for i in range(20):
+    g.write_device(bus.data_ptr(),2048,pos); pos+=1024
+g.synchronize()
+lib.pg_graph_diag(g._h,buf,64)
+t=[buf[i] for i in range(20)]
+print('sched dbg', [hex(buf[i]) for i in range(40,49)])
+print('done@last chunk', buf[20], buf[21], 't_max', buf[22], 'mvalid', [buf[24+i] for i in range(16)])
+names={0:'start',16:'voice staged',17:'schedule done',18:'window filled',19:'interp done',1:'after source',8:'fx staged',9:'processor logic',10:'reverb_params',11:'t_max',12:'rec setup',2:'rev: chunk setup done',3:'rev: predelay done',4:'rev: biquadA done',5:'rev: phase3 done',6:'rev: epilogue done',7:'rev: B/asin/C/mix done',14:'effects done',15:'end'}
+prev=t[0]
+for k in [0,16,17,18,19,1,8,9,10,11,12,2,3,4,5,6,7,14,15]:
+    print(f"{names[k]:28s} +{(t[k]-prev):8d} cyc  (t={t[k]-t[0]})")
+    prev=t[k]
