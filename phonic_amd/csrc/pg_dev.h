@@ -90,6 +90,11 @@ struct PgReverb {  // ReverbEffect (src/effect/reverb.rs:41-73)
   PgAllpass ap[4];
   double* pre;  // DelayLine<2>, pow2 4096 frames
   uint32_t pre_mask, pre_write_pos;
+  // block parameters of the steady state (fast path): valid while room/wet targets are unchanged
+  float cache_room, cache_wet;
+  int32_t cache_valid;
+  uint32_t c_predelay;
+  double c_blend, c_regen;
   const double* vib_tab;  // [8][129][2]: cos(j*d_i), sin(j*d_i) of the per-frame vibrato increment d_i = depth_i * 0.1 (shared, read-only)
 };
 struct PgChorus {  // ChorusEffect (src/effect/chorus.rs:47-75)

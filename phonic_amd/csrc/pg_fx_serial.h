@@ -334,6 +334,7 @@ DEV void reverb_frame(PgFx& fx, float* frame, const ReverbBlock& rb) {
 // ReverbEffect::process  :409-447
 DEVN void reverb_serial(PgFx& fx, float* sig, int n) {
   PgReverb& r = fx.u.reverb;
+  r.cache_valid = 0;
   ReverbBlock rb;
   if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) {
     for (int f = 0; f + 2 <= n; f += 2) {

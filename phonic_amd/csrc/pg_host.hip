@@ -516,7 +516,7 @@ static int rebuild_topology(pg_graph* g) {
     HIP_TRY(hipMalloc((void**)&g->d_unit_out, nr * g->stride * sizeof(float)));
     g->unit_out_rows = nr;
   }
-  size_t prow = (rows + 31) / 32;
+  size_t prow = (rows + 15) / 16;
   if (prow > g->partial_rows) {
     if (g->d_partial) (void)hipFree(g->d_partial);
     HIP_TRY(hipMalloc((void**)&g->d_partial, prow * 2 * g->stride * sizeof(float)));

@@ -434,31 +434,35 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) { pg_unit_body
 // Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
 // Stage 2: bus[s] = sum over groups (in order) of partial[g][s]; audible = OR over units.
 // Lanes run over the sample index s (coalesced float4); the f32 sum order is fixed (deterministic).
-__global__ void __launch_bounds__(256) pg_mix_kernel_1(const float* __restrict__ unit_out, uint32_t stride, int n_units, int group, float* __restrict__ partial,
-                                                       int n_vec4) {
+__global__ void __launch_bounds__(64) pg_mix_kernel_1(const float* __restrict__ unit_out, uint32_t stride, int n_units, int group, float* __restrict__ partial,
+                                                      int n_vec4) {
   int s4 = blockIdx.x * blockDim.x + threadIdx.x;
   int g = blockIdx.y;
   if (s4 >= n_vec4) return;
   int u0 = g * group, u1 = u0 + group;
   if (u1 > n_units) u1 = n_units;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
   for (int u = u0; u < u1; ++u) {
     float4 v = *(const float4*)(unit_out + (size_t)u * stride + (size_t)s4 * 4);
     acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
   }
   *(float4*)(partial + (size_t)g * stride + (size_t)s4 * 4) = acc;
 }
-__global__ void __launch_bounds__(256) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_vec4,
-                                                       const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
-                                                       int* __restrict__ audible_out) {
+__global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_vec4,
+                                                      const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
+                                                      int* __restrict__ audible_out) {
   int s4 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && audible_out) {
+  if (blockIdx.x == gridDim.x - 1 && audible_out) {  // the extra last block: OR of the units' audible flags (wave reduction)
     int a = 0;
-    for (int u = 0; u < n_units; ++u) a |= units[order[u]].audible;
-    *audible_out = a;
+    for (int u = threadIdx.x; u < n_units; u += 64) a |= units[order[u]].audible;
+    for (int off = 32; off > 0; off >>= 1) a |= __shfl_xor(a, off, 64);
+    if (threadIdx.x == 0) *audible_out = a;
+    return;
   }
   if (s4 >= n_vec4) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
   for (int g = 0; g < n_groups; ++g) {
     float4 v = *(const float4*)(partial + (size_t)g * stride + (size_t)s4 * 4);
     acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
@@ -490,10 +494,10 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
                          const int32_t* order, int* audible_out, hipStream_t stream) {
   int n_vec4 = (int)((n_samples + 3) / 4);
-  int group = 32;
+  int group = 16;
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
-  dim3 b(256), g1((n_vec4 + 255) / 256, n_groups), g2((n_vec4 + 255) / 256);
+  dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
   hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out, stride, n_units, group, partial, n_vec4);
   hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, n_vec4, units, order, n_units, audible_out);
   return hipGetLastError();

@@ -197,7 +197,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   double* gl = (double*)lp;    lp += 16 * 8;                 // [16] epilogue gets
   RevDesc* desc = (RevDesc*)lp; lp += 13 * sizeof(RevDesc);  // [13]
   double* xchg = (double*)lp;  lp += 4 * 8;                  // biquad scan hand-over
-  double* anch = (double*)lp;  lp += 16 * 3 * 8;             // [16] {phase, sin, cos} at the sub-chunk's first item
+  double* anch = (double*)lp;  lp += 9 * 16 * 3 * 8;         // [9][16] {sin, cos, d_eps} anchors: 8 sub-chunks + the epilogue
   double* vtab = (double*)lp;  lp += 8 * 129 * 2 * 8;        // vibrato rotation table (LDS copy)
   int* ctl = fc.ctl;
   constexpr int T_CAP = 1024;
@@ -206,10 +206,14 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   __syncthreads();
   for (int i = tid; i < 8 * 129 * 2; i += nt) vtab[i] = ((const gdouble*)r.vib_tab)[i];
   if (tid == 0) {
-    ReverbBlock rb;
-    reverb_params(fx, (double)r.room.target, (double)r.wet.target, rb);
-    ((double*)gl)[0] = rb.blend; ((double*)gl)[1] = rb.regen; ((double*)gl)[2] = rb.wet;
-    ctl[4] = (int)rb.predelay;
+    if (!(r.cache_valid && r.cache_room == r.room.target && r.cache_wet == r.wet.target)) {
+      ReverbBlock rb;
+      reverb_params(fx, (double)r.room.target, (double)r.wet.target, rb);
+      r.c_blend = rb.blend; r.c_regen = rb.regen; r.c_predelay = rb.predelay;
+      r.cache_room = r.room.target; r.cache_wet = r.wet.target; r.cache_valid = 1;
+    }
+    ((double*)gl)[0] = r.c_blend; ((double*)gl)[1] = r.c_regen; ((double*)gl)[2] = (double)r.wet.target;
+    ctl[4] = (int)r.c_predelay;
   }
   __syncthreads();
   PG_STAMP(fc.diag, 10);
@@ -273,67 +277,84 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     rev_biquad_scan(r.ca, r.sa, bufA, T, xchg);
     __syncthreads();
 
+    // ---- vibrato anchors for the whole chunk, one lane per (sub-chunk, line, channel): sin/cos (accurate libm) of the exact
+    // phase of the sub-chunk's first item; inside the sub-chunk sin(phase_n) follows by the angle-addition rotation with
+    // the per-line table. Slot 8 = the epilogue's phase (after the chunk's last step).
+    if (tid < 9 * 16) {
+      const int sub = tid >> 4, lc = tid & 15;
+      const uint32_t nb = sub == 8 ? (uint32_t)T : (uint32_t)(sub == 0 ? 1 : sub * (nt / 2));
+      if (sub == 8 || nb <= (uint32_t)T) {
+        const RevRec rc = rec[lc];
+        const double pb = rev_phase_at(rc, nb);
+        const double dd = r.line[lc >> 1].depth * 0.1;
+        anch[tid * 3] = sin(pb);
+        anch[tid * 3 + 1] = cos(pb);
+        anch[tid * 3 + 2] = (nb <= rc.m0 ? rc.du0 : rc.du1) - dd;  // per-frame deviation of the rounded accumulation from the ideal one
+        if (sub == 8) gl[lc] = pb;
+      }
+    }
+    __syncthreads();
     PG_STAMP(fc.diag, 4);
     // ---- phase 3: allpasses + vibrato lines, sub-chunks of nt/2 frames ----
     for (int base = 0; base < T; base += nt / 2) {
       const int n = base + (tid >> 1), ch = tid & 1;
       const bool active = n < T;
-      // vibrato anchors: exact phase of the sub-chunk's first item and its sin/cos (accurate libm), one lane per (line, ch).
-      // Inside the sub-chunk sin(phase_n) follows by the angle-addition rotation with the per-line table.
-      if (tid < 16) {
-        const double pb = rev_phase_at(rec[tid], (uint32_t)(base > 0 ? base : 1));
-        anch[tid * 3] = pb; anch[tid * 3 + 1] = sin(pb); anch[tid * 3 + 2] = cos(pb);
-      }
-      __syncthreads();
       double sv[8];   // values the eight lines are `set` to (allpass tap + feedback), reverb.rs:275-282,588-594
       double apw[4];  // values written into the four allpass rings
       double o_prev = 0.0;
       if (active) {
+        // Order matters for latency: first everything that only needs the (known) vibrato phases — the 16 line taps of
+        // the previous frame's `get` — and the 4 allpass taps go out to HBM; the f64 sin of the front end and the allpass
+        // chain then run underneath those loads.
+        double tv1[8], tv2[8], tfr[8];
+        if (n >= 1) {
+          // sin(phase_n) = sin(pb + j*d + eps): pb = anchor phase, j*d = tabulated rotation, eps = j*(du - d) the (tiny) deviation
+          // of the reference's rounded accumulation from the ideal progression; first-order term kept.
+          const int jb = n - (base > 0 ? base : 1);
+          const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 3;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // ReverbDelayLine::get, address part (reverb.rs:563-576); count = position of frame n
+            const RevDesc ld = desc[i];
+            const double* an = anb + (i * 2 + ch) * 3;
+            const double ct = vtab[(i * 129 + jb) * 2], stn = vtab[(i * 129 + jb) * 2 + 1];
+            const double sn = (an[0] * ct + an[1] * stn) + ((double)jb * an[2]) * (an[1] * ct - an[0] * stn);
+            const double working = (double)rev_at(ld, n) + (sn + 1.0) * 7.0;
+            const double w_floor = floor(working);
+            tfr[i] = working - w_floor;
+            uint32_t read_1 = (uint32_t)w_floor;
+            uint32_t read_2 = read_1 + 1;
+            if (read_1 > ld.delay) read_1 -= ld.delay + 1;
+            if (read_2 > ld.delay) read_2 -= ld.delay + 1;
+            tv1[i] = ((const gdouble*)ld.buf)[(size_t)read_1 * 2 + ch];
+            tv2[i] = ((const gdouble*)ld.buf)[(size_t)read_2 * 2 + ch];
+          }
+        }
+        double dl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const RevDesc a = desc[8 + i]; dl[i] = ((const gdouble*)a.buf)[(size_t)rev_at(a, n + 1) * 2 + ch]; }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
         double v = sin(bufA[REV_IDX(n, ch)] * wet);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const RevDesc a = desc[8 + i];
-          const double dl = ((const gdouble*)a.buf)[(size_t)rev_at(a, n + 1) * 2 + ch];  // `delayed` (== new_delayed for delay >= 1)
-          const double b = v - (dl * 0.5);
+          const double b = v - (dl[i] * 0.5);
           apw[i] = b;
-          v = b * 0.5 + dl;
+          v = b * 0.5 + dl[i];   // == buf*0.5 + new_delayed (delay >= 1)
           apo[i] = v;
         }
         double F[8];
-#ifdef PG_EXP_NO_G
-        if (false) {
-#else
         if (n >= 1) {
-#endif
-          // gets after the step of frame n-1: count = position of frame n, phase after n steps. Left to the scheduler to
-          // interleave: the 16 tap loads depend on the sin results, so overlapping the eight lines hides their latency.
-          // sin(phase_n) = sin(pb + j*d + eps) with pb the anchor phase, j*d the tabulated rotation and eps the (tiny, exactly
-          // computed) difference between the reference's rounded accumulation and the ideal progression: first-order term kept.
-          const int jb = n - (base > 0 ? base : 1);
-#define REV_G(i) ({ const RevDesc ld = desc[i]; \
-                    const double* an = anch + ((i) * 2 + ch) * 3; \
-                    const double ph = rev_phase_at(rec[(i) * 2 + ch], (uint32_t)n); \
-                    const double dd = r.line[i].depth * 0.1; \
-                    const double eps = (ph - an[0]) - (double)jb * dd; \
-                    const double ct = vtab[((i) * 129 + jb) * 2], stn = vtab[((i) * 129 + jb) * 2 + 1]; \
-                    const double sn = (an[1] * ct + an[2] * stn) + eps * (an[2] * ct - an[1] * stn); \
-                    double gv = rev_get(ld.buf, rev_at(ld, n), ld.delay, ch, sn, blend); \
-                    gv; })
-          {
-            const double a = REV_G(0), b = REV_G(1), c = REV_G(2), d = REV_G(3);
-            F[0] = (a - (b + c + d)) * regen; F[1] = (b - (a + c + d)) * regen;   // reverb.rs:303-306
-            F[2] = (c - (a + b + d)) * regen; F[3] = (d - (a + b + c)) * regen;
-            o_prev = a + b + c + d;                                              // reverb.rs:321-329 (left-assoc sum)
+          double g[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // interpolation + blend (reverb.rs:578-583)
+            const double interpol = tv1[i] * (1.0 - tfr[i]) + tv2[i] * tfr[i];
+            g[i] = (1.0 - blend) * interpol + (tv1[i] * blend);
           }
-          {
-            const double e = REV_G(4), f = REV_G(5), g = REV_G(6), h = REV_G(7);
-            F[4] = (e - (f + g + h)) * regen; F[5] = (f - (e + g + h)) * regen;   // reverb.rs:307-310
-            F[6] = (g - (e + f + h)) * regen; F[7] = (h - (e + f + g)) * regen;
-            o_prev = (o_prev + e + f + g + h) / 8.0;
-          }
-#undef REV_G
+          F[0] = (g[0] - (g[1] + g[2] + g[3])) * regen; F[1] = (g[1] - (g[0] + g[2] + g[3])) * regen;   // reverb.rs:303-306
+          F[2] = (g[2] - (g[0] + g[1] + g[3])) * regen; F[3] = (g[3] - (g[0] + g[1] + g[2])) * regen;
+          F[4] = (g[4] - (g[5] + g[6] + g[7])) * regen; F[5] = (g[5] - (g[4] + g[6] + g[7])) * regen;   // reverb.rs:307-310
+          F[6] = (g[6] - (g[4] + g[5] + g[7])) * regen; F[7] = (g[7] - (g[4] + g[5] + g[6])) * regen;
+          o_prev = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;                        // reverb.rs:321-329
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) F[i] = r.line[i].feedback[ch];  // handed over from the previous chunk
@@ -350,16 +371,19 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const RevDesc ld = desc[i]; ((gdouble*)ld.buf)[(size_t)rev_at(ld, n) * 2 + ch] = sv[i]; }
       }
-      __syncthreads();
+      // no barrier here: the next sub-chunk only reads ring positions that are written by its own or later items, and LDS
+      // slots >= its first frame, so its reads cannot collide with these writes
     }
+    __syncthreads();
     PG_STAMP(fc.diag, 5);
     // ---- epilogue: gets after the step of the chunk's last frame (16 lanes: one (line, channel) each) ----
     if (tid < 16) {
       const int i = tid >> 1, ch = tid & 1;
       const RevDesc ld = desc[i];
-      const double ph = rev_phase_at(rec[tid], (uint32_t)T);
-      gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sin(ph), blend);
+      const double ph = gl[tid];  // exact phase after the chunk's last step (anchor slot 8)
+      const double sn = anch[(8 * 16 + tid) * 3];
       r.line[i].vib_phase[ch] = ph;
+      gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sn, blend);
     }
     __syncthreads();
     if (tid < 2) {
