@@ -113,6 +113,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from phonic_amd.graph import Graph
+    from phonic_amd.parallel import reduce_master_bus
 
     name = args.workload
     v_per_gpu = args.voices or DEFAULT_VOICES[name]
@@ -137,7 +138,7 @@ def main():
         if w != n_samples:
             raise RuntimeError("graph write failed: " + str(w))
         if world > 1:
-            dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM)
+            reduce_master_bus(bus, root=0)
             if bus_on_root and rank == 0:
                 g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
         pos += block

@@ -1,0 +1,85 @@
+"""N > 1 path on CPU: world_size 2 over gloo. Each rank renders its shard of the voices (the CPU oracle stands in for the
+GPU graph: no GPU here), the partial master buses are sum-reduced to rank 0 with phonic_amd.parallel, and rank 0 checks
+the result against the unsharded graph. Covers shard_range + reduce_master_bus, the code bench.py runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_voices, blocks, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    import workloads
+    from phonic_amd.parallel import reduce_master_bus, shard_range
+
+    start, count = shard_range(n_voices, rank, world)
+    g = oracle.OracleGraph(48000, 2, 512)
+    workloads.build_headline(g, count, first_voice=start, total_voices=n_voices, seconds=0.1)
+    out = []
+    pos = 0
+    for _ in range(blocks):
+        blk = np.zeros(1024, np.float32)
+        g.write(blk, pos)
+        bus = torch.from_numpy(blk)
+        reduce_master_bus(bus, root=0)
+        out.append(bus.numpy().copy())
+        pos += 512
+    if rank == 0:
+        q.put(np.concatenate(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from phonic_amd.parallel import shard_range
+
+    for n, w in ((1024, 8), (10, 4), (3, 8), (8192, 8), (7, 2)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert sum(c for _, c in spans) == n
+        pos = 0
+        for s, c in spans:
+            assert s == pos
+            pos += c
+
+
+def test_two_rank_voice_sharding_and_bus_reduce():
+    n_voices, blocks, world = 5, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_voices, blocks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import workloads
+
+    g = oracle.OracleGraph(48000, 2, 512)
+    workloads.build_headline(g, n_voices, seconds=0.1)
+    ref = g.render(blocks, 512)
+    # f32 sum order differs (shard sums are reduced instead of one serial sum): reassociation error only
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+    assert np.abs(ref).max() > 1e-3

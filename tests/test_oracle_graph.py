@@ -1,0 +1,105 @@
+"""Mixer-graph semantics of the CPU oracle (MixedSource, EffectProcessor, SubMixerProcessor; reference
+src/source/mixed.rs, mixed/effect.rs, mixed/submixer.rs): integer scheduling arithmetic, bypass/tail logic, edge cases."""
+import numpy as np
+
+import oracle
+import workloads
+from phonic_amd import _capi
+
+SR = 48000
+
+
+def test_empty_mixer_returns_zero_and_leaves_buffer():
+    g = oracle.OracleGraph(SR, 2)
+    out = np.full(256, 3.0, np.float32)
+    assert g.write(out, 0) == 0  # mixed.rs:664-670
+    assert np.all(out == 3.0)
+
+
+def test_source_start_time_is_sample_accurate():
+    g = oracle.OracleGraph(SR, 2)
+    buf = np.ones(2 * 101, np.float32)
+    buf[-2:] = 0  # extra zero frame
+    g.add_voice(0, buf, 2, SR, start_time=300)
+    out = np.zeros(2 * 1024, np.float32)
+    assert g.write(out, 0) == 2048
+    assert np.all(out[:600] == 0) and np.all(out[600:800] == 1.0) and out[802] == 0.0
+
+
+def test_event_splits_block_at_sample_time():
+    """A Gain parameter event at frame 517 takes effect exactly there (event.rs:41-50, mixed.rs:679-712)."""
+    g = oracle.OracleGraph(SR, 2)
+    buf = np.concatenate([np.full(2 * 4000, 0.5, np.float32), np.zeros(2, np.float32)])
+    g.add_voice(0, buf, 2, SR)
+    fx = g.add_effect(0, _capi.FX_GAIN)
+    g.schedule_param(fx, "gain", 0.25, 517)
+    out = np.zeros(2 * 1024, np.float32)
+    g.write(out, 0)
+    assert np.all(out[: 2 * 517] == 0.5)
+    assert out[2 * 517] < 0.5 and out[2 * 517] > 0.49  # exponential ramp starts at the event frame
+    assert out[-1] < out[2 * 600]
+
+
+def test_stop_with_fade_out_then_source_is_dropped():
+    g = oracle.OracleGraph(SR, 2)
+    buf = np.concatenate([np.full(2 * 48000, 0.5, np.float32), np.zeros(2, np.float32)])
+    v = g.add_voice(0, buf, 2, SR)
+    g.stop_voice(v, 100)
+    out = np.zeros(2 * 4096, np.float32)
+    assert g.write(out, 0) == 8192
+    assert np.all(out[:200] == 0.5)
+    assert 0 < out[2 * 2400] < 0.01  # 50 ms fade-out = 2400 frames to ~1%
+    rets = [g.write(out, 4096 * (i + 1)) for i in range(3)]
+    assert rets[-1] == 0  # fader finished -> exhausted -> transient source removed -> mixer empty
+
+
+def test_effect_auto_bypass_after_tail():
+    """Gain has tail 0: with a silent input the processor bypasses it on the block after the source ended
+    (effect.rs:88-145); the reverb on the bus keeps running for its tail."""
+    g = oracle.OracleGraph(SR, 2)
+    buf = np.concatenate([np.full(2 * 100, 0.5, np.float32), np.zeros(2, np.float32)])
+    g.add_voice(0, buf, 2, SR)
+    g.add_effect(0, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(0))
+    outs = [np.zeros(2048, np.float32) for _ in range(4)]
+    for i, o in enumerate(outs):
+        assert g.write(o, 1024 * i) == 2048
+    assert np.abs(outs[3]).max() > 1e-6  # reverb tail still audible (tail ~ 270k frames)
+
+
+def test_submixer_silence_gate_two_seconds():
+    """A sub-mixer without sources returns 0 samples; it counts as silent and stops contributing to `audible_input`
+    after 2 s (submixer.rs:47-77) — observable through the bus effect's bypass: Gain leaves the cleared buffer alone."""
+    g = oracle.OracleGraph(SR, 2)
+    g.add_mixer()
+    out = np.full(2 * 4096, 1.0, np.float32)
+    for i in range(30):
+        assert g.write(out, 4096 * i) == 8192
+        assert np.all(out == 0.0)
+
+
+def test_render_is_chunking_invariant_for_sources():
+    """write() in 1 x 4096 or 4 x 1024 frames gives identical source output (state carried across calls)."""
+    def build():
+        g = oracle.OracleGraph(SR, 2)
+        for i in range(3):
+            g.add_voice(0, workloads.tone_buffer(i, 44100, 0.05), 2, 44100, volume=0.4, panning=workloads.voice_pan(i), has_repeat=1,
+                        repeat=_capi.PG_REPEAT_FOREVER)
+        return g
+    a = build().render(1, 4096)
+    b = build().render(4, 1024)
+    assert np.array_equal(a, b)
+
+
+def test_normalized_parameter_updates():
+    """Normalized updates go through the parameter scaling (float.rs:137-141, scaling.rs:45-74)."""
+    e = oracle.OracleEffect(_capi.FX_FILTER)
+    e.initialize(SR, 2, 4096)
+    e.set_parameter("cuto", 0.5, normalized=True)  # 20 + 0.5^2.5 * 19980 = 3552.0...
+    x = workloads.test_signal(4096, seed=1)
+    e.process(x)
+    e2 = oracle.OracleEffect(_capi.FX_FILTER)
+    e2.initialize(SR, 2, 4096)
+    e2.set_parameter("cuto", float(np.float32(20.0) + np.float32(0.5) ** np.float32(2.5) * np.float32(19980.0)))
+    y = workloads.test_signal(4096, seed=1)
+    e2.process(y)
+    np.testing.assert_allclose(x, y, atol=1e-6)
