@@ -51,7 +51,7 @@ def build_workload(g, name, n_voices, first_voice, total_voices, seconds):
         raise ValueError(name)
 
 
-def cpu_baseline(name, block, seconds_budget=15.0):
+def cpu_baseline(name, block, seconds_budget=5.0):
     """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core chunk)."""
     import ctypes as C
 
@@ -68,6 +68,7 @@ def cpu_baseline(name, block, seconds_budget=15.0):
     gcal.render(8, block)
     t_cal = (time.perf_counter() - t0) / 8.0  # s per block per graph on one core
     n_graphs = threads
+    # one graph per thread; sized from the single-thread calibration (contention on a many-core host stretches it 2-4x)
     n_blocks = int(max(8, min(2000, seconds_budget / max(t_cal, 1e-6))))
     graphs = [oracle.OracleGraph(48000, 2, block) for _ in range(n_graphs)]
     for i, g in enumerate(graphs):
@@ -204,7 +205,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "pg_unit_kernel",
+                "kernel": "pg_unit_kernel_fast",
                 "kernel_ms": kernel_ms,
                 "launches": launches,
                 "bytes_per_voice_frame": B_ALG[name],
