@@ -51,6 +51,23 @@ def build_workload(g, name, n_voices, first_voice, total_voices, seconds):
         raise ValueError(name)
 
 
+def pmc_traffic(name, v_per_gpu, block):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 FETCH correction applied), if one matches this configuration.
+    bench.py cannot run the profiler on itself; the file names the command that produced it."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == name and d.get("voices_per_gpu") == v_per_gpu and d.get("block_frames") == block:
+            best = d
+    return best["traffic_bytes_per_launch"] if best else None
+
+
 def cpu_baseline(name, block, seconds_budget=5.0):
     """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core chunk)."""
     import ctypes as C
@@ -204,7 +221,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(name, v_per_gpu, block),
                 "kernel": "pg_unit_kernel_fast",
                 "kernel_ms": kernel_ms,
                 "launches": launches,
