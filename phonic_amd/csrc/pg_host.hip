@@ -451,6 +451,8 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].kind = topo[i].kind;
   units[i].n_voices = topo[i].n_voices; units[i].voice_off = topo[i].voice_off;
   units[i].n_fx = topo[i].n_fx; units[i].fx_off = topo[i].fx_off;
+  units[i].static_defer = topo[i].static_defer;
+  units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
 __global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -480,7 +482,13 @@ static int rebuild_topology(pg_graph* g) {
     HostMixer& mx = g->mixers[m];
     PgUnit& u = topo[mx.unit_slot];
     u.fx_off = (int)fidx.size(); u.n_fx = (int)mx.fx.size();
-    for (int f : mx.fx) fidx.push_back(f);
+    u.static_defer = 0;
+    for (int f : mx.fx) {
+      fidx.push_back(f);
+      const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)
+      if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_REVERB || k == PG_FX_DISTORTION)) u.static_defer = 1;
+      if (k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) u.static_defer = 1;  // DC filter: serial recurrence
+    }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);

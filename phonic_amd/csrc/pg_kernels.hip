@@ -297,9 +297,10 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
   if (FAST_ONLY) {
     if (tid == 0) {
-      int ok = 1;
-      for (int ci0 = 0; ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) { ok = 0; break; }  // parameter events: exact path
-      for (int fi = 0; ok && fi < unit.n_fx; ++fi) ok = fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]]) ? 1 : 0;
+      // Ramps only start with a parameter command, and commands are always rendered (and the ramp state re-evaluated at the
+      // end of the block) by the generic kernel: the unit record alone decides, no walk over the effect states.
+      int ok = !(unit.static_defer || unit.maybe_ramping);
+      for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
       unit.deferred = ok ? 0 : 1;
       ctl[5] = ok;
     }
@@ -326,7 +327,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
   bool any_audible = false;
   while (frame0 < N) {
     // apply all commands due at frame0 (process_events, event.rs:41-50)
-    while (ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {
+    while (!FAST_ONLY && ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {  // (the fast kernel defers units with commands)
       const PgCmd cmd = L.cmds[ci];
       int flush = 0;
       __syncthreads();
@@ -389,6 +390,11 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
     __syncthreads();
   }
 
+  if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
+    int ramping = 0;
+    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]]) ? 0 : 1;
+    unit.maybe_ramping = ramping;
+  }
   PG_STAMP(L.diag, 14);
   // ---- hand the block to the parent mixer ----
   if (external) {

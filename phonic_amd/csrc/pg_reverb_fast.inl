@@ -202,9 +202,18 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   int* ctl = fc.ctl;
   constexpr int T_CAP = 1024;
 
+  // vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store
+  {
+    const gdouble* tg = (const gdouble*)r.vib_tab;
+    double t0[5], t1[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; const int j = i < 8 * 129 ? i : 0; t0[k] = tg[2 * j]; t1[k] = tg[2 * j + 1]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; if (i < 8 * 129) { vtab[2 * i] = t0[k]; vtab[2 * i + 1] = t1[k]; } }
+  }
   // ---- block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets ----
   __syncthreads();
-  for (int i = tid; i < 8 * 129 * 2; i += nt) vtab[i] = ((const gdouble*)r.vib_tab)[i];
+
   if (tid == 0) {
     if (!(r.cache_valid && r.cache_room == r.room.target && r.cache_wet == r.wet.target)) {
       ReverbBlock rb;
@@ -261,15 +270,29 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
 
     // ---- phase 1: predelay (DelayLine<2>::process, delay.rs:47-66) ----
     {
+      const int ch0 = tid & 1;  // nt is even: a lane keeps its channel across trips
       const RevDesc pd = desc[12];
-      for (int s = tid; s < 2 * T; s += nt) {
-        int n = s >> 1, ch = s & 1;
-        bufA[REV_IDX(n, ch)] = ((const gdouble*)pd.buf)[(size_t)rev_at(pd, n + 1) * 2 + ch];
+      const uint32_t fpd = ch0 ? r.fpd_r : r.fpd_l;
+      for (int s_base = 0; s_base < 2 * T; s_base += 8 * nt) {  // 8 samples per lane and trip: all loads in flight together
+        double pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int s = s_base + k * nt + tid;
+          pv[k] = s < 2 * T ? ((const gdouble*)pd.buf)[(size_t)rev_at(pd, (s >> 1) + 1) * 2 + ch0] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int s = s_base + k * nt + tid;
+          if (s < 2 * T) bufA[REV_IDX(s >> 1, ch0)] = pv[k];
+        }
       }
       __syncthreads();
-      for (int s = tid; s < 2 * T; s += nt) {
-        int n = s >> 1, ch = s & 1;
-        ((gdouble*)pd.buf)[(size_t)rev_at(pd, n) * 2 + ch] = rev_guard(s0[s], ch ? r.fpd_r : r.fpd_l);
+      for (int s_base = 0; s_base < 2 * T; s_base += 8 * nt) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int s = s_base + k * nt + tid;
+          if (s < 2 * T) ((gdouble*)pd.buf)[(size_t)rev_at(pd, s >> 1) * 2 + ch0] = rev_guard(s0[s], fpd);
+        }
       }
     }
     PG_STAMP(fc.diag, 3);
