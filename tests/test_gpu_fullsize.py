@@ -1,0 +1,63 @@
+"""Full-size checks of the headline configuration (1024 voices, BASELINE.json) through size-independent properties:
+the oracle cannot render 1024 reverb voices in seconds, so the full graph is checked by
+  * linearity of the mixer: the sum of independently rendered voice shards equals the full render (f32 reassociation only);
+  * determinism: two runs are bit-identical (deterministic tree sum, no atomics);
+  * call-size invariance of the steady state: 4 x 1024 frames == 1 x 4096 frames (MixedSource chunking, mixed.rs:679-712);
+  * oracle spot checks: voices are independent until the master sum, so single voices of the 1024 (first / middle / last)
+    rendered alone on the GPU must match the oracle.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import workloads
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+V = 1024
+
+
+def gpu_graph(max_frames=1024):
+    from phonic_amd.graph import Graph
+
+    return Graph(SR, 2, max_frames, 0)
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.asarray(x, np.float64) ** 2)))
+
+
+def test_full_size_linearity_determinism_and_spot_checks():
+    blocks = 6
+    g = gpu_graph()
+    workloads.build_headline(g, V, 0, V, seconds=0.25)
+    full = g.render(blocks, 1024)
+    assert np.isfinite(full).all() and np.abs(full).max() > 1e-2
+    # determinism
+    g2 = gpu_graph()
+    workloads.build_headline(g2, V, 0, V, seconds=0.25)
+    assert np.array_equal(g2.render(blocks, 1024), full)
+    # linearity over shards (the multi-GPU decomposition): 4 shards of 256 voices
+    acc = np.zeros_like(full, dtype=np.float64)
+    for s in range(4):
+        gs = gpu_graph()
+        workloads.build_headline(gs, 256, s * 256, V, seconds=0.25)
+        acc += gs.render(blocks, 1024)
+    assert rms(acc - full) <= 1e-6 and np.abs(acc - full).max() <= 1e-5
+    # oracle spot checks on single voices of the full configuration
+    for i in (0, 511, 1023):
+        gg, gc = gpu_graph(), oracle.OracleGraph(SR, 2, 1024)
+        for h in (gg, gc):
+            workloads.build_headline(h, 1, i, V, seconds=0.25)
+        a, b = gg.render(blocks, 1024), gc.render(blocks, 1024)
+        assert rms(a - b) <= 1e-5 / np.sqrt(V) * 4, (i, rms(a - b))  # per-voice level is 1/sqrt(V) of the bus
+
+
+def test_call_size_invariance_steady_state():
+    a_g = gpu_graph(4096)
+    b_g = gpu_graph(4096)
+    for h in (a_g, b_g):
+        workloads.build_headline(h, 64, 0, 64, seconds=0.25)
+    a = a_g.render(2, 4096)
+    b = b_g.render(8, 1024)
+    assert rms(a - b) <= 1e-6
