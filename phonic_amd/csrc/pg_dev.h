@@ -210,7 +210,7 @@ struct PgUnit {
   int32_t static_defer;         // host: the chain holds an effect kind without a time-parallel path -> always generic kernel
   int32_t maybe_ramping;        // device: a parameter command was applied and some smoother may still ramp (cleared by the generic
                                 // kernel once every effect of the unit is back in steady state)
-  int32_t pad2;
+  int32_t voice0;               // host: device index of the unit's first voice (skips one dependent load at kernel start)
 };
 
 enum PgCmdType {

@@ -452,6 +452,7 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].n_voices = topo[i].n_voices; units[i].voice_off = topo[i].voice_off;
   units[i].n_fx = topo[i].n_fx; units[i].fx_off = topo[i].fx_off;
   units[i].static_defer = topo[i].static_defer;
+  units[i].voice0 = topo[i].voice0;
   units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
 __global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
@@ -491,6 +492,7 @@ static int rebuild_topology(pg_graph* g) {
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
+    u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
   }
   // main-mixer sources: one unit each
@@ -500,6 +502,7 @@ static int rebuild_topology(pg_graph* g) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
     u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
+    u.voice0 = g->voices[v].dev_index;
     vidx.push_back(g->voices[v].dev_index);
     g->order.push_back(slot);
   }

@@ -355,7 +355,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
     } else {
       audible_input = false;
       for (int vi = 0; vi < unit.n_voices; ++vi) {
-        PgVoice* gv = &L.voices[L.voice_index[unit.voice_off + vi]];
+        PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
         audible_input |= voice_process(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
       }
     }

@@ -33,6 +33,17 @@ DEVO void src_carve(char* base, SrcScratch& s) {
   s.sched_c = (uint16_t*)base;
 }
 
+// Steady-state per-sample scalings of the source chain folded into the resampler's output loop: VolumeFader target
+// (fader.rs:105-107), AmplifiedSource gain (smoothing.rs:67-70), PannedSource factors (smoothing.rs:100-108). Same
+// multiplications in the same order as the separate passes; only used when nothing ramps and the file is stereo.
+struct SrcPost { int on; int use_f, use_g, use_p; float fs, gain, pl, pr; };
+DEVO float src_post(const SrcPost& P, float v, int ch) {
+  if (P.use_f) v = v * P.fs;
+  if (P.use_g) v = v * P.gain;
+  if (P.use_p) v = v * (ch ? P.pr : P.pl);
+  return v;
+}
+
 // Hermite x-form  src/utils/resampler/cubic.rs:125-142
 DEVO float cubic_interp(float ym1, float y0, float y1, float y2, float fraction) {
   float c0 = y0;
@@ -44,7 +55,9 @@ DEVO float cubic_interp(float ym1, float y0, float y1, float y2, float fraction)
 
 // PreloadedFileSource::write_buffer (src/source/file/preloaded.rs:270-332) for `out_frames` frames of the file's
 // channel layout into `out` (LDS). `v` is the unit's LDS copy of the voice. Returns frames written (uniform).
-DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScratch& S) {
+// When `acc` is given (steady state), the finished samples are added straight into the mixer's block (add_buffers,
+// src/source/mixed.rs:606-608) instead of going through the temporary mix buffer.
+DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScratch& S, const SrcPost& P, float* acc) {
   const int C = (int)v->channels;
   const int tid = threadIdx.x, nt = blockDim.x;
   // loop range in samples (:273-280)
@@ -60,7 +73,9 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
       uint64_t want = (uint64_t)(out_frames - written) * C;
       int nsm = (int)(remaining_in < want ? remaining_in : want);
-      for (int i = tid; i < nsm; i += nt) out[written * C + i] = v->pcm[pp + i];
+      if (P.on && acc) { for (int i = tid; i < nsm; i += nt) acc[written * C + i] = acc[written * C + i] + src_post(P, v->pcm[pp + i], i & 1); }
+      else if (P.on) { for (int i = tid; i < nsm; i += nt) out[written * C + i] = src_post(P, v->pcm[pp + i], i & 1); }
+      else for (int i = tid; i < nsm; i += nt) out[written * C + i] = v->pcm[pp + i];
       __syncthreads();
       if (tid == 0) {
         v->playback_pos = pp + nsm;
@@ -207,11 +222,30 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       __syncthreads();
     }
     // ---- all lanes: gather the consumed frames (coalesced runs between loop wraps) and the history ----
-    for (int ch = 0; ch < C; ++ch) {
-      float* w = S.win + ch * (SRC_WIN_CAP + 4);
-      if (tid < 4) w[tid] = v->input[ch][3 - tid];  // oldest first: input[3], input[2], input[1], input[0]
-      if (S.ctl[2]) { const uint64_t b = (uint64_t)(uint32_t)S.ctl[3]; for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(b + j) * C + ch]; }
-      else for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(uint64_t)S.posmap[j] * C + ch];
+    if (C == 2 && S.ctl[2]) {
+      // stereo, one contiguous run of input frames: one 8-byte load per frame, four loads in flight per lane
+      typedef __attribute__((address_space(1))) const unsigned long long gu64;  // one 8-byte global load = one stereo frame
+      gu64* src = (gu64*)(v->pcm) + (uint64_t)(uint32_t)S.ctl[3];
+      float* w0 = S.win;
+      float* w1 = S.win + (SRC_WIN_CAP + 4);
+      if (tid < 4) { w0[tid] = v->input[0][3 - tid]; w1[tid] = v->input[1][3 - tid]; }  // oldest first: input[3] .. input[0]
+      for (int jb = 0; jb < c_total; jb += 4 * nt) {
+        unsigned long long x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = jb + k * nt + tid; x[k] = j < c_total ? src[j] : 0ull; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = jb + k * nt + tid;
+          if (j < c_total) { w0[4 + j] = __uint_as_float((uint32_t)x[k]); w1[4 + j] = __uint_as_float((uint32_t)(x[k] >> 32)); }
+        }
+      }
+    } else {
+      for (int ch = 0; ch < C; ++ch) {
+        float* w = S.win + ch * (SRC_WIN_CAP + 4);
+        if (tid < 4) w[tid] = v->input[ch][3 - tid];  // oldest first: input[3], input[2], input[1], input[0]
+        if (S.ctl[2]) { const uint64_t b = (uint64_t)(uint32_t)S.ctl[3]; for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(b + j) * C + ch]; }
+        else for (int j = tid; j < c_total; j += nt) w[4 + j] = v->pcm[(uint64_t)S.posmap[j] * C + ch];
+      }
     }
     __syncthreads();
     PG_STAMP(S.diag, 18);
@@ -220,7 +254,9 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       int k = i / C, ch = i - k * C;
       const float* w = S.win + ch * (SRC_WIN_CAP + 4);
       int c = S.sched_c[k];
-      out[(written + k) * C + ch] = cubic_interp(w[c], w[c + 1], w[c + 2], w[c + 3], S.sched_f[k]);
+      const float y = cubic_interp(w[c], w[c + 1], w[c + 2], w[c + 3], S.sched_f[k]);
+      if (P.on && acc) acc[(written + k) * C + ch] = acc[(written + k) * C + ch] + src_post(P, y, ch);
+      else out[(written + k) * C + ch] = P.on ? src_post(P, y, ch) : y;
     }
     __syncthreads();
     PG_STAMP(S.diag, 19);
@@ -243,7 +279,8 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
 // PreloadedFileSource::write (preloaded.rs:396-475) + ChannelMappedSource::write (mapped.rs:61-99) +
 // AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
 // Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
-DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S) {
+DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
+  *added = 0;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int C = (int)v->channels;
   // process_messages: Stop (preloaded.rs:195-208)
@@ -260,8 +297,24 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   }
   __syncthreads();
   if (v->finished) return 0;
-  int wf = src_write_buffer(v, out, frames, S);  // frames of the file layout
+  SrcPost P;
+  P.on = (C == 2 && v->fader_state != 1 && !sm_need_ramp(v->volume) && !sm_need_ramp(v->panning)) ? 1 : 0;
+  P.fs = v->fader_target; P.use_f = P.fs != 1.0f;
+  P.gain = v->volume.target; P.use_g = fabsf(1.0f - P.gain) > 0.000001f;
+  P.use_p = fabsf(v->panning.target) > 0.000001f; P.pl = 1.0f; P.pr = 1.0f;
+  if (P.use_p) panning_factors(v->panning.target, P.pl, P.pr);
+  int wf = src_write_buffer(v, out, frames, S, P, P.on ? acc : nullptr);  // frames of the file layout
+  *added = P.on && acc ? 1 : 0;
   int total = wf * C;
+  if (P.on) {  // fader / gain / pan were applied in the resampler's output loop; only the end-of-block bookkeeping is left
+    __syncthreads();
+    if (tid == 0) {  // preloaded.rs:465-472
+      bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;
+      if (v->pos_eof || fade_out_completed) v->finished = 1;
+    }
+    __syncthreads();
+    return total;
+  }
   // VolumeFader::process  fader.rs:103-122
   if (v->fader_state != 1) {
     float tv = v->fader_target;
@@ -363,8 +416,9 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     uint64_t remaining = (uint64_t)(out_len - total_written);
     if (samples_until_stop < remaining) remaining = samples_until_stop;
     int to_write = (int)(remaining < 8192 ? remaining : 8192);
-    int written = voice_write(lv, tmp, to_write / 2, pending_stop, S);
-    for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
+    int added;
+    int written = voice_write(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
+    if (!added) for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
     __syncthreads();
     total_written += written;
     produced_output |= written > 0;
