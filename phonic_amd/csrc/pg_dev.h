@@ -242,6 +242,7 @@ struct PgLaunch {
   uint64_t pos;           // SourceTime.pos_in_frames of the first frame
   uint32_t sample_rate;
   int32_t fast;           // 1: time-parallel paths enabled
+  int32_t wide;           // fast kernel variant: 0 = lean (Gain/Panning/Reverb), 1 = all fast-capable kinds
   int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only
   float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
   uint32_t out_stride;    // floats per unit row

@@ -21,11 +21,46 @@ constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 
 
 #include "pg_reverb_fast.inl"
 
+// FilterEffect (filter.rs:193-200) and Eq5Effect (eq5.rs:297-326) in steady state: cascaded TPT-SVF biquads on the f32
+// signal, each stage a blocked scan over the block (see rev_biquad_scan_t). The block is staged as f64 in the skewed
+// scratch buffer; `as f32` between stages is reproduced by rounding every stage's output through f32.
+DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs, PgState2* st /*[ch][n_stages]*/, int n_stages, int st_stride,
+                            FastCtx& fc) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* buf = (double*)fc.scratch;
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  PgState2* lst = (PgState2*)(xchg + 4);  // [2] per-stage state view for the scan
+  const int frames = n_samples / 2;
+  for (int done = 0; done < frames; done += 1024) {
+    const int T = frames - done < 1024 ? frames - done : 1024;
+    __syncthreads();
+    for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
+    __syncthreads();
+    for (int k = 0; k < n_stages; ++k) {
+      if (tid < 2) lst[tid] = st[tid * st_stride + k];
+      __syncthreads();
+      rev_biquad_scan_t<true>(coefs[k], lst, buf, T, xchg);
+      __syncthreads();
+      if (tid < 2) st[tid * st_stride + k] = lst[tid];
+    }
+    __syncthreads();
+    for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)];
+  }
+  __syncthreads();
+}
+DEVO bool eq5_steady(const PgEq5& e) {
+  bool ramp = false;
+  for (int i = 0; i < 5; ++i) ramp = ramp || sm_need_ramp(e.freqs[i]) || sm_need_ramp(e.bws[i]) || sm_need_ramp(e.gains[i]);
+  return !ramp;
+}
+
 // Must mirror the acceptance conditions of fx_fast_process exactly: the fast kernel has no serial code to fall back to.
 DEVO bool fx_fast_eligible(const PgFx& fx) {
   switch (fx.kind) {
     case 0: return fx.u.gain.dc_mode == 0 && !sm_need_ramp(fx.u.gain.gain);
     case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
+    case 2: return !sm_need_ramp(fx.u.filter.cutoff) && !sm_need_ramp(fx.u.filter.q);
+    case 3: return eq5_steady(fx.u.eq5);
     case 5: return reverb_fast_eligible(fx);
     case 9: return !sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f);
     default: return false;
@@ -33,8 +68,11 @@ DEVO bool fx_fast_eligible(const PgFx& fx) {
 }
 
 // Memoryless / constant-gain cases: every sample is independent.
+// KMASK: bit k set = the code of effect kind k is compiled into this kernel variant (register budget of the hot variants).
+template <int KMASK>
 DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (!((KMASK >> fx.kind) & 1)) return false;
   switch (fx.kind) {
     case 0: {  // GainEffect without DC filter and without ramp: scale_buffer (gain.rs:162-165)
       const PgGain& g = fx.u.gain;
@@ -65,8 +103,20 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       __syncthreads();
       return true;
     }
-    case 5: return reverb_fast(fx, sig, n, fc);
-    case 9: {  // DistortionEffect, no ramps (distortion.rs:331-341)
+    case 2: if constexpr ((KMASK >> 2) & 1) {  // FilterEffect, no ramp (filter.rs:193-200)
+      PgFilter& f = fx.u.filter;
+      if (sm_need_ramp(f.cutoff) || sm_need_ramp(f.q)) return false;
+      biquad_chain_fast(sig, n, &f.coef, f.st, 1, 1, fc);
+      return true;
+    } else return false;
+    case 3: if constexpr ((KMASK >> 3) & 1) {  // Eq5Effect, no ramp (eq5.rs:297-326)
+      PgEq5& e = fx.u.eq5;
+      if (!eq5_steady(e)) return false;
+      biquad_chain_fast(sig, n, e.coef, &e.st[0][0], 5, 5, fc);
+      return true;
+    } else return false;
+    case 5: if constexpr ((KMASK >> 5) & 1) return reverb_fast(fx, sig, n, fc); else return false;
+    case 9: if constexpr ((KMASK >> 9) & 1) {  // DistortionEffect, no ramps (distortion.rs:331-341)
       const PgDist& d = fx.u.dist;
       if (sm_need_ramp(d.mix) || sm_need_ramp(d.drive)) return false;
       if (d.mix.target == 0.0f) return true;
@@ -78,7 +128,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       for (int i = tid; i < n; i += nt) sig[i] = dist_shape(ty, sig[i], drive) * comp;
       __syncthreads();
       return true;
-    }
+    } else return false;
     default: return false;
   }
 }

@@ -405,6 +405,7 @@ struct pg_graph {
   hipStream_t stream = nullptr;
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
+  bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
   bool defer_bus = false;
   // host mirrors
   std::vector<HostMixer> mixers;        // [0] = main
@@ -487,7 +488,8 @@ static int rebuild_topology(pg_graph* g) {
     for (int f : mx.fx) {
       fidx.push_back(f);
       const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)
-      if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_REVERB || k == PG_FX_DISTORTION)) u.static_defer = 1;
+      if (m != 0 && (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DISTORTION)) g->wide = true;
+      if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_REVERB || k == PG_FX_DISTORTION)) u.static_defer = 1;
       if (k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) u.static_defer = 1;  // DC filter: serial recurrence
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
@@ -831,7 +833,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   }
   if (timed) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
   if (g->fast) {
-    L.mode = 1;  // lean fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+    L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
     HIP_TRY(pg_launch_units(L, stream));
     if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
     L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit

@@ -196,13 +196,13 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
 
 // ---- Effect::process dispatch: time-parallel steady-state path when eligible, exact serial path otherwise ----
 // FAST_ONLY kernels contain no serial effect code at all (register budget); eligibility was checked up front.
-template <bool FAST_ONLY>
+template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
   if (FAST_ONLY) {
-    (void)fx_fast_process(fx, sig, n, fc);
+    (void)fx_fast_process<KMASK>(fx, sig, n, fc);
     return;
   } else {
-    if (fast && fx_fast_process(fx, sig, n, fc)) return;
+    if (fast && fx_fast_process<KMASK>(fx, sig, n, fc)) return;
     __syncthreads();
     if (threadIdx.x == 0) {
       switch (fx.kind) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
 
 // ---- EffectProcessor::process  src/source/mixed/effect.rs:56-145 -------------------------------------
 // ctl: LDS words for uniform decisions. Returns true when the effect processed output.
-template <bool FAST_ONLY>
+template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
                                      float* red) {
   __syncthreads();
@@ -237,7 +237,7 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
   __syncthreads();
   if (ctl[0]) return false;
   PG_STAMP(fc.diag, 9);
-  fx_process_wg<FAST_ONLY>(fx, sig, n, fc, fast);
+  fx_process_wg<FAST_ONLY, KMASK>(fx, sig, n, fc, fast);
   if (input_bypassed) {  // update_tail_counters :111-145
     if (threadIdx.x == 0) {
       uint64_t tail_frames;
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
 // dynamic LDS: [sig 2*n_frames f32][tmp 2*n_frames f32][scratch]
 extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 
-template <bool FAST_ONLY>
+template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
   if ((int)blockIdx.x >= L.n_units) return;
   const int u = L.unit_order ? L.unit_order[blockIdx.x] : L.unit_base + (int)blockIdx.x;
@@ -375,8 +375,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
           PgFx& fx = *lfx;
           PG_STAMP(L.diag, 8);
           bool is_active;
-          if (fx.standalone) { fx_process_wg<FAST_ONLY>(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
-          else is_active = fx_processor_process<FAST_ONLY>(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+          if (fx.standalone) { fx_process_wg<FAST_ONLY, KMASK>(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
+          else is_active = fx_processor_process<FAST_ONLY, KMASK>(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
           if (is_active) { input_bypassed = false; all_bypassed = false; }
           __syncthreads();
           for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
@@ -433,8 +433,13 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
 #ifndef PG_FAST_WAVES
 #define PG_FAST_WAVES 2
 #endif
-__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true>(L); }
-__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) { pg_unit_body<false>(L); }
+// Fast-kernel variants by the effect kinds compiled in: the lean one (Gain, Panning, Reverb = the headline per-voice chain)
+// keeps the hot loop free of spills; the wide one adds Filter, Eq5 and Distortion. The host picks by the kinds present.
+#define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
+#define PG_KMASK_ALL 0x3ff
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true, PG_KMASK_LEAN>(L); }
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) { pg_unit_body<true, PG_KMASK_ALL>(L); }
+__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) { pg_unit_body<false, PG_KMASK_ALL>(L); }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
 // Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
@@ -491,9 +496,12 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)pg_unit_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)pg_unit_kernel_fast_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (L.mode == 1) hipLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), lds, stream, L);
+  if (L.mode == 1 && L.wide) hipLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), lds, stream, L);
+  else if (L.mode == 1) hipLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), lds, stream, L);
   else hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units), dim3(256), lds, stream, L);
   return hipGetLastError();
 }

@@ -112,7 +112,8 @@ DEVO Mat2 mat2_mul(const Mat2& x, const Mat2& y) { return Mat2{x.a * y.a + x.b *
 //           wave of a channel is seeded with the lower wave's final state through LDS);
 //   pass 2: each segment re-run from its true start state, writing the outputs.
 // Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative).
-DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
+template <bool ROUND_F32>
+DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
@@ -170,11 +171,14 @@ DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int 
     double v2 = b2 + a2 * b1 + a3 * v3;
     b1 = 2.0 * v1 - b1;
     b2 = 2.0 * v2 - b2;
-    buf[REV_IDX(n0 + k, ch)] = m0 * v0 + m1 * v1 + m2 * v2;
+    const double y = m0 * v0 + m1 * v1 + m2 * v2;
+    buf[REV_IDX(n0 + k, ch)] = ROUND_F32 ? (double)(float)y : y;  // `as f32` between cascaded stages (eq5.rs:318-320)
   }
   __syncthreads();  // all lanes have read the carried state
   if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
 }
+
+DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg) { rev_biquad_scan_t<false>(c, st, buf, T, xchg); }
 
 // steady state and a geometry whose shortest feedback lag leaves room for a chunk (always true for valid room sizes)
 DEVO bool reverb_fast_eligible(const PgFx& fx) {

@@ -198,3 +198,27 @@ def test_write_device_matches_write():
         pos += 1024
     g2.synchronize()
     assert np.array_equal(dev.cpu().numpy().reshape(-1), host)
+
+
+def test_fast_kernel_generic_kernel_handover_on_parameter_ramp():
+    """A reverb parameter change in the middle of a run: the unit leaves the time-parallel kernel for the exact per-frame
+    path while room/wet ramp (delay lengths and filter coefficients change every frame) and returns afterwards."""
+    def build(g):
+        ids = []
+        for i in range(3):
+            m = g.add_mixer()
+            ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i)))
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.3), 2, 44100, volume=0.5, panning=workloads.voice_pan(i), has_repeat=1,
+                        repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    def act2(g, ids, pos):
+        g.schedule_param(ids[0], "room", 0.2, pos + 100)
+        g.schedule_param(ids[1], "wet ", 0.9, pos + 700)
+
+    def act5(g, ids, pos):
+        g.schedule_param(ids[0], "room", 0.95, pos)
+        g.schedule_reset(ids[2], pos + 512)
+
+    a, b = both(build, 10, 1024, actions={2: act2, 5: act5}, max_frames=1024)
+    compare(a, b)
