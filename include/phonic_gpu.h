@@ -177,6 +177,11 @@ int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time);
 int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time);
 int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time);
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time);
+/* FilePlaybackHandle::set_speed(speed, glide) / seek(position) (src/player/handles/file.rs -> MixerMessage::SetSourceSpeed /
+ * SeekSource, src/source/mixed.rs:338-383; PreloadedFileSource::set_speed / seek, src/source/file/preloaded.rs:139-192).
+ * glide_semitones_per_second <= 0 = no glide (Option<f32>::None). */
+int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glide_semitones_per_second, uint64_t sample_time);
+int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint64_t sample_time);
 
 /* Source::write(&mut output, &SourceTime{pos_in_frames}) of the main MixedSource
  * (src/source/mixed.rs:659-719): returns the samples written == n_samples, or 0 when the

@@ -211,6 +211,20 @@ int po_graph_stop_voice(po_graph* g, int voice, uint64_t sample_time) {
   it->second->message_queue.push_back(std::move(m));
   return PG_OK;
 }
+int po_graph_set_voice_speed(po_graph* g, int voice, double speed, float glide, uint64_t sample_time) {
+  auto it = g->voice_mixer.find(voice);
+  if (it == g->voice_mixer.end()) return PG_ERR_NOT_FOUND;
+  MixedSource::MixerEvent ev;
+  ev.kind = MixedSource::MixerEvent::SetSourceSpeed; ev.id = voice; ev.sample_time = sample_time; ev.a = speed; ev.f = glide; ev.flag = glide > 0.0f;
+  return push_event(it->second, ev);
+}
+int po_graph_seek_voice(po_graph* g, int voice, double seconds, uint64_t sample_time) {
+  auto it = g->voice_mixer.find(voice);
+  if (it == g->voice_mixer.end()) return PG_ERR_NOT_FOUND;
+  MixedSource::MixerEvent ev;
+  ev.kind = MixedSource::MixerEvent::SeekSource; ev.id = voice; ev.sample_time = sample_time; ev.a = seconds;
+  return push_event(it->second, ev);
+}
 size_t po_graph_write(po_graph* g, float* out, size_t n_samples, uint64_t pos) { return g->main->write(out, n_samples, pos); }
 
 // CPU baseline helper for bench.py: runs `n_blocks` write() calls of `block_samples` on each of `n_graphs`

@@ -120,6 +120,8 @@ def declare(lib, prefix):
         "graph_set_voice_volume": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_set_voice_panning": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_stop_voice": (C.c_int, [vp, C.c_int, C.c_uint64]),
+        "graph_set_voice_speed": (C.c_int, [vp, C.c_int, C.c_double, C.c_float, C.c_uint64]),
+        "graph_seek_voice": (C.c_int, [vp, C.c_int, C.c_double, C.c_uint64]),
         "graph_write": (C.c_size_t, [vp, P(C.c_float), C.c_size_t, C.c_uint64]),
     }
     for name, (res, args) in sigs.items():

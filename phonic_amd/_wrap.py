@@ -152,6 +152,13 @@ class GraphHandle:
     def stop_voice(self, voice, sample_time):
         self._check(self._fn("graph_stop_voice")(self._h, voice, sample_time))
 
+    def set_voice_speed(self, voice, speed, sample_time, glide=None):
+        """FilePlaybackHandle::set_speed(speed, glide): glide in semitones per second, None = immediate."""
+        self._check(self._fn("graph_set_voice_speed")(self._h, voice, float(speed), float(glide) if glide else 0.0, sample_time))
+
+    def seek_voice(self, voice, seconds, sample_time):
+        self._check(self._fn("graph_seek_voice")(self._h, voice, float(seconds), sample_time))
+
     def write(self, out, pos_in_frames):
         """`Source::write`: fills `out` (float32 interleaved), returns samples written."""
         assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]

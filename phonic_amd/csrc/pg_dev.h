@@ -166,6 +166,10 @@ struct PgVoice {
   // PlayingSource (src/source/mixed.rs:34-42)
   uint64_t start_time, stop_time;
   int32_t has_stop, active;
+  // speed / glide (FileSourceImpl, src/source/file/common.rs:47-52)
+  double current_speed, target_speed;
+  float speed_glide_rate;
+  uint32_t samples_to_next_speed_update;
   int32_t sched_class, sched_rep;  // resampler schedule cache: class of voices sharing a ratio; 1 = this voice publishes the schedule
 };
 
@@ -219,6 +223,8 @@ enum PgCmdType {
   CMD_VOICE_VOLUME = 2, // target = voice index
   CMD_VOICE_PAN = 3,
   CMD_VOICE_STOP = 4,   // sets stop_time = value64
+  CMD_VOICE_SPEED = 5,  // value64 = f64 bits of the speed, value = glide (semitones/s, <= 0: none)
+  CMD_VOICE_SEEK = 6,   // value64 = f64 bits of the position in seconds
 };
 struct PgCmd {
   int32_t type, unit, target, param;

@@ -679,6 +679,7 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
   v.start_time = opt->start_time;
   v.active = 1;
+  v.current_speed = opt->speed; v.target_speed = opt->speed; v.speed_glide_rate = 0.0f; v.samples_to_next_speed_update = 0;
   {  // resampler schedule cache class: voices sharing the f32 ratio; the first one publishes
     uint32_t rb;
     memcpy(&rb, &v.ratio, 4);
@@ -760,6 +761,24 @@ static int voice_event(pg_graph* g, int voice_id, int type, float value, uint64_
 }
 int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_VOLUME, volume, sample_time); }
 int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_PAN, panning, sample_time); }
+int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glide, uint64_t sample_time) {
+  if (!(speed > 0.0)) return set_error(PG_ERR_PARAMETER, "speed must be > 0");
+  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_VOICE_SPEED; c.target = g->voices[voice_id].dev_index; c.value = glide; c.param = voice_id;
+  memcpy(&c.value64, &speed, 8);
+  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+}
+int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint64_t sample_time) {
+  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  if (!(position_seconds >= 0.0)) return set_error(PG_ERR_PARAMETER, "seek position must be >= 0");
+  PgCmd c;
+  memset(&c, 0, sizeof c);
+  c.type = CMD_VOICE_SEEK; c.target = g->voices[voice_id].dev_index; c.param = voice_id;
+  memcpy(&c.value64, &position_seconds, 8);
+  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+}
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // MixerMessage::StopSource (mixed.rs:389-400): not an event
   if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   PgCmd c;
@@ -877,7 +896,7 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
     while (!main.events.empty() && main.events.front().sample_time <= now) {
       PgCmd c = main.events.front().cmd;
       c.frame = 0;
-      c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET) ? main.unit_slot : g->source_unit_of_voice[c.param];
+      c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET) ? main.unit_slot : g->source_unit_of_voice[c.param];  // voice commands carry the voice id in `param`
       cmds.push_back(c);
       main.events.erase(main.events.begin());
     }

@@ -336,6 +336,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
         else if (cmd.type == CMD_VOICE_VOLUME) sm_set_target(L.voices[cmd.target].volume, cmd.value);
         else if (cmd.type == CMD_VOICE_PAN) sm_set_target(L.voices[cmd.target].panning, cmd.value);
         else if (cmd.type == CMD_VOICE_STOP) { L.voices[cmd.target].has_stop = 1; L.voices[cmd.target].stop_time = cmd.value64; }
+        else if (cmd.type == CMD_VOICE_SPEED) voice_set_speed(&L.voices[cmd.target], __longlong_as_double((long long)cmd.value64), cmd.value);
+        else if (cmd.type == CMD_VOICE_SEEK) voice_seek(&L.voices[cmd.target], __longlong_as_double((long long)cmd.value64));
         ctl[2] = flush;
       }
       __syncthreads();
@@ -356,7 +358,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
       audible_input = false;
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
-        audible_input |= voice_process(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
+        audible_input |= voice_process<!FAST_ONLY>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
       }
     }
     PG_STAMP(L.diag, 1);
@@ -393,6 +395,10 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
   if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
     int ramping = 0;
     for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]]) ? 0 : 1;
+    for (int vi = 0; vi < unit.n_voices; ++vi) {  // a pitch glide in progress is rendered here as well
+      const PgVoice& vv = L.voices[L.voice_index[unit.voice_off + vi]];
+      ramping |= (vv.current_speed != vv.target_speed) ? 1 : 0;
+    }
     unit.maybe_ramping = ramping;
   }
   PG_STAMP(L.diag, 14);

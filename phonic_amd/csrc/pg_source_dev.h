@@ -276,9 +276,45 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
   return written;
 }
 
+// FileSourceImpl::update_speed  src/source/file/common.rs:141-169 (lane 0)
+DEVO void voice_update_speed(PgVoice* v) {
+  const double speed_diff = v->target_speed - v->current_speed;
+  if (v->speed_glide_rate > 0.0f && fabs(speed_diff) > 0.0001) {
+    const double semitone_diff = fabs(12.0 * log2(v->target_speed / v->current_speed));
+    const float duration_secs = (float)semitone_diff / v->speed_glide_rate;
+    if (duration_secs > 0.0f) {
+      const float duration_frames = duration_secs * (float)v->out_rate;
+      const double speed_step_per_frame = (v->target_speed - v->current_speed) / (double)duration_frames;
+      const double speed_change_this_call = speed_step_per_frame * 64.0;  // SPEED_UPDATE_CHUNK_SIZE
+      if (fabs(v->target_speed - v->current_speed) < fabs(speed_change_this_call)) v->current_speed = v->target_speed;
+      else v->current_speed += speed_change_this_call;
+    } else v->current_speed = v->target_speed;
+  } else v->current_speed = v->target_speed;
+  const uint32_t new_output_rate = (uint32_t)d2u64((double)v->out_rate / v->current_speed);
+  v->ratio = (float)((double)v->src_rate / (double)new_output_rate);  // CubicResampler::update  cubic.rs:188-200
+}
+// PreloadedFileSource::set_speed  preloaded.rs:181-192 (lane 0)
+DEVO void voice_set_speed(PgVoice* v, double speed, float glide) {
+  if (v->finished) return;
+  v->samples_to_next_speed_update = 0;
+  v->target_speed = speed;
+  v->speed_glide_rate = glide > 0.0f ? glide : 0.0f;
+  if (v->speed_glide_rate == 0.0f) { v->current_speed = speed; voice_update_speed(v); }
+}
+// PreloadedFileSource::seek  preloaded.rs:139-147 (lane 0)
+DEVO void voice_seek(PgVoice* v, double seconds) {
+  if (v->finished) return;
+  const double buffer_pos = seconds * (double)v->src_rate * (double)v->channels;
+  uint64_t p = d2u64(buffer_pos);
+  v->playback_pos = p < v->n_samples ? p : v->n_samples;
+  for (int c = 0; c < 2; ++c) { for (int k = 0; k < 4; ++k) v->input[c][k] = 0.0f; v->sub_pos[c] = 0.0f; v->initialized[c] = 0; }  // resampler.reset()
+}
+
 // PreloadedFileSource::write (preloaded.rs:396-475) + ChannelMappedSource::write (mapped.rs:61-99) +
 // AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
 // Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
+// GLIDE = false: the kernel variant never sees a gliding voice (the fast kernel defers such units), so the loop is left out.
+template <bool GLIDE>
 DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
   *added = 0;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -303,7 +339,31 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   P.gain = v->volume.target; P.use_g = fabsf(1.0f - P.gain) > 0.000001f;
   P.use_p = fabsf(v->panning.target) > 0.000001f; P.pl = 1.0f; P.pr = 1.0f;
   if (P.use_p) panning_factors(v->panning.target, P.pl, P.pr);
-  int wf = src_write_buffer(v, out, frames, S, P, P.on ? acc : nullptr);  // frames of the file layout
+  int wf;
+  if (GLIDE && v->current_speed != v->target_speed) {
+    // pitch glide: the resampler is re-targeted every 64 frames (preloaded.rs:421-446, common.rs:56)
+    wf = 0;
+    while (wf < frames) {
+      __syncthreads();
+      if (tid == 0 && v->samples_to_next_speed_update == 0) {
+        if (v->current_speed != v->target_speed) voice_update_speed(v);
+        v->samples_to_next_speed_update = 64u * (uint32_t)C;
+      }
+      __syncthreads();
+      int chunk = frames - wf;
+      const int until = (int)(v->samples_to_next_speed_update / (uint32_t)C);
+      if (chunk > until) chunk = until;
+      const int w = src_write_buffer(v, out + wf * C, chunk, S, P, (P.on && acc) ? acc + wf * C : nullptr);
+      __syncthreads();
+      if (tid == 0) v->samples_to_next_speed_update -= (uint32_t)(w * C);
+      wf += w;
+      if (w < chunk) break;  // input exhausted
+    }
+    __syncthreads();
+  } else {
+    if (tid == 0) v->samples_to_next_speed_update = 0;
+    wf = src_write_buffer(v, out, frames, S, P, P.on ? acc : nullptr);  // frames of the file layout
+  }
   *added = P.on && acc ? 1 : 0;
   int total = wf * C;
   if (P.on) {  // fader / gain / pan were applied in the resampler's output loop; only the end-of-block bookkeeping is left
@@ -377,6 +437,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 
 // MixedSource::process_sources for ONE playing source (src/source/mixed.rs:558-624): renders into `tmp` and adds
 // into `sig`. Returns true when the source produced output.
+template <bool GLIDE>
 DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
                         const PgSchedEntry* sched, int sched_bank) {
   SrcScratch S = S0;
@@ -417,7 +478,7 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     if (samples_until_stop < remaining) remaining = samples_until_stop;
     int to_write = (int)(remaining < 8192 ? remaining : 8192);
     int added;
-    int written = voice_write(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
+    int written = voice_write<GLIDE>(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
     if (!added) for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
     __syncthreads();
     total_written += written;

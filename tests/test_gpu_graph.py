@@ -222,3 +222,30 @@ def test_fast_kernel_generic_kernel_handover_on_parameter_ramp():
 
     a, b = both(build, 10, 1024, actions={2: act2, 5: act5}, max_frames=1024)
     compare(a, b)
+
+
+def test_speed_glide_and_seek():
+    """FilePlaybackHandle::set_speed (immediate and with a glide in semitones/s: the resampler ratio is re-targeted every
+    64 frames, common.rs:141-169) and seek (position jump + resampler reset), scheduled at sample times inside blocks."""
+    def build(g):
+        v0 = g.add_voice(0, workloads.tone_buffer(2, 44100, 0.4), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        v1 = g.add_voice(0, workloads.tone_buffer(7, 48000, 0.4, channels=1), 1, 48000, volume=0.5, panning=0.3, has_repeat=1,
+                         repeat=_capi.PG_REPEAT_FOREVER)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(21))
+        v2 = g.add_voice(m, workloads.tone_buffer(9, 44100, 0.4), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return [v0, v1, v2]
+
+    def act1(g, ids, pos):
+        g.set_voice_speed(ids[0], 1.5, pos + 200)             # immediate: ratio > 1 branch
+        g.set_voice_speed(ids[1], 0.5, pos + 10, glide=48.0)  # glide down one octave at 48 st/s = 0.25 s
+        g.set_voice_speed(ids[2], 2.0, pos + 333, glide=96.0)
+
+    def act3(g, ids, pos):
+        g.seek_voice(ids[0], 0.05, pos + 77)
+        g.seek_voice(ids[2], 0.2, pos + 900)
+        g.set_voice_speed(ids[0], 0.75, pos + 512, glide=24.0)
+
+    a, b = both(build, 16, 1024, actions={1: act1, 3: act3}, max_frames=1024)
+    compare(a, b)
+    assert not np.array_equal(a[:2048], a[2048 * 8:2048 * 9])
