@@ -215,6 +215,8 @@ struct PgUnit {
   int32_t maybe_ramping;        // device: a parameter command was applied and some smoother may still ramp (cleared by the generic
                                 // kernel once every effect of the unit is back in steady state)
   int32_t voice0;               // host: device index of the unit's first voice (skips one dependent load at kernel start)
+  int32_t fx0;                  // host: device index of the unit's first effect (prefetched during the source stage)
+  int32_t pad3;
 };
 
 enum PgCmdType {

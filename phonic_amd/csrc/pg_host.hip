@@ -454,6 +454,7 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].n_fx = topo[i].n_fx; units[i].fx_off = topo[i].fx_off;
   units[i].static_defer = topo[i].static_defer;
   units[i].voice0 = topo[i].voice0;
+  units[i].fx0 = topo[i].fx0;
   units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
 __global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
@@ -485,6 +486,7 @@ static int rebuild_topology(pg_graph* g) {
     PgUnit& u = topo[mx.unit_slot];
     u.fx_off = (int)fidx.size(); u.n_fx = (int)mx.fx.size();
     u.static_defer = 0;
+    u.fx0 = mx.fx.empty() ? 0 : mx.fx[0];
     for (int f : mx.fx) {
       fidx.push_back(f);
       const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)

@@ -311,6 +311,13 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
     __syncthreads();
     if (!ctl[5]) return;
   }
+  // Prefetch the first effect's state block (one dword per lane, ~1 KB): the HBM round trip completes under the source
+  // stage; the words are parked in a register until the chain stages them in LDS.
+  unsigned long long fx0_word = 0;
+  const int n_fx_words = (int)(sizeof(PgFx) / 4);
+  static_assert(sizeof(PgFx) % 8 == 0 && sizeof(PgFx) / 8 <= 256, "PgFx must fit one qword per lane of the workgroup");
+  if (FAST_ONLY && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
+  bool fx0_fresh = FAST_ONLY && unit.n_fx > 0;  // the generic kernel applies commands to the global copy first
   const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
   float* ext = L.bus;
   if (external) {
@@ -372,7 +379,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
           // delay-length updates, ring positions) then costs LDS instead of HBM round trips; written back afterwards
           PgFx& gfx = L.fx[L.fx_index[unit.fx_off + fi]];
           __syncthreads();
-          for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
+          if (fi == 0 && fx0_fresh) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; fx0_fresh = false; }
+          else for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
           __syncthreads();
           PgFx& fx = *lfx;
           PG_STAMP(L.diag, 8);
