@@ -13,7 +13,12 @@
 #ifdef PG_DIAG
 #define PG_STAMP(ptr, k) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) (ptr)[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PG_STAMP_VAL(ptr, k, v) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) (ptr)[k] = (unsigned long long)(v); } while (0)
+// accumulating lap timer (wave 0 of workgroup 0): adds the shader clocks since the previous lap to slot k
+#define PG_LAP(ptr, k, t) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); lapacc[(k) - 50] += t1_ - (t); (t) = t1_; } } while (0)
+#define PG_LAP_DECL(t) unsigned long long t = __builtin_amdgcn_s_memtime()
 #else
+#define PG_LAP(ptr, k, t) do { } while (0)
+#define PG_LAP_DECL(t) do { } while (0)
 #define PG_STAMP_VAL(ptr, k, v) do { } while (0)
 #define PG_STAMP(ptr, k) do { } while (0)
 #endif

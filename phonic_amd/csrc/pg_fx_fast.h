@@ -17,7 +17,7 @@ struct FastCtx {
   unsigned long long* diag;
 };
 
-constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 3 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
+constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
 
 #include "pg_reverb_fast.inl"
 

@@ -70,6 +70,40 @@ DEVO uint32_t rev_at(const RevDesc& d, uint32_t i) {
   return i == 0 ? d.p0 : i - 1;  // stale position above a shrunk ring: the first write lands there, then 0, 1, 2 ...
 }
 
+// values every lane of the workgroup agrees on, moved to scalar registers (loop control and ring arithmetic go to the SALU)
+DEVO uint32_t uni_u32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+DEVO double uni_f64(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Workgroup-uniform ring descriptor held in scalar registers: ring arithmetic on it costs no LDS round trip.
+//   position of frame i = (pe + i) mod m, except the first write above a shrunk ring (`stale`), which lands on the raw p0.
+struct RevRing {
+  double* buf;
+  uint32_t p0, m, pe, stale;
+};
+DEVO RevRing rev_ring_uniform(const RevDesc& d) {
+  const unsigned long long b = (unsigned long long)d.buf;
+  const uint32_t lo = uni_u32((uint32_t)b), hi = uni_u32((uint32_t)(b >> 32));
+  RevRing u;
+  u.buf = (double*)(((unsigned long long)hi << 32) | lo);
+  u.p0 = uni_u32(d.p0);
+  const uint32_t delay = uni_u32(d.delay);
+  u.m = delay + 1;
+  u.stale = u.p0 > delay ? 1u : 0u;
+  u.pe = u.stale ? delay : u.p0;
+  return u;
+}
+DEVO uint32_t ring_wrap(uint32_t v, uint32_t m) { const uint32_t w = v - m; return v < w ? v : w; }  // v < 2m: one conditional subtract
+DEVO uint32_t ring_at(const RevRing& R, uint32_t i) {   // == rev_at(desc, i) for i <= m
+  uint32_t v = ring_wrap(R.pe + i, R.m);
+  if (R.stale) { if (i == 0) v = R.p0; }  // uniform (scalar) branch, practically never taken
+  return v;
+}
+// element address of (ring position, channel) in the [pos][2] f64 ring
+DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) { return (gdouble*)R.buf + ((pos << 1) | (uint32_t)ch); }
+
 DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
   double v = (double)x;
   if (fabs(v) < 1.18e-23) v = (double)fpd * 1.18e-17;
@@ -201,10 +235,14 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   double* gl = (double*)lp;    lp += 16 * 8;                 // [16] epilogue gets
   RevDesc* desc = (RevDesc*)lp; lp += 13 * sizeof(RevDesc);  // [13]
   double* xchg = (double*)lp;  lp += 4 * 8;                  // biquad scan hand-over
-  double* anch = (double*)lp;  lp += 9 * 16 * 3 * 8;         // [9][16] {sin, cos, d_eps} anchors: 8 sub-chunks + the epilogue
+  double* anch = (double*)lp;  lp += 9 * 16 * 2 * 8;         // [9][16] {sin, cos} anchors: 8 sub-chunks + the epilogue
   double* vtab = (double*)lp;  lp += 8 * 129 * 2 * 8;        // vibrato rotation table (LDS copy)
   int* ctl = fc.ctl;
   constexpr int T_CAP = 1024;
+#ifdef PG_DIAG
+  unsigned long long* lapacc = (unsigned long long*)lp;  // 8 lap accumulators in the scratch slack
+  if (tid == 0) for (int i = 0; i < 8; ++i) lapacc[i] = 0;
+#endif
 
   // vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store
   {
@@ -230,8 +268,8 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   }
   __syncthreads();
   PG_STAMP(fc.diag, 10);
-  const double blend = gl[0], regen = gl[1], wet = gl[2];
-  const uint32_t predelay = (uint32_t)ctl[4];
+  const double blend = uni_f64(gl[0]), regen = uni_f64(gl[1]), wet = uni_f64(gl[2]);
+  const uint32_t predelay = uni_u32((uint32_t)ctl[4]);
   __syncthreads();
   // chunk length bound: all reads must hit pre-chunk data
   uint32_t t_max = predelay;
@@ -239,6 +277,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   for (int i = 0; i < 8; ++i) { uint32_t d = r.line[i].delay > 17 ? r.line[i].delay - 17 : 0; t_max = t_max < d ? t_max : d; }
   if (t_max < 32) return false;  // degenerate geometry: serial path
   if (t_max > (uint32_t)T_CAP) t_max = T_CAP;
+  t_max = uni_u32(t_max);
 
   PG_STAMP(fc.diag, 11);
   int done = 0;
@@ -263,6 +302,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     int T = frames - done;
     if ((uint32_t)T > t_max) T = (int)t_max;
     for (int i = 0; i < 16; ++i) T = T < ctl[8 + i] ? T : ctl[8 + i];
+    T = (int)uni_u32((uint32_t)T);
     float* s0 = sig + 2 * done;
 
     PG_STAMP(fc.diag, 2);
@@ -271,18 +311,21 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     else if (tid < 12) desc[tid] = RevDesc{r.ap[tid - 8].buf, r.ap[tid - 8].write_pos, r.ap[tid - 8].delay};
     else if (tid == 12) desc[12] = RevDesc{r.pre, r.pre_write_pos & r.pre_mask, predelay};
     __syncthreads();
+    RevRing D[13];  // the same descriptors as scalars (all uses below index them with compile-time constants)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) D[i] = rev_ring_uniform(desc[i]);
 
     // ---- phase 1: predelay (DelayLine<2>::process, delay.rs:47-66) ----
     {
       const int ch0 = tid & 1;  // nt is even: a lane keeps its channel across trips
-      const RevDesc pd = desc[12];
+      const RevRing pd = D[12];
       const uint32_t fpd = ch0 ? r.fpd_r : r.fpd_l;
       for (int s_base = 0; s_base < 2 * T; s_base += 8 * nt) {  // 8 samples per lane and trip: all loads in flight together
         double pv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int s = s_base + k * nt + tid;
-          pv[k] = s < 2 * T ? ((const gdouble*)pd.buf)[(size_t)rev_at(pd, (s >> 1) + 1) * 2 + ch0] : 0.0;
+          pv[k] = s < 2 * T ? *ring_ptr(pd, ring_at(pd, (s >> 1) + 1), ch0) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -295,7 +338,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int s = s_base + k * nt + tid;
-          if (s < 2 * T) ((gdouble*)pd.buf)[(size_t)rev_at(pd, s >> 1) * 2 + ch0] = rev_guard(s0[s], fpd);
+          if (s < 2 * T) *ring_ptr(pd, ring_at(pd, s >> 1), ch0) = rev_guard(s0[s], fpd);
         }
       }
     }
@@ -313,10 +356,8 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       if (sub == 8 || nb <= (uint32_t)T) {
         const RevRec rc = rec[lc];
         const double pb = rev_phase_at(rc, nb);
-        const double dd = r.line[lc >> 1].depth * 0.1;
-        anch[tid * 3] = sin(pb);
-        anch[tid * 3 + 1] = cos(pb);
-        anch[tid * 3 + 2] = (nb <= rc.m0 ? rc.du0 : rc.du1) - dd;  // per-frame deviation of the rounded accumulation from the ideal one
+        anch[tid * 2] = sin(pb);
+        anch[tid * 2 + 1] = cos(pb);
         if (sub == 8) gl[lc] = pb;
       }
     }
@@ -324,41 +365,46 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     PG_STAMP(fc.diag, 4);
     // ---- phase 3: allpasses + vibrato lines, sub-chunks of nt/2 frames ----
     for (int base = 0; base < T; base += nt / 2) {
-      const int n = base + (tid >> 1), ch = tid & 1;
+#pragma clang fp contract(fast)  // the only place mul+add pairs may fuse: measured faster, error ~1e-16 relative (the parity gate is 1e-5 RMS)
+      int lane_frame = tid >> 1;
+      asm volatile("" : "+v"(lane_frame));  // keeps per-lane ring addresses from being hoisted out of the loop into 36 long-lived VGPRs
+      int ch = tid & 1;
+      asm volatile("" : "+v"(ch));
+      const int n = base + lane_frame;
       const bool active = n < T;
       double sv[8];   // values the eight lines are `set` to (allpass tap + feedback), reverb.rs:275-282,588-594
       double apw[4];  // values written into the four allpass rings
       double o_prev = 0.0;
+      PG_LAP_DECL(lap_t);
       if (active) {
         // Order matters for latency: first everything that only needs the (known) vibrato phases — the 16 line taps of
         // the previous frame's `get` — and the 4 allpass taps go out to HBM; the f64 sin of the front end and the allpass
         // chain then run underneath those loads.
         double tv1[8], tv2[8], tfr[8];
         if (n >= 1) {
-          // sin(phase_n) = sin(pb + j*d + eps): pb = anchor phase, j*d = tabulated rotation, eps = j*(du - d) the (tiny) deviation
-          // of the reference's rounded accumulation from the ideal progression; first-order term kept.
+          // sin(phase_n) ~= sin(pb + j*d): pb = the sub-chunk's exact anchor phase, j*d = tabulated rotation. The reference's
+          // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 128 * 2^-52 * |p|
+          // (< 6e-14 in the tap position), far below the 1-ulp spread between libm implementations of sin itself.
           const int jb = n - (base > 0 ? base : 1);
-          const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 3;
+          const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 2;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // ReverbDelayLine::get, address part (reverb.rs:563-576); count = position of frame n
-            const RevDesc ld = desc[i];
-            const double* an = anb + (i * 2 + ch) * 3;
+            const RevRing ld = D[i];
+            const double* an = anb + (i * 2 + ch) * 2;
             const double ct = vtab[(i * 129 + jb) * 2], stn = vtab[(i * 129 + jb) * 2 + 1];
-            const double sn = (an[0] * ct + an[1] * stn) + ((double)jb * an[2]) * (an[1] * ct - an[0] * stn);
-            const double working = (double)rev_at(ld, n) + (sn + 1.0) * 7.0;
+            const double sn = fma(an[0], ct, an[1] * stn);
+            const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;
             const double w_floor = floor(working);
             tfr[i] = working - w_floor;
-            uint32_t read_1 = (uint32_t)w_floor;
-            uint32_t read_2 = read_1 + 1;
-            if (read_1 > ld.delay) read_1 -= ld.delay + 1;
-            if (read_2 > ld.delay) read_2 -= ld.delay + 1;
-            tv1[i] = ((const gdouble*)ld.buf)[(size_t)read_1 * 2 + ch];
-            tv2[i] = ((const gdouble*)ld.buf)[(size_t)read_2 * 2 + ch];
+            const uint32_t w_int = (uint32_t)w_floor;                 // < count + 15 <= delay + 15 < 2 * (delay + 1)
+            tv1[i] = *ring_ptr(ld, ring_wrap(w_int, ld.m), ch);       // `if read > delay { read -= delay + 1 }`
+            tv2[i] = *ring_ptr(ld, ring_wrap(w_int + 1, ld.m), ch);
           }
         }
+        PG_LAP(fc.diag, 50, lap_t);
         double dl[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const RevDesc a = desc[8 + i]; dl[i] = ((const gdouble*)a.buf)[(size_t)rev_at(a, n + 1) * 2 + ch]; }  // `delayed`
+        for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
         double v = sin(bufA[REV_IDX(n, ch)] * wet);
@@ -369,6 +415,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
           v = b * 0.5 + dl[i];   // == buf*0.5 + new_delayed (delay >= 1)
           apo[i] = v;
         }
+        PG_LAP(fc.diag, 51, lap_t);
         double F[8];
         if (n >= 1) {
           double g[8];
@@ -390,14 +437,17 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
         sv[0] = apo[3] + F[0]; sv[1] = apo[2] + F[1]; sv[2] = apo[1] + F[2]; sv[3] = apo[0] + F[3];
         sv[4] = apo[0] + F[4]; sv[5] = apo[1] + F[5]; sv[6] = apo[2] + F[6]; sv[7] = apo[3] + F[7];
       }
+      PG_LAP(fc.diag, 52, lap_t);
       __syncthreads();  // every read of this sub-chunk has been issued and consumed
+      PG_LAP(fc.diag, 53, lap_t);
       if (active) {
         if (n >= 1) bufA[REV_IDX(n - 1, ch)] = o_prev;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const RevDesc a = desc[8 + i]; ((gdouble*)a.buf)[(size_t)rev_at(a, n) * 2 + ch] = apw[i]; }
+        for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[i]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const RevDesc ld = desc[i]; ((gdouble*)ld.buf)[(size_t)rev_at(ld, n) * 2 + ch] = sv[i]; }
+        for (int i = 0; i < 8; ++i) { const RevRing ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[i]; }
       }
+      PG_LAP(fc.diag, 54, lap_t);
       // no barrier here: the next sub-chunk only reads ring positions that are written by its own or later items, and LDS
       // slots >= its first frame, so its reads cannot collide with these writes
     }
@@ -408,7 +458,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const int i = tid >> 1, ch = tid & 1;
       const RevDesc ld = desc[i];
       const double ph = gl[tid];  // exact phase after the chunk's last step (anchor slot 8)
-      const double sn = anch[(8 * 16 + tid) * 3];
+      const double sn = anch[(8 * 16 + tid) * 2];
       r.line[i].vib_phase[ch] = ph;
       gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sn, blend);
     }
@@ -444,5 +494,8 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     PG_STAMP(fc.diag, 7);
     done += T;
   }
+#ifdef PG_DIAG
+  if (fc.diag && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; ++i) fc.diag[50 + i] += lapacc[i];
+#endif
   return true;
 }

@@ -25,3 +25,6 @@ prev=t[0]
 for k in [0,16,17,18,19,1,8,9,10,11,12,2,3,4,5,6,7,14,15]:
     print(f"{names[k]:28s} +{(t[k]-prev):8d} cyc  (t={t[k]-t[0]})")
     prev=t[k]
+
+laps=[buf[50+i] for i in range(5)]
+print('phase-3 laps of wave 0, summed over 20 blocks (cycles/block):', {n: laps[i]//20 for i,n in enumerate(['line taps issued','ap loads+sin+chain','interp+householder','barrier wait','stores'])})
