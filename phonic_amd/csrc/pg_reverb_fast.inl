@@ -387,12 +387,19 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
           // (< 6e-14 in the tap position), far below the 1-ulp spread between libm implementations of sin itself.
           const int jb = n - (base > 0 ? base : 1);
           const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 2;
+          // The rotation operands of line i + 1 are fetched from LDS before line i is evaluated (two register sets): one
+          // exposed LDS round trip per sub-chunk instead of one per line.
+          double q_ct[2], q_st[2], q_a0[2], q_a1[2];
+          q_ct[0] = vtab[jb * 2]; q_st[0] = vtab[jb * 2 + 1]; q_a0[0] = anb[ch * 2]; q_a1[0] = anb[ch * 2 + 1];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // ReverbDelayLine::get, address part (reverb.rs:563-576); count = position of frame n
             const RevRing ld = D[i];
-            const double* an = anb + (i * 2 + ch) * 2;
-            const double ct = vtab[(i * 129 + jb) * 2], stn = vtab[(i * 129 + jb) * 2 + 1];
-            const double sn = fma(an[0], ct, an[1] * stn);
+            if (i + 1 < 8) {
+              const double* an = anb + ((i + 1) * 2 + ch) * 2;
+              q_ct[(i + 1) & 1] = vtab[((i + 1) * 129 + jb) * 2]; q_st[(i + 1) & 1] = vtab[((i + 1) * 129 + jb) * 2 + 1];
+              q_a0[(i + 1) & 1] = an[0]; q_a1[(i + 1) & 1] = an[1];
+            }
+            const double sn = fma(q_a0[i & 1], q_ct[i & 1], q_a1[i & 1] * q_st[i & 1]);
             const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;
             const double w_floor = floor(working);
             tfr[i] = working - w_floor;
