@@ -101,6 +101,10 @@ DEVO uint32_t ring_at(const RevRing& R, uint32_t i) {   // == rev_at(desc, i) fo
   if (R.stale) { if (i == 0) v = R.p0; }  // uniform (scalar) branch, practically never taken
   return v;
 }
+DEVO void ring_advance(RevRing& R, uint32_t T) {  // T in [1, m]
+  const uint32_t np = ring_wrap(R.pe + T, R.m);
+  R.p0 = np; R.pe = np; R.stale = 0;
+}
 // element address of (ring position, channel) in the [pos][2] f64 ring
 DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) { return (gdouble*)R.buf + ((pos << 1) | (uint32_t)ch); }
 
@@ -223,39 +227,61 @@ DEVO bool reverb_fast_eligible(const PgFx& fx) {
   return d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17;
 }
 
-DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+// ---- the three stages of the time-parallel reverb ------------------------------------------------------------------------
+// front : predelay ring (chunks <= predelay) + biquad A over the whole piece            -> bufA
+// mid   : allpasses + vibrato lines in chunks (phase records, anchors, sub-chunks)      bufA -> bufA (o of every frame)
+// tail  : biquad B -> clamp/asin -> biquad C -> dry mix                                 bufA -> signal
+// The front does not depend on the mid stage of the same piece and the tail only on the mid stage's output, so the fused
+// kernel runs them back to back on one LDS buffer and the staged pipeline (pg_stage*_kernel) runs each at its own occupancy,
+// handing bufA over through HBM.
+constexpr int REV_T_CAP = 1024;  // frames per piece (capacity of bufA)
+
+struct RevLds {   // LDS carve-up of the reverb arena
+  double* bufA;   // [REV_T_CAP][2] f64, skewed (REV_IDX)
+  RevRec* rec;    // [16]
+  double* gl;     // [16] epilogue gets / uniform scalars
+  RevDesc* desc;  // [13]
+  double* xchg;   // biquad scan hand-over
+  double* anch;   // [9][16] {sin, cos} anchors: 8 sub-chunks + the epilogue
+  double* vtab;   // vibrato rotation table (LDS copy)
+  char* slack;    // 64 bytes
+};
+DEVO RevLds rev_lds(char* scratch) {
+  RevLds m;
+  m.bufA = (double*)scratch;
+  char* lp = scratch + REV_BUF_DOUBLES * 8;
+  m.rec = (RevRec*)lp;    lp += 16 * sizeof(RevRec);
+  m.gl = (double*)lp;     lp += 16 * 8;
+  m.desc = (RevDesc*)lp;  lp += 13 * sizeof(RevDesc);
+  m.xchg = (double*)lp;   lp += 4 * 8;
+  m.anch = (double*)lp;   lp += 9 * 16 * 2 * 8;
+  m.vtab = (double*)lp;   lp += 8 * 129 * 2 * 8;
+  m.slack = lp;
+  return m;
+}
+
+struct RevBlock {  // per-block uniform parameters
+  double blend, regen, wet;
+  uint32_t predelay, t_mid;
+};
+
+// vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store (caller syncs)
+DEVO void rev_load_vtab(const PgReverb& r, const RevLds& m) {
+  const int tid = threadIdx.x;
+  const gdouble* tg = (const gdouble*)r.vib_tab;
+  double t0[5], t1[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; const int j = i < 8 * 129 ? i : 0; t0[k] = tg[2 * j]; t1[k] = tg[2 * j + 1]; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; if (i < 8 * 129) { m.vtab[2 * i] = t0[k]; m.vtab[2 * i + 1] = t1[k]; } }
+}
+
+// block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets; cached in the effect
+// state while room size and wet stay put. All lanes call; returns false for a degenerate geometry (serial path).
+DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
   PgReverb& r = fx.u.reverb;
-  if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;  // per-frame delay sizes / coefficients: exact serial path
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int frames = n_samples / 2;
-  if (frames == 0) return true;
-  double* bufA = (double*)fc.scratch;                       // [T_CAP][2] f64, skewed (REV_IDX)
-  char* lp = fc.scratch + REV_BUF_DOUBLES * 8;
-  RevRec* rec = (RevRec*)lp;   lp += 16 * sizeof(RevRec);    // [16]
-  double* gl = (double*)lp;    lp += 16 * 8;                 // [16] epilogue gets
-  RevDesc* desc = (RevDesc*)lp; lp += 13 * sizeof(RevDesc);  // [13]
-  double* xchg = (double*)lp;  lp += 4 * 8;                  // biquad scan hand-over
-  double* anch = (double*)lp;  lp += 9 * 16 * 2 * 8;         // [9][16] {sin, cos} anchors: 8 sub-chunks + the epilogue
-  double* vtab = (double*)lp;  lp += 8 * 129 * 2 * 8;        // vibrato rotation table (LDS copy)
-  int* ctl = fc.ctl;
-  constexpr int T_CAP = 1024;
-#ifdef PG_DIAG
-  unsigned long long* lapacc = (unsigned long long*)lp;  // 8 lap accumulators in the scratch slack
-  if (tid == 0) for (int i = 0; i < 8; ++i) lapacc[i] = 0;
-#endif
-
-  // vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store
-  {
-    const gdouble* tg = (const gdouble*)r.vib_tab;
-    double t0[5], t1[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; const int j = i < 8 * 129 ? i : 0; t0[k] = tg[2 * j]; t1[k] = tg[2 * j + 1]; }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; if (i < 8 * 129) { vtab[2 * i] = t0[k]; vtab[2 * i + 1] = t1[k]; } }
-  }
-  // ---- block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets ----
+  const int tid = threadIdx.x;
   __syncthreads();
-
   if (tid == 0) {
     if (!(r.cache_valid && r.cache_room == r.room.target && r.cache_wet == r.wet.target)) {
       ReverbBlock rb;
@@ -263,26 +289,75 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       r.c_blend = rb.blend; r.c_regen = rb.regen; r.c_predelay = rb.predelay;
       r.cache_room = r.room.target; r.cache_wet = r.wet.target; r.cache_valid = 1;
     }
-    ((double*)gl)[0] = r.c_blend; ((double*)gl)[1] = r.c_regen; ((double*)gl)[2] = (double)r.wet.target;
+    m.gl[0] = r.c_blend; m.gl[1] = r.c_regen; m.gl[2] = (double)r.wet.target;
     ctl[4] = (int)r.c_predelay;
   }
   __syncthreads();
-  PG_STAMP(fc.diag, 10);
-  const double blend = uni_f64(gl[0]), regen = uni_f64(gl[1]), wet = uni_f64(gl[2]);
-  const uint32_t predelay = uni_u32((uint32_t)ctl[4]);
+  b.blend = uni_f64(m.gl[0]); b.regen = uni_f64(m.gl[1]); b.wet = uni_f64(m.gl[2]);
+  b.predelay = uni_u32((uint32_t)ctl[4]);
   __syncthreads();
-  // chunk length bound: all reads must hit pre-chunk data
-  uint32_t t_max = predelay;
-  for (int i = 0; i < 4; ++i) t_max = t_max < r.ap[i].delay ? t_max : r.ap[i].delay;
-  for (int i = 0; i < 8; ++i) { uint32_t d = r.line[i].delay > 17 ? r.line[i].delay - 17 : 0; t_max = t_max < d ? t_max : d; }
-  if (t_max < 32) return false;  // degenerate geometry: serial path
-  if (t_max > (uint32_t)T_CAP) t_max = T_CAP;
-  t_max = uni_u32(t_max);
+  // chunk length bound of the mid stage: all its reads must hit pre-chunk data
+  uint32_t t_mid = 0xffffffffu;
+  for (int i = 0; i < 4; ++i) t_mid = t_mid < r.ap[i].delay ? t_mid : r.ap[i].delay;
+  for (int i = 0; i < 8; ++i) { uint32_t d = r.line[i].delay > 17 ? r.line[i].delay - 17 : 0; t_mid = t_mid < d ? t_mid : d; }
+  if (t_mid > (uint32_t)REV_T_CAP) t_mid = REV_T_CAP;
+  b.t_mid = uni_u32(t_mid);
+  return b.t_mid >= 32 && b.predelay >= 32;
+}
 
-  PG_STAMP(fc.diag, 11);
+// ---- front: predelay (DelayLine<2>::process, delay.rs:47-66) in chunks of <= predelay frames, then biquad A ----
+DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* bufA = m.bufA;
+  const int ch0 = tid & 1;  // nt is even: a lane keeps its channel across trips
+  const uint32_t fpd = ch0 ? r.fpd_r : r.fpd_l;
+  RevRing pd = rev_ring_uniform(RevDesc{r.pre, r.pre_write_pos & r.pre_mask, b.predelay});
+  __syncthreads();  // every lane holds the ring position before lane 0 may advance it
+  for (int c0 = 0; c0 < T; c0 += (int)b.predelay) {
+    const int Tc = T - c0 < (int)b.predelay ? T - c0 : (int)b.predelay;
+    for (int s_base = 0; s_base < 2 * Tc; s_base += 8 * nt) {  // 8 samples per lane and trip: all loads in flight together
+      double pv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s_base + k * nt + tid;
+        pv[k] = s < 2 * Tc ? *ring_ptr(pd, ring_at(pd, (s >> 1) + 1), ch0) : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s_base + k * nt + tid;
+        if (s < 2 * Tc) bufA[REV_IDX(c0 + (s >> 1), ch0)] = pv[k];
+      }
+    }
+    __syncthreads();
+    for (int s_base = 0; s_base < 2 * Tc; s_base += 8 * nt) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s_base + k * nt + tid;
+        if (s < 2 * Tc) *ring_ptr(pd, ring_at(pd, s >> 1), ch0) = rev_guard(s0[2 * c0 + s], fpd);
+      }
+    }
+    ring_advance(pd, (uint32_t)Tc);
+    if (c0 + Tc < T) { __threadfence_block(); __syncthreads(); }  // the next chunk reads what this one wrote
+  }
+  if (tid == 0) r.pre_write_pos = pd.p0;
+  PG_STAMP(diag, 3);
+  rev_biquad_scan(r.ca, r.sa, bufA, T, m.xchg);
+  __syncthreads();
+}
+
+// ---- mid: allpasses + vibrato lines ----
+DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  RevRec* rec = m.rec; double* gl = m.gl; RevDesc* desc = m.desc; double* anch = m.anch; double* vtab = m.vtab;
+  const double blend = b.blend, regen = b.regen, wet = b.wet;
+#ifdef PG_DIAG
+  unsigned long long* lapacc = (unsigned long long*)m.slack;  // 8 lap accumulators in the scratch slack
+  if (tid == 0) for (int i = 0; i < 8; ++i) lapacc[i] = 0;
+#endif
   int done = 0;
   while (done < frames) {
-    // ---- chunk set-up: vibrato phase records + chunk length (16 lanes) ----
+    double* bufA = m.bufA + 0;  // chunk frames are addressed as done + n below
+    // ---- chunk set-up: vibrato phase records + chunk length (16 lanes), ring descriptors (13 lanes) ----
     if (tid < 16) {
       const PgReverbLine& l = r.line[tid >> 1];
       const double d = l.depth * 0.1;
@@ -293,59 +368,21 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       rc.m1 = rev_phase_piece(rc.p1, d, rc.du1);
       rec[tid] = rc;
       ctl[8 + tid] = (int)(rc.m0 + 1u + rc.m1);
-    }
+    } else if (tid >= 64 && tid < 64 + 8) desc[tid - 64] = RevDesc{r.line[tid - 64].buf, r.line[tid - 64].count, r.line[tid - 64].delay};
+    else if (tid >= 64 + 8 && tid < 64 + 12) desc[tid - 64] = RevDesc{r.ap[tid - 72].buf, r.ap[tid - 72].write_pos, r.ap[tid - 72].delay};
     __syncthreads();
-    PG_STAMP(fc.diag, 12);
-    PG_STAMP_VAL(fc.diag, 20 + (done > 0 ? 1 : 0), done);
-    PG_STAMP_VAL(fc.diag, 22, t_max);
-    for (int i = 0; i < 16; ++i) PG_STAMP_VAL(fc.diag, 24 + i, ctl[8 + i]);
+    PG_STAMP(diag, 12);
+    PG_STAMP_VAL(diag, 20 + (done > 0 ? 1 : 0), done);
+    PG_STAMP_VAL(diag, 22, b.t_mid);
+    for (int i = 0; i < 16; ++i) PG_STAMP_VAL(diag, 24 + i, ctl[8 + i]);
     int T = frames - done;
-    if ((uint32_t)T > t_max) T = (int)t_max;
+    if ((uint32_t)T > b.t_mid) T = (int)b.t_mid;
     for (int i = 0; i < 16; ++i) T = T < ctl[8 + i] ? T : ctl[8 + i];
     T = (int)uni_u32((uint32_t)T);
-    float* s0 = sig + 2 * done;
-
-    PG_STAMP(fc.diag, 2);
-    // ---- ring descriptors of the 13 delay lines for this chunk -> LDS (uniform data stays out of the VGPR budget) ----
-    if (tid < 8) desc[tid] = RevDesc{r.line[tid].buf, r.line[tid].count, r.line[tid].delay};
-    else if (tid < 12) desc[tid] = RevDesc{r.ap[tid - 8].buf, r.ap[tid - 8].write_pos, r.ap[tid - 8].delay};
-    else if (tid == 12) desc[12] = RevDesc{r.pre, r.pre_write_pos & r.pre_mask, predelay};
-    __syncthreads();
-    RevRing D[13];  // the same descriptors as scalars (all uses below index them with compile-time constants)
+    PG_STAMP(diag, 2);
+    RevRing D[12];  // the ring descriptors as scalars (all uses below index them with compile-time constants)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) D[i] = rev_ring_uniform(desc[i]);
-
-    // ---- phase 1: predelay (DelayLine<2>::process, delay.rs:47-66) ----
-    {
-      const int ch0 = tid & 1;  // nt is even: a lane keeps its channel across trips
-      const RevRing pd = D[12];
-      const uint32_t fpd = ch0 ? r.fpd_r : r.fpd_l;
-      for (int s_base = 0; s_base < 2 * T; s_base += 8 * nt) {  // 8 samples per lane and trip: all loads in flight together
-        double pv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int s = s_base + k * nt + tid;
-          pv[k] = s < 2 * T ? *ring_ptr(pd, ring_at(pd, (s >> 1) + 1), ch0) : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int s = s_base + k * nt + tid;
-          if (s < 2 * T) bufA[REV_IDX(s >> 1, ch0)] = pv[k];
-        }
-      }
-      __syncthreads();
-      for (int s_base = 0; s_base < 2 * T; s_base += 8 * nt) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int s = s_base + k * nt + tid;
-          if (s < 2 * T) *ring_ptr(pd, ring_at(pd, s >> 1), ch0) = rev_guard(s0[s], fpd);
-        }
-      }
-    }
-    PG_STAMP(fc.diag, 3);
-    // ---- phase A: biquad A ----
-    rev_biquad_scan(r.ca, r.sa, bufA, T, xchg);
-    __syncthreads();
+    for (int i = 0; i < 12; ++i) D[i] = rev_ring_uniform(desc[i]);
 
     // ---- vibrato anchors for the whole chunk, one lane per (sub-chunk, line, channel): sin/cos (accurate libm) of the exact
     // phase of the sub-chunk's first item; inside the sub-chunk sin(phase_n) follows by the angle-addition rotation with
@@ -362,8 +399,8 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       }
     }
     __syncthreads();
-    PG_STAMP(fc.diag, 4);
-    // ---- phase 3: allpasses + vibrato lines, sub-chunks of nt/2 frames ----
+    PG_STAMP(diag, 4);
+    // ---- sub-chunks of nt/2 frames ----
     for (int base = 0; base < T; base += nt / 2) {
 #pragma clang fp contract(fast)  // the only place mul+add pairs may fuse: measured faster, error ~1e-16 relative (the parity gate is 1e-5 RMS)
       int lane_frame = tid >> 1;
@@ -408,21 +445,21 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
             tv2[i] = *ring_ptr(ld, ring_wrap(w_int + 1, ld.m), ch);
           }
         }
-        PG_LAP(fc.diag, 50, lap_t);
+        PG_LAP(diag, 50, lap_t);
         double dl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
-        double v = sin(bufA[REV_IDX(n, ch)] * wet);
+        double v = sin(bufA[REV_IDX(done + n, ch)] * wet);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const double b = v - (dl[i] * 0.5);
-          apw[i] = b;
-          v = b * 0.5 + dl[i];   // == buf*0.5 + new_delayed (delay >= 1)
+          const double bb = v - (dl[i] * 0.5);
+          apw[i] = bb;
+          v = bb * 0.5 + dl[i];   // == buf*0.5 + new_delayed (delay >= 1)
           apo[i] = v;
         }
-        PG_LAP(fc.diag, 51, lap_t);
+        PG_LAP(diag, 51, lap_t);
         double F[8];
         if (n >= 1) {
           double g[8];
@@ -444,22 +481,22 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
         sv[0] = apo[3] + F[0]; sv[1] = apo[2] + F[1]; sv[2] = apo[1] + F[2]; sv[3] = apo[0] + F[3];
         sv[4] = apo[0] + F[4]; sv[5] = apo[1] + F[5]; sv[6] = apo[2] + F[6]; sv[7] = apo[3] + F[7];
       }
-      PG_LAP(fc.diag, 52, lap_t);
+      PG_LAP(diag, 52, lap_t);
       __syncthreads();  // every read of this sub-chunk has been issued and consumed
-      PG_LAP(fc.diag, 53, lap_t);
+      PG_LAP(diag, 53, lap_t);
       if (active) {
-        if (n >= 1) bufA[REV_IDX(n - 1, ch)] = o_prev;
+        if (n >= 1) bufA[REV_IDX(done + n - 1, ch)] = o_prev;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[i]; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const RevRing ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[i]; }
       }
-      PG_LAP(fc.diag, 54, lap_t);
+      PG_LAP(diag, 54, lap_t);
       // no barrier here: the next sub-chunk only reads ring positions that are written by its own or later items, and LDS
       // slots >= its first frame, so its reads cannot collide with these writes
     }
     __syncthreads();
-    PG_STAMP(fc.diag, 5);
+    PG_STAMP(diag, 5);
     // ---- epilogue: gets after the step of the chunk's last frame (16 lanes: one (line, channel) each) ----
     if (tid < 16) {
       const int i = tid >> 1, ch = tid & 1;
@@ -478,31 +515,55 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       r.line[2].feedback[ch] = (g[2] - (g[0] + g[1] + g[3])) * regen; r.line[3].feedback[ch] = (g[3] - (g[0] + g[1] + g[2])) * regen;
       r.line[4].feedback[ch] = (g[4] - (g[5] + g[6] + g[7])) * regen; r.line[5].feedback[ch] = (g[5] - (g[4] + g[6] + g[7])) * regen;
       r.line[6].feedback[ch] = (g[6] - (g[4] + g[5] + g[7])) * regen; r.line[7].feedback[ch] = (g[7] - (g[4] + g[5] + g[6])) * regen;
-      bufA[REV_IDX(T - 1, ch)] = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;
+      bufA[REV_IDX(done + T - 1, ch)] = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;
     }
-    if (tid < 8) r.line[tid].count = rev_at(desc[tid], T);  // advance ring positions (uniform integer bookkeeping)
-    else if (tid < 12) r.ap[tid - 8].write_pos = rev_at(desc[tid], T);
-    else if (tid == 12) r.pre_write_pos = rev_at(desc[12], T);
+    if (tid >= 64 && tid < 64 + 8) r.line[tid - 64].count = rev_at(desc[tid - 64], T);  // advance ring positions (uniform integer bookkeeping)
+    else if (tid >= 64 + 8 && tid < 64 + 12) r.ap[tid - 72].write_pos = rev_at(desc[tid - 64], T);
     __syncthreads();
-    PG_STAMP(fc.diag, 6);
-    // ---- biquad B -> clamp -> asin -> biquad C -> dry mix (reverb.rs:340-368) ----
-    rev_biquad_scan(r.cb, r.sb, bufA, T, xchg);
-    __syncthreads();
-    for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = asin(clampd(bufA[bi], -1.0, 1.0)); }
-    __syncthreads();
-    rev_biquad_scan(r.cc, r.sc, bufA, T, xchg);
-    __syncthreads();
-    for (int s = tid; s < 2 * T; s += nt) {
-      double y = bufA[REV_IDX(s >> 1, s & 1)];
-      if (wet != 1.0) y += rev_guard(s0[s], (s & 1) ? r.fpd_r : r.fpd_l) * (1.0 - wet);
-      s0[s] = (float)y;
-    }
-    __syncthreads();
-    PG_STAMP(fc.diag, 7);
+    PG_STAMP(diag, 6);
     done += T;
   }
 #ifdef PG_DIAG
-  if (fc.diag && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; ++i) fc.diag[50 + i] += lapacc[i];
+  if (diag && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; ++i) diag[50 + i] += lapacc[i];
 #endif
+}
+
+// ---- tail: biquad B -> clamp -> asin -> biquad C -> dry mix (reverb.rs:340-368) ----
+DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* bufA = m.bufA;
+  const double wet = b.wet;
+  rev_biquad_scan(r.cb, r.sb, bufA, T, m.xchg);
+  __syncthreads();
+  for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = asin(clampd(bufA[bi], -1.0, 1.0)); }
+  __syncthreads();
+  rev_biquad_scan(r.cc, r.sc, bufA, T, m.xchg);
+  __syncthreads();
+  for (int s = tid; s < 2 * T; s += nt) {
+    double y = bufA[REV_IDX(s >> 1, s & 1)];
+    if (wet != 1.0) y += rev_guard(s0[s], (s & 1) ? r.fpd_r : r.fpd_l) * (1.0 - wet);
+    s0[s] = (float)y;
+  }
+  __syncthreads();
+  PG_STAMP(diag, 7);
+}
+
+DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  PgReverb& r = fx.u.reverb;
+  if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;  // per-frame delay sizes / coefficients: exact serial path
+  const int frames = n_samples / 2;
+  if (frames == 0) return true;
+  const RevLds m = rev_lds(fc.scratch);
+  rev_load_vtab(r, m);
+  RevBlock b;
+  if (!rev_block_params(fx, m, fc.ctl, b)) return false;  // degenerate geometry: serial path
+  PG_STAMP(fc.diag, 11);
+  for (int done = 0; done < frames; done += REV_T_CAP) {
+    const int T = frames - done < REV_T_CAP ? frames - done : REV_T_CAP;
+    float* s0 = sig + 2 * done;
+    rev_front(r, s0, T, m, b, fc.diag);
+    rev_mid(r, T, m, b, fc.ctl, fc.diag);
+    rev_tail(r, s0, T, m, b, fc.diag);
+  }
   return true;
 }
