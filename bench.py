@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
+    ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +141,7 @@ def main():
     g = Graph(48000, 2, block, local_rank)
     if args.exact:
         g.set_fast_math(0)
+    g.set_staged(args.staged)
     bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
     if world > 1 and bus_on_root:
         g.set_defer_bus(True)

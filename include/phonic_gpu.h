@@ -207,6 +207,10 @@ int pg_graph_is_voice_playing(pg_graph* g, int voice_id);
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
 /* 0 = exact serial filters, 1 = time-parallel (blocked) evaluation of linear filters (default) */
 int pg_graph_set_fast_math(pg_graph* g, int level);
+/* How sub-mixers whose chain is [Gain|Panning]* -> Reverb are rendered: 1 (default) = staged kernel (three separately
+ * register-allocated stage functions in one launch, four workgroups per CU), 2 = one launch per stage (profiling), 0 = the
+ * fused fast kernel. Same stage functions in every mode: results agree up to f64 rounding. */
+int pg_graph_set_staged(pg_graph* g, int mode);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,7 @@ struct PgVoice {
   float speed_glide_rate;
   uint32_t samples_to_next_speed_update;
   int32_t sched_class, sched_rep;  // resampler schedule cache: class of voices sharing a ratio; 1 = this voice publishes the schedule
+  int32_t sched_hit, pad_sched;    // device: how the last resampling piece got its schedule: 0 serial replay, 1 schedule cache, 2 time-parallel
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.
@@ -216,8 +217,11 @@ struct PgUnit {
                                 // kernel once every effect of the unit is back in steady state)
   int32_t voice0;               // host: device index of the unit's first voice (skips one dependent load at kernel start)
   int32_t fx0;                  // host: device index of the unit's first effect (prefetched during the source stage)
-  int32_t pad3;
+  int32_t staged;               // host: the chain is [Gain|Panning]* -> Reverb: eligible for the staged pipeline (pg_stage*_kernel)
+  int32_t stage_flags;          // device: hand-over between the stage kernels of one block (PG_STAGE_*)
+  int32_t pad4;
 };
+enum { PG_STAGE_ACTIVE = 1, PG_STAGE_INPUT_BYPASSED = 2, PG_STAGE_ALL_BYPASSED = 4, PG_STAGE_AUDIBLE = 8, PG_STAGE_SKIPPED = 16 };
 
 enum PgCmdType {
   CMD_FX_PARAM = 0,     // target = fx index, param = parameter index, value = raw (already denormalized/clamped) value
@@ -259,4 +263,10 @@ struct PgLaunch {
   PgSchedEntry* sched;    // [n_classes][2 banks]; nullptr disables the schedule cache
   int32_t sched_bank;     // bank read by this launch; the representatives write bank ^ 1
   unsigned long long* diag;  // diagnostic builds (-DPG_DIAG): shader-clock stamps of workgroup 0, else unused
+  double* stage_buf;      // [n_units][PG_STAGE_BUF_DOUBLES] f64 hand-over buffer of the staged pipeline (nullptr: pipeline off)
+  int32_t* defer_count;   // fast kernels append the launch slots they defer: count of this round ...
+  int32_t* defer_list;    // ... and the slots; the generic kernel (mode 2) walks the list
+  int32_t* defer_reset;   // the other round's counter, zeroed by the generic kernel for the next round
+  int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
 };
+constexpr int PG_STAGE_BUF_DOUBLES = 2 * 1024 + 128 + 8;

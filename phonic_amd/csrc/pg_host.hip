@@ -26,6 +26,7 @@ using namespace pgh;
 
 size_t pg_unit_lds_bytes(uint32_t n_frames);
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream);
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
                          const int32_t* order, int* audible_out, hipStream_t stream);
 
@@ -406,6 +407,12 @@ struct pg_graph {
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
+  int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
+  int n_staged = 0;        // graph units eligible for the staged pipeline
+  double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
+  int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
+  size_t defer_rows = 0;
+  size_t stage_rows = 0;
   bool defer_bus = false;
   // host mirrors
   std::vector<HostMixer> mixers;        // [0] = main
@@ -455,6 +462,7 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].static_defer = topo[i].static_defer;
   units[i].voice0 = topo[i].voice0;
   units[i].fx0 = topo[i].fx0;
+  units[i].staged = topo[i].staged;
   units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
 __global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
@@ -494,6 +502,12 @@ static int rebuild_topology(pg_graph* g) {
       if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_REVERB || k == PG_FX_DISTORTION)) u.static_defer = 1;
       if (k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) u.static_defer = 1;  // DC filter: serial recurrence
     }
+    // staged pipeline: a sub-mixer whose chain is [Gain (no DC filter) | Panning]* -> Reverb
+    u.staged = 0;
+    if (m != 0 && !u.static_defer && !mx.fx.empty() && g->fx[mx.fx.back()]->kind == PG_FX_REVERB) {
+      u.staged = 1;
+      for (size_t i = 0; i + 1 < mx.fx.size(); ++i) { const int k = g->fx[mx.fx[i]]->kind; if (!(k == PG_FX_GAIN || k == PG_FX_PANNING)) u.staged = 0; }
+    }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
@@ -511,6 +525,8 @@ static int rebuild_topology(pg_graph* g) {
     g->order.push_back(slot);
   }
   g->n_graph_units = (int)g->order.size();
+  g->n_staged = 0;
+  for (int slot : g->order) g->n_staged += topo[slot].staged ? 1 : 0;
   g->h_units = topo;
   int rc;
   if ((rc = g->d_voice_index.upload(vidx))) return rc;
@@ -530,6 +546,18 @@ static int rebuild_topology(pg_graph* g) {
     size_t nr = std::max(rows, g->unit_out_rows * 2);
     HIP_TRY(hipMalloc((void**)&g->d_unit_out, nr * g->stride * sizeof(float)));
     g->unit_out_rows = nr;
+  }
+  if (rows > g->defer_rows) {
+    if (g->d_defer) (void)hipFree(g->d_defer);
+    HIP_TRY(hipMalloc((void**)&g->d_defer, (2 + rows) * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(g->d_defer, 0, (2 + rows) * sizeof(int32_t), g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->defer_rows = rows;
+  }
+  if (g->n_staged > 0 && rows > g->stage_rows) {
+    if (g->d_stage) (void)hipFree(g->d_stage);
+    HIP_TRY(hipMalloc((void**)&g->d_stage, rows * (size_t)PG_STAGE_BUF_DOUBLES * sizeof(double)));
+    g->stage_rows = rows;
   }
   size_t prow = (rows + 15) / 16;
   if (prow > g->partial_rows) {
@@ -596,6 +624,8 @@ void pg_graph_destroy(pg_graph* g) {
   g->d_cmds.release(); g->d_sched.release();
   if (g->d_unit_out) (void)hipFree(g->d_unit_out);
   if (g->d_partial) (void)hipFree(g->d_partial);
+  if (g->d_stage) (void)hipFree(g->d_stage);
+  if (g->d_defer) (void)hipFree(g->d_defer);
   if (g->d_bus) (void)hipFree(g->d_bus);
   if (g->d_audible) (void)hipFree(g->d_audible);
   if (g->h_pinned) (void)hipHostFree(g->h_pinned);
@@ -799,6 +829,7 @@ int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic 
 }
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
 int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; return PG_OK; }
+int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
 int pg_graph_synchronize(pg_graph* g) {
   (void)hipSetDevice(g->device);
@@ -843,6 +874,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.unit_out = g->d_unit_out; L.out_stride = g->stride;
   L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
   L.diag = g->d_diag;
+  if (g->d_defer) { L.defer_count = g->d_defer + (g->launch_counter & 1); L.defer_reset = g->d_defer + ((g->launch_counter & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;
   bool timed = g->ev_used < 8192 && L.n_units > 0;
@@ -855,12 +887,18 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   if (timed) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
   if (g->fast) {
     L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
-    HIP_TRY(pg_launch_units(L, stream));
+    const bool staged = g->staged_mode && g->n_staged > 0 && g->d_stage && n <= 1024;
+    if (staged) {  // [Gain|Panning]* -> Reverb units: three stage launches, each at its own occupancy
+      L.stage_buf = g->d_stage; L.staged_on = 1;
+      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0));
+    }
+    if (!staged || g->n_staged < g->n_graph_units) HIP_TRY(pg_launch_units(L, stream));
     if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
     L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit
     HIP_TRY(pg_launch_units(L, stream));
   } else {
     L.mode = 0;
+    if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
     HIP_TRY(pg_launch_units(L, stream));
     if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
   }

@@ -224,9 +224,8 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
 
 // ---- EffectProcessor::process  src/source/mixed/effect.rs:56-145 -------------------------------------
 // ctl: LDS words for uniform decisions. Returns true when the effect processed output.
-template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
-                                     float* red) {
+// pre-part: bypass decision (:88-101). Returns true when the effect is bypassed for this block. All lanes call.
+__device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, int* ctl) {
   __syncthreads();
   if (threadIdx.x == 0) {
     bool should_bypass = input_bypassed && fx.tail_counter == 0 && fx.silence_counter == PG_USIZE_MAX;  // :88-91
@@ -235,9 +234,10 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
     ctl[0] = fx.bypassed;
   }
   __syncthreads();
-  if (ctl[0]) return false;
-  PG_STAMP(fc.diag, 9);
-  fx_process_wg<FAST_ONLY, KMASK>(fx, sig, n, fc, fast);
+  return ctl[0] != 0;
+}
+// post-part: update_tail_counters / reset_tail_counters (:111-152) after the effect rendered `n` samples into `sig`
+__device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, int n, bool input_bypassed, uint32_t sample_rate, int* ctl, float* red) {
   if (input_bypassed) {  // update_tail_counters :111-145
     if (threadIdx.x == 0) {
       uint64_t tail_frames;
@@ -264,6 +264,14 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
     fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0;  // reset_tail_counters :148-152
   }
   __syncthreads();
+}
+template <bool FAST_ONLY, int KMASK>
+__device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
+                                     float* red) {
+  if (fx_processor_pre(fx, input_bypassed, ctl)) return false;
+  PG_STAMP(fc.diag, 9);
+  fx_process_wg<FAST_ONLY, KMASK>(fx, sig, n, fc, fast);
+  fx_processor_post(fx, sig, n, input_bypassed, sample_rate, ctl, red);
   return true;
 }
 
@@ -272,9 +280,9 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
 extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 
 template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
-  if ((int)blockIdx.x >= L.n_units) return;
-  const int u = L.unit_order ? L.unit_order[blockIdx.x] : L.unit_base + (int)blockIdx.x;
+__device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) {
+  if (slot >= L.n_units) return;
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   PgUnit& unit = L.units[u];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = (int)L.n_frames;
@@ -296,12 +304,14 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
   if (FAST_ONLY) {
+    if (L.staged_on && unit.staged) return;  // rendered by the stage kernels of this round
     if (tid == 0) {
       // Ramps only start with a parameter command, and commands are always rendered (and the ramp state re-evaluated at the
       // end of the block) by the generic kernel: the unit record alone decides, no walk over the effect states.
       int ok = !(unit.static_defer || unit.maybe_ramping);
       for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
       unit.deferred = ok ? 0 : 1;
+      if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
       ctl[5] = ok;
     }
     __syncthreads();
@@ -415,7 +425,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
     for (int i = tid; i < 2 * N; i += nt) ext[i] = sig[i];
     return;
   }
-  float* out = L.unit_out + (size_t)blockIdx.x * L.out_stride;
+  float* out = L.unit_out + (size_t)slot * L.out_stride;
   if (unit.kind == UNIT_SUBMIXER) {
     // SubMixerProcessor::process  src/source/mixed/submixer.rs:47-77. (A sub-mixer without sources, effects or
     // events returns 0 samples: max over an empty slice = 0 -> counts as silent.)
@@ -451,9 +461,287 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L) {
 // keeps the hot loop free of spills; the wide one adds Filter, Eq5 and Distortion. The host picks by the kinds present.
 #define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
 #define PG_KMASK_ALL 0x3ff
-__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true, PG_KMASK_LEAN>(L); }
-__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) { pg_unit_body<true, PG_KMASK_ALL>(L); }
-__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) { pg_unit_body<false, PG_KMASK_ALL>(L); }
+#define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) { pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x); }
+// The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
+// walks its share of the units, so the launch that finds nothing deferred costs 256 workgroup starts instead of n_units.
+__global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
+  if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
+    const int n = *L.defer_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *L.defer_reset = 0;
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+      pg_unit_body<false, PG_KMASK_ALL>(L, L.defer_list[i]);
+      __syncthreads();
+    }
+    return;
+  }
+  for (int slot = (int)blockIdx.x; slot < L.n_units; slot += (int)gridDim.x) {
+    pg_unit_body<false, PG_KMASK_ALL>(L, slot);
+    __syncthreads();
+  }
+}
+
+// ---- staged pipeline for [Gain|Panning]* -> Reverb units -------------------------------------------------------------------
+// The fused fast kernel above is one function at 256 VGPRs / 55 KB LDS: two workgroups per CU, latency-bound. Here the same
+// stage functions of the reverb are separate units of register allocation with an LDS plan of 38 KB, so four workgroups fit a CU:
+//   stage 1: deferral decision, source stage, leading Gain/Panning effects, reverb bypass logic + front (predelay, biquad A)
+//   stage 2: reverb mid (allpasses + vibrato lines)
+//   stage 3: reverb tail (biquad B, asin, biquad C, dry mix), tail counters, sub-mixer silence gate, unit output
+// Two drivers: pg_stage_fused_kernel runs the three stages back to back in one launch (chunk buffer and effect state stay in
+// LDS, the dry signal is parked in the unit's output row during stage 2); pg_stage1/2/3_kernel are one launch per stage with
+// the chunk buffer handed over through HBM/L2 (kept for profiling the stages in isolation).
+// LDS plan (all stages): [PgFx][ctl 128][red 64][arena ...]; the arena starts with bufA in every stage.
+//   stage 1: arena = union(source scratch, bufA .. xchg), then [sig][tmp][PgVoice]      36.6 KB at 1024 frames
+//   stage 2: arena = full reverb arena (bufA, records, anchors, rotation table)          38.6 KB
+//   stage 3: arena = bufA .. xchg, then [sig]                                            27.9 KB
+__device__ __forceinline__ int stage_image_doubles(int T) { return 2 * T + (T >> 3) + 2; }
+__device__ __forceinline__ void stage_store_image(double* g, const double* lds, int T) {
+  const int n2 = (stage_image_doubles(T) + 1) >> 1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) ((double2*)g)[i] = ((const double2*)lds)[i];
+}
+__device__ __forceinline__ void stage_load_image(double* lds, const double* g, int T) {
+  const int n2 = (stage_image_doubles(T) + 1) >> 1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) ((double2*)lds)[i] = ((const double2*)g)[i];
+}
+constexpr size_t STAGE_ARENA_PREFIX = (size_t)REV_BUF_DOUBLES * 8 + 16 * sizeof(RevRec) + 16 * 8 + 13 * sizeof(RevDesc) + 4 * 8;  // bufA .. xchg
+constexpr size_t STAGE_FIXED = ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
+constexpr size_t STAGE1_UNION = ((SRC_SCRATCH_BYTES > STAGE_ARENA_PREFIX ? SRC_SCRATCH_BYTES : STAGE_ARENA_PREFIX) + 15) & ~15ull;
+
+struct StageLds { PgFx* lfx; int* ctl; float* red; char* arena; };
+__device__ __forceinline__ StageLds stage_lds() {
+  StageLds m;
+  char* p = pg_smem;
+  m.lfx = (PgFx*)p;   p += (sizeof(PgFx) + 15) & ~15ull;
+  m.ctl = (int*)p;    p += 128;
+  m.red = (float*)p;  p += 64;
+  m.arena = p;
+  return m;
+}
+__device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& unit) { return L.fx[L.fx_index[unit.fx_off + unit.n_fx - 1]]; }
+
+// Stage 1. RESIDENT: the later stages run in the same launch (bufA and the effect state stay in LDS). Returns false when the
+// unit was deferred to the generic kernel.
+template <int TAG, bool RESIDENT>
+__device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  PgUnit& unit = L.units[u];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = (int)L.n_frames;
+  float* out = L.unit_out + (size_t)slot * L.out_stride;
+  const int n_fx_words = (int)(sizeof(PgFx) / 4);
+  PgFx& gfx = stage_reverb(L, unit);
+  const StageLds m0 = stage_lds();
+  PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
+  float* sig = (float*)(m0.arena + STAGE1_UNION);
+  float* tmp = sig + 2 * N;
+  PgVoice* lv = (PgVoice*)(tmp + 2 * N);
+  SrcScratch S;
+  src_carve(m0.arena, S);
+  S.diag = L.diag;
+  S.sched_rd = nullptr;
+  FastCtx fc;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = m0.arena; fc.ctl = ctl; fc.red = red; fc.diag = L.diag;
+  PG_STAMP(L.diag, 0);
+  // deferral decision: identical to the fused fast kernel
+  if (tid == 0) {
+    int ok = !(unit.static_defer || unit.maybe_ramping);
+    for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;
+    unit.deferred = ok ? 0 : 1;
+    if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
+    ctl[5] = ok;
+  }
+  __syncthreads();
+  if (!ctl[5]) return false;
+  // prefetch the reverb's state block under the source stage (one qword per lane)
+  unsigned long long fxr_word = 0;
+  if (tid < n_fx_words / 2) fxr_word = ((const unsigned long long*)&gfx)[tid];
+  for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
+  __syncthreads();
+  bool audible_input = false;
+  for (int vi = 0; vi < unit.n_voices; ++vi) {
+    PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
+    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, L.pos, S, L.sched, L.sched_bank);
+  }
+  PG_STAMP(L.diag, 1);
+  int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
+  bool input_bypassed = !audible_input;
+  if (unit.effects_bypassed && input_bypassed) flags |= PG_STAGE_SKIPPED;  // process_effects (mixed.rs:627-655)
+  else {
+    bool all_bypassed = true;
+    for (int fi = 0; fi + 1 < unit.n_fx; ++fi) {  // leading Gain / Panning effects
+      PgFx& g1 = L.fx[L.fx_index[unit.fx_off + fi]];
+      __syncthreads();
+      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&g1)[i];
+      __syncthreads();
+      bool is_active;
+      if (lfx->standalone) { fx_process_wg<true, PG_KMASK_GAINPAN>(*lfx, sig, N * 2, fc, L.fast); is_active = true; }
+      else is_active = fx_processor_process<true, PG_KMASK_GAINPAN>(*lfx, sig, N * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+      if (is_active) { input_bypassed = false; all_bypassed = false; }
+      __syncthreads();
+      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&g1)[i] = ((const uint32_t*)lfx)[i];
+    }
+    __syncthreads();
+    if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fxr_word;
+    __syncthreads();
+    PG_STAMP(L.diag, 8);
+    const bool active = lfx->standalone ? true : !fx_processor_pre(*lfx, input_bypassed, ctl);
+    if (active) {
+      flags |= PG_STAGE_ACTIVE;
+      const RevLds m = rev_lds(m0.arena);
+      RevBlock b;
+      (void)rev_block_params(*lfx, m, ctl, b);  // geometry was validated by the eligibility check (reverb_fast_eligible)
+      PG_STAMP(L.diag, 11);
+      rev_front(lfx->u.reverb, sig, N, m, b, L.diag);
+      if (!RESIDENT) stage_store_image(L.stage_buf + (size_t)slot * PG_STAGE_BUF_DOUBLES, m.bufA, N);
+    }
+    if (input_bypassed) flags |= PG_STAGE_INPUT_BYPASSED;
+    if (all_bypassed) flags |= PG_STAGE_ALL_BYPASSED;
+    __syncthreads();
+    if (!RESIDENT || !(flags & PG_STAGE_ACTIVE)) for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
+  }
+  for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];  // the dry signal waits in the unit's output row
+  if (tid == 0) unit.stage_flags = flags;
+  PG_STAMP(L.diag, 14);
+  if (L.sched && tid == 0) {  // schedule cache: representatives replay the next block's resampler schedule
+    const int piece = N < SRC_OUT_CAP ? N : SRC_OUT_CAP;
+    for (int vi = 0; vi < unit.n_voices; ++vi) sched_publish(&L.voices[L.voice_index[unit.voice_off + vi]], L.sched, L.sched_bank, piece);
+  }
+  PG_STAMP(L.diag, 13);
+  return true;
+}
+
+template <int TAG, bool RESIDENT>
+__device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flags) {
+  if (!(flags & PG_STAGE_ACTIVE)) return;
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  PgUnit& unit = L.units[u];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = (int)L.n_frames;
+  const int n_fx_words = (int)(sizeof(PgFx) / 4);
+  const StageLds m0 = stage_lds();
+  PgFx* lfx = m0.lfx;
+  const RevLds m = rev_lds(m0.arena);
+  if (!RESIDENT) {
+    PgFx& gfx = stage_reverb(L, unit);
+    for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
+    stage_load_image(m.bufA, L.stage_buf + (size_t)slot * PG_STAGE_BUF_DOUBLES, N);
+  }
+  __syncthreads();
+  rev_load_vtab(lfx->u.reverb, m);
+  RevBlock b;
+  (void)rev_block_params(*lfx, m, m0.ctl, b);
+  rev_mid(lfx->u.reverb, N, m, b, m0.ctl, L.diag);
+  __syncthreads();
+  if (!RESIDENT) {
+    PgFx& gfx = stage_reverb(L, unit);
+    stage_store_image(L.stage_buf + (size_t)slot * PG_STAGE_BUF_DOUBLES, m.bufA, N);
+    for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
+  }
+}
+
+template <int TAG, bool RESIDENT>
+__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags) {
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  PgUnit& unit = L.units[u];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = (int)L.n_frames;
+  float* out = L.unit_out + (size_t)slot * L.out_stride;
+  const int n_fx_words = (int)(sizeof(PgFx) / 4);
+  const StageLds m0 = stage_lds();
+  PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
+  float* sig = (float*)(m0.arena + ((STAGE_ARENA_PREFIX + 15) & ~15ull));
+  __syncthreads();
+  for (int i = tid; i < 2 * N; i += nt) sig[i] = out[i];
+  if (!(flags & PG_STAGE_SKIPPED)) {
+    bool all_bypassed = (flags & PG_STAGE_ALL_BYPASSED) != 0;
+    if (flags & PG_STAGE_ACTIVE) {
+      PgFx& gfx = stage_reverb(L, unit);
+      const RevLds m = rev_lds(m0.arena);
+      if (!RESIDENT) {
+        for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
+        stage_load_image(m.bufA, L.stage_buf + (size_t)slot * PG_STAGE_BUF_DOUBLES, N);
+      }
+      __syncthreads();
+      RevBlock b;
+      (void)rev_block_params(*lfx, m, ctl, b);
+      rev_tail(lfx->u.reverb, sig, N, m, b, L.diag);
+      if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, L.sample_rate, ctl, red);
+      all_bypassed = false;
+      __syncthreads();
+      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
+    }
+    __syncthreads();
+    if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- hand the block to the parent mixer (same as the fused kernel) ----
+  if (unit.kind == UNIT_SUBMIXER) {
+    float max_sample = wg_max_abs(sig, 2 * N, red);
+    if (tid == 0) {
+      int audible;
+      if (max_sample < 0.001f) {
+        unit.silence_counter += (uint64_t)N;
+        audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
+      } else { unit.silence_counter = 0; audible = 1; }
+      unit.audible = audible;
+      ctl[3] = audible;
+    }
+    __syncthreads();
+    if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
+    else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
+  } else {
+    for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
+    if (tid == 0) unit.audible = (flags & PG_STAGE_AUDIBLE) ? 1 : 0;
+  }
+  PG_STAMP(L.diag, 15);
+}
+
+#ifndef PG_STAGE_WAVES
+#define PG_STAGE_WAVES 4
+#endif
+__device__ __forceinline__ bool stage_unit_staged(const PgLaunch& L, int slot) {
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  return L.units[u].staged != 0;
+}
+__device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, bool& deferred) {
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  deferred = L.units[u].deferred != 0;
+  return L.units[u].stage_flags;
+}
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage1_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  (void)stage1_run<1, false>(L, blockIdx.x);
+}
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage2_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
+  if (!deferred) stage2_run<1, false>(L, blockIdx.x, flags);
+}
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
+  if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags);
+}
+// One launch, three separately register-allocated stage functions (the launch structure lives in LDS for the calls).
+__device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
+__device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
+__device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units) return;
+  if (!stage_unit_staged(L, blockIdx.x)) return;
+  __shared__ PgLaunch sL;
+  for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
+  __syncthreads();
+  const int slot = blockIdx.x;
+  if (!stage1_call(&sL, slot)) return;
+  __syncthreads();
+  const int u = sL.unit_order ? sL.unit_order[slot] : sL.unit_base + slot;
+  const int flags = sL.units[u].stage_flags;
+  stage2_call(&sL, slot, flags);
+  __syncthreads();
+  stage3_call(&sL, slot, flags);
+}
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
 // Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
@@ -501,6 +789,37 @@ size_t pg_unit_lds_bytes(uint32_t n_frames) {
   size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
+  const size_t s1 = STAGE_FIXED + STAGE1_UNION + (size_t)n_frames * 16 + ((sizeof(PgVoice) + 15) & ~15ull);
+  const size_t s2 = STAGE_FIXED + ((FAST_SCRATCH_BYTES + 15) & ~15ull);
+  const size_t s3 = STAGE_FIXED + ((STAGE_ARENA_PREFIX + 15) & ~15ull) + (size_t)n_frames * 8;
+  if (stage == 1) return s1;
+  if (stage == 2) return s2;
+  if (stage == 3) return s3;
+  return (s1 > s2 ? (s1 > s3 ? s1 : s3) : (s2 > s3 ? s2 : s3));  // stage 0: the fused single launch
+}
+// The staged pipeline of one round (units flagged `staged`): single_launch = pg_stage_fused_kernel, else three launches
+// (L.stage_buf must then hold n_units rows).
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch) {
+  if (L.n_units <= 0) return hipSuccess;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)pg_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)pg_stage2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)pg_stage3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (single_launch) {
+    hipLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
+  } else {
+    hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
+    hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);
+    hipLaunchKernelGGL(pg_stage3_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(3, L.n_frames), stream, L);
+  }
+  return hipGetLastError();
+}
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
   if (L.n_units <= 0) return hipSuccess;
   size_t lds = pg_unit_lds_bytes(L.n_frames);
@@ -516,7 +835,7 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
   }
   if (L.mode == 1 && L.wide) hipLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), lds, stream, L);
   else if (L.mode == 1) hipLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), lds, stream, L);
-  else hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units), dim3(256), lds, stream, L);
+  else hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), lds, stream, L);
   return hipGetLastError();
 }
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,

@@ -53,6 +53,106 @@ DEVO float cubic_interp(float ym1, float y0, float y1, float y2, float fraction)
   return ((c3 * fraction + c2) * fraction + c1) * fraction + c0;
 }
 
+// ---- exact time-parallel evaluation of the resampler schedule (cubic.rs:72-90, ratio in [0.5, 1)) ----------------------------
+// The reference advances an f32 accumulator once per output frame:  ge = sp >= 1; cc += ge; sp = ge ? sp - 1 : sp; emit;
+// sp += ratio.  In units of u = 2^-24 every quantity is an integer (ratio in [0.5, 1) has ulp u; sp - 1 is exact; a sum below 1
+// is exact; a sum A in [1, 2) is representable iff A is even, an odd A is a tie and rounds to the multiple of 4). So
+//     U_k = U0_k + d_k,   U0_k = ((S + (k-1) R) mod 2^24) + R   (the recurrence without rounding, closed form),
+//     d_k = d_{k-1} + rho(U0_k + d_{k-1}),   rho(A) = A >= 2^24 and A odd ? (A mod 4 == 3 ? +1 : -1) : 0,
+// as long as the wrap decisions of the rounded and the unrounded sequence agree. d enters rho only through d mod 4, so the
+// step k is a 4-entry increment table and the tables compose: one Kogge-Stone scan over the piece gives every d_k. Where a
+// decision differs (a value within |d| of the wrap threshold, ~0.6 % of 1024-frame pieces) the closed form restarts from the
+// exact state in front of it. Bit-identical to the serial recurrence (checked against it on the host model and by the parity tests).
+struct SchedTab { int t[4]; };
+DEVO int schedtab_at(const SchedTab& a, int m) { m &= 3; return m == 0 ? a.t[0] : (m == 1 ? a.t[1] : (m == 2 ? a.t[2] : a.t[3])); }
+DEVO SchedTab schedtab_compose(const SchedTab& a, const SchedTab& b) {  // a first, then b
+  SchedTab c;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) c.t[m] = a.t[m] + schedtab_at(b, m + a.t[m]);
+  return c;
+}
+DEVO int sched_rho(int A) { return (A >= (1 << 24) && (A & 1)) ? ((A & 3) == 3 ? 1 : -1) : 0; }
+
+// All lanes of the workgroup (256). `scr`: >= 32 ints of LDS. Returns false when it gave up (caller replays serially).
+DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TWO24 = 1 << 24;
+  const int R = (int)(ratio * 16777216.0f);  // exact: ratio in [0.5, 1)
+  int* s_viol = scr;          // first element whose wrap decision differs from the closed form
+  int* s_start = scr + 1;     // restart: element, exact U of that element, wraps counted in front of it
+  int* s_res = scr + 4;       // c_total, sp_out bits
+  int* s_wave = scr + 8;      // [4 waves][4] wave totals
+  if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * 16777216.0f); s_start[2] = 0; }
+  for (int iter = 0; iter < 16; ++iter) {
+    __syncthreads();
+    const int k0 = s_start[0], S = s_start[1], cc0 = s_start[2];
+    if (tid == 0) *s_viol = 0x7fffffff;
+    // closed form of this lane's four elements
+    int U0[4]; int side[4]; SchedTab T[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * tid + e, j = k - k0;
+      int u0 = S;
+      if (j >= 1) u0 = (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)(j - 1) * (unsigned)R) & (unsigned long long)(TWO24 - 1)) + R;
+      U0[e] = u0;
+      side[e] = u0 >= TWO24;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { const int A = u0 + m; T[e].t[m] = (j >= 1 && k < piece && side[e] && (A & 1)) ? ((A & 3) == 3 ? 1 : -1) : 0; }
+    }
+    SchedTab incl = schedtab_compose(schedtab_compose(T[0], T[1]), schedtab_compose(T[2], T[3]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      SchedTab b;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) b.t[m] = __shfl_up(incl.t[m], off, 64);
+      if (lane >= off) incl = schedtab_compose(b, incl);
+    }
+    if (lane == 63) { for (int m = 0; m < 4; ++m) s_wave[wave * 4 + m] = incl.t[m]; }
+    SchedTab excl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { excl.t[m] = __shfl_up(incl.t[m], 1, 64); if (lane == 0) excl.t[m] = 0; }
+    __syncthreads();
+    int d = 0;  // d at the start element is 0; tables in front of it are identities
+    for (int w = 0; w < wave; ++w) { const int m = d & 3; d += s_wave[w * 4 + m]; }
+    d += schedtab_at(excl, d);
+    // walk the four elements with the true d
+    int viol = 0x7fffffff;
+    int Ue[4], cce[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * tid + e, j = k - k0;
+      const int A = U0[e] + d;
+      d += schedtab_at(T[e], d);
+      const int U = U0[e] + d;
+      Ue[e] = U;
+      const int cc = cc0 + (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)(j > 0 ? j : 0) * (unsigned)R) >> 24);
+      cce[e] = cc;
+      if (j >= 0 && k < piece) {
+        if (j >= 1 && (((A >= TWO24) != (side[e] != 0)) || ((U >= TWO24) != (side[e] != 0))) && viol == 0x7fffffff) viol = k;
+        const int P = U - (side[e] ? TWO24 : 0);
+        oc[k] = (uint16_t)cc;
+        of[k] = (float)P * 5.9604644775390625e-08f;
+        if (k == piece - 1) { const int A1 = P + R; s_res[0] = cc; s_res[1] = (int)__float_as_uint((float)(A1 + sched_rho(A1)) * 5.9604644775390625e-08f); }
+      }
+    }
+    if (viol != 0x7fffffff) atomicMin(s_viol, viol);
+    __syncthreads();
+    const int kv = *s_viol;
+    if (kv == 0x7fffffff) { c_total = s_res[0]; sp_out = __uint_as_float((uint32_t)s_res[1]); return true; }
+    // restart from the exact state of the element in front of the first differing decision
+    const int kr = kv - 1;
+    __syncthreads();
+    if (kr >= 4 * tid && kr < 4 * tid + 4) {
+      const int e = kr - 4 * tid;
+      const int U = e == 0 ? Ue[0] : (e == 1 ? Ue[1] : (e == 2 ? Ue[2] : Ue[3]));
+      const int cc = e == 0 ? cce[0] : (e == 1 ? cce[1] : (e == 2 ? cce[2] : cce[3]));
+      s_start[0] = kr; s_start[1] = U; s_start[2] = cc - (U >= TWO24 ? 1 : 0);
+    }
+  }
+  __syncthreads();
+  return false;
+}
+
 // PreloadedFileSource::write_buffer (src/source/file/preloaded.rs:270-332) for `out_frames` frames of the file's
 // channel layout into `out` (LDS). `v` is the unit's LDS copy of the voice. Returns frames written (uniform).
 // When `acc` is given (steady state), the finished samples are added straight into the mixer's block (add_buffers,
@@ -100,6 +200,18 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       if (cap < 1) cap = 1;
       if (piece > cap) piece = cap;
     }
+    // steady playback with ratio in [0.5, 1): every lane takes part in the exact time-parallel schedule
+    bool par_ok = false;
+    int par_c = 0;
+    float par_sp = 0.0f;
+    {
+      const float ratio = v->ratio, sp0 = v->sub_pos[0];
+      const uint64_t pp0 = v->playback_pos;
+      const uint64_t num_in0 = (lr_end > pp0 ? lr_end - pp0 : 0) / C;
+      const float t = sp0 * 16777216.0f;
+      if (ratio >= 0.5f && ratio < 1.0f && v->initialized[0] && num_in0 > (uint64_t)piece && sp0 >= 0.0f && sp0 < 2.0f && t == floorf(t) && nt == 256)
+        par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+    }
     if (tid == 0) {
       float sub_pos = v->sub_pos[0];
       const float ratio = v->ratio;
@@ -117,8 +229,15 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
         uint64_t num_in = remaining_in / C;
         const PgSchedEntry* se = S.sched_rd;
-        if (ratio < 1.0f && initialized && num_in > (uint64_t)piece && se && se->valid && se->piece == piece &&
-            se->ratio_bits == __float_as_uint(ratio) && se->subpos_in_bits == __float_as_uint(sub_pos)) {
+        if (se && !(se->valid && se->piece == piece && se->ratio_bits == __float_as_uint(ratio) && se->subpos_in_bits == __float_as_uint(sub_pos))) se = nullptr;
+        if (par_ok) {
+          S.ctl[3] = (int)(uint32_t)(pp / C);
+          c = par_c;
+          sub_pos = par_sp;
+          pp += (uint64_t)c * C;
+          produced = piece;
+          linear = 1;
+        } else if (ratio < 1.0f && initialized && num_in > (uint64_t)piece && se) {
           // schedule cache hit: the class representative replayed exactly this recurrence; lanes copy it below
           S.ctl[3] = (int)(uint32_t)(pp / C);
           c = se->c_total;
@@ -211,6 +330,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       v->sub_pos[0] = sub_pos; v->sub_pos[1] = sub_pos;
       v->initialized[0] = initialized; v->initialized[1] = initialized;
       v->playback_pos = pp; v->repeat_count = repeat_count; v->pos_eof = eof;
+      v->sched_hit = par_ok ? 2 : (linear == 2 ? 1 : 0);
       S.ctl[0] = produced; S.ctl[1] = c;
     }
     __syncthreads();
@@ -498,10 +618,28 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
   return produced_output;
 }
 
-// Representative voices publish the schedule of the NEXT block (same piece length assumed) into the other bank.
-// Runs on lane 0 after the unit's audio has been written: off the critical path of every other workgroup.
+// The f32 schedule recurrence of one piece (cubic.rs:72-90 with ratio < 1): identical operations to the replay in
+// src_write_buffer. One lane; results go to `oc` / `of` (LDS or global).
+template <typename C16, typename F32>
+DEVO void sched_replay(float ratio, float& sp, int& cc, int piece, C16* oc, F32* of) {
+  asm volatile("" : "+v"(sp), "+v"(cc));
+  for (int k = 0; k < piece; ++k) {
+    const bool ge = sp >= 1.0f;
+    cc += ge ? 1 : 0;
+    sp = ge ? sp - 1.0f : sp;
+    oc[k] = (uint16_t)cc;
+    of[k] = sp;
+    sp += ratio;
+  }
+}
+
+// Schedule cache for the ratios the time-parallel schedule does not cover (ratio < 0.5): the class representative publishes the
+// schedule of the NEXT block (same piece length assumed) into the other bank, from its own state after this block; the other
+// voices of the class (same f32 ratio, same sub_pos) copy it instead of replaying it. Runs on lane 0 after the unit's audio has
+// been written.
 DEVO void sched_publish(const PgVoice* gv, PgSchedEntry* sched, int sched_bank, int piece) {
   if (!sched || gv->sched_class < 0 || !gv->sched_rep) return;
+  if (gv->sched_hit == 2) return;  // the class runs the time-parallel schedule: nobody reads the cache
   PgSchedEntry* e = sched + (size_t)gv->sched_class * 2 + (sched_bank ^ 1);
   const float ratio = gv->ratio;
   const bool ok = gv->active && !gv->finished && gv->initialized[0] && ratio < 1.0f && fabsf(ratio - 1.0f) >= 0.000001f && piece >= 1 && piece <= PG_SCHED_CAP;
@@ -511,15 +649,7 @@ DEVO void sched_publish(const PgVoice* gv, PgSchedEntry* sched, int sched_bank, 
   e->ratio_bits = __float_as_uint(ratio);
   e->subpos_in_bits = __float_as_uint(sp);
   e->piece = piece;
-  asm volatile("" : "+v"(sp), "+v"(cc));
-  for (int k = 0; k < piece; ++k) {  // identical operations to the replay in src_write_buffer (cubic.rs:72-90)
-    const bool ge = sp >= 1.0f;
-    cc += ge ? 1 : 0;
-    sp = ge ? sp - 1.0f : sp;
-    e->sched_c[k] = (uint16_t)cc;
-    e->sched_f[k] = sp;
-    sp += ratio;
-  }
+  sched_replay(ratio, sp, cc, piece, e->sched_c, e->sched_f);
   e->subpos_out_bits = __float_as_uint(sp);
   e->c_total = cc;
   e->valid = 1;

@@ -43,6 +43,10 @@ class Graph(GraphHandle):
     def set_fast_math(self, level):
         self._check(self._lib.pg_graph_set_fast_math(self._h, int(level)))
 
+    def set_staged(self, mode):
+        """[Gain|Panning]* -> Reverb sub-mixers: 1/True = staged single launch (default), 2 = one launch per stage, 0/False = fused fast kernel."""
+        self._check(self._lib.pg_graph_set_staged(self._h, int(mode)))
+
 
 def effect_parameters(kind):
     """`Effect::parameters()` descriptors of an effect kind."""

@@ -249,3 +249,79 @@ def test_speed_glide_and_seek():
     a, b = both(build, 16, 1024, actions={1: act1, 3: act3}, max_frames=1024)
     compare(a, b)
     assert not np.array_equal(a[:2048], a[2048 * 8:2048 * 9])
+
+
+def _render_modes(build, n_blocks, block, actions=None):
+    """Renders the same graph with the staged kernel, with one launch per stage, with the fused kernel, and on the oracle."""
+    from phonic_amd.graph import Graph
+
+    outs = []
+    for mode in ("staged", "per-stage", "fused", "oracle"):
+        g = oracle.OracleGraph(SR, 2, block) if mode == "oracle" else Graph(SR, 2, block, 0)
+        if mode != "oracle":
+            g.set_staged({"staged": 1, "per-stage": 2, "fused": 0}[mode])
+        ids = build(g)
+        out = np.zeros((n_blocks, block * 2), np.float32)
+        pos = 0
+        for blk in range(n_blocks):
+            if actions and blk in actions:
+                actions[blk](g, ids, pos)
+            w = g.write(out[blk], pos)
+            assert w in (0, block * 2)
+            pos += block
+        outs.append(out.reshape(-1))
+    return outs
+
+
+def test_staged_pipeline_matches_fused_kernel_and_oracle():
+    """[Gain|Panning]* -> Reverb sub-mixers go through pg_stage1/2/3_kernel by default; pg_graph_set_staged(0) keeps them
+    in the fused kernel. Both must agree with each other (same stage functions, f64 rounding only) and with the oracle."""
+    def build(g):
+        workloads.build_headline(g, 5, seconds=0.2)
+        m = g.add_mixer()   # two voices, leading Gain and Panning effects in front of the reverb
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.7})
+        g.add_effect(m, _capi.FX_PANNING, params={"pan ": -0.3})
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.45, "wet ": 0.6}, reverb_seeds=workloads.reverb_seeds(77))
+        for i in range(2):
+            g.add_voice(m, workloads.tone_buffer(20 + i, 44100, 0.2), 2, 44100, volume=0.4, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return {}
+    staged, per_stage, fused, ref = _render_modes(build, 8, 1024)
+    assert np.array_equal(staged, per_stage)
+    assert float(np.abs(staged - fused).max()) <= 2e-6
+    compare(staged, ref)
+    compare(fused, ref)
+    assert np.abs(staged).max() > 1e-3
+
+
+def test_staged_pipeline_tail_bypass_and_parameter_handover():
+    """One-shot voice into a reverb sub-mixer: source ends, the reverb runs on silence (tail/silence counters, auto-bypass,
+    sub-mixer silence gate); a second sub-mixer gets a room-size ramp in the middle (stage 1 defers it to the generic kernel)."""
+    def build(g):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.3}, reverb_seeds=workloads.reverb_seeds(5))
+        g.add_voice(m, workloads.tone_buffer(4, 48000, 0.05), 2, 48000)
+        m2 = g.add_mixer()
+        fx = g.add_effect(m2, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(6))
+        g.add_voice(m2, workloads.tone_buffer(9, 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return [fx]
+
+    def act(g, ids, pos):
+        g.schedule_param(ids[0], "room", 0.8, pos + 300)
+
+    staged, per_stage, fused, ref = _render_modes(build, 130, 1024, actions={40: act})
+    assert np.array_equal(staged, per_stage)
+    assert float(np.abs(staged - fused).max()) <= 2e-6
+    compare(staged, ref)
+
+
+@pytest.mark.parametrize("rate,block,n_blocks", [(44100, 1024, 400), (32000, 1000, 60), (40000, 777, 80), (16000, 1024, 40), (22050, 512, 60), (47999, 1024, 60)])
+def test_resampler_schedule_bit_exact_over_many_blocks(rate, block, n_blocks):
+    """The f32 sub_pos schedule has three device implementations — the exact time-parallel one (ratio in [0.5, 1): closed form +
+    rounding-table scan, restarted where a wrap decision differs, which happens in ~0.6 % of the blocks, hence 400 blocks at
+    44.1 kHz), the schedule cache (ratio < 0.5, two voices of one class) and the serial replay. All must equal the reference's
+    serial recurrence bit for bit: a single unit-gain voice straight into the main mixer is compared with array_equal."""
+    def build(g):
+        return [g.add_voice(0, workloads.tone_buffer(1, rate, 0.11), 2, rate, volume=1.0, panning=0.0, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)]
+    a, b = both(build, n_blocks, block, max_frames=1024)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 1e-3
