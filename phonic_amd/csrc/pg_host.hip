@@ -410,6 +410,7 @@ struct pg_graph {
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
+  DeviceVec<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
   int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
   size_t defer_rows = 0;
   size_t stage_rows = 0;
@@ -525,6 +526,15 @@ static int rebuild_topology(pg_graph* g) {
     g->order.push_back(slot);
   }
   g->n_graph_units = (int)g->order.size();
+  {
+    std::vector<int4> info;
+    for (int slot : g->order) {
+      const PgUnit& u = topo[slot];
+      info.push_back(make_int4(slot, u.voice0, u.n_fx > 0 ? fidx[u.fx_off + u.n_fx - 1] : 0, u.n_voices));
+    }
+    int rc0;
+    if ((rc0 = g->d_slot_info.upload(info))) return rc0;
+  }
   g->n_staged = 0;
   for (int slot : g->order) g->n_staged += topo[slot].staged ? 1 : 0;
   g->h_units = topo;
@@ -621,7 +631,7 @@ void pg_graph_destroy(pg_graph* g) {
   for (auto& v : g->voices) if (v.d_pcm) (void)hipFree(v.d_pcm);
   for (auto& f : g->fx) if (f->d_mem) (void)hipFree(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_cmds.release(); g->d_sched.release();
+  g->d_cmds.release(); g->d_sched.release(); g->d_slot_info.release();
   if (g->d_unit_out) (void)hipFree(g->d_unit_out);
   if (g->d_partial) (void)hipFree(g->d_partial);
   if (g->d_stage) (void)hipFree(g->d_stage);
@@ -822,9 +832,10 @@ int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // M
 
 int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic builds: shader-clock stamps of workgroup 0
   (void)hipSetDevice(g->device);
-  if (!g->d_diag) { HIP_TRY(hipMalloc((void**)&g->d_diag, 64 * 8)); HIP_TRY(hipMemset(g->d_diag, 0, 64 * 8)); return PG_OK; }
+  const int cap = 64 + 4 * 4096;  // 64 stamps of workgroup 0, then {start, stage-1 end, stage-2 end, end} (s_memrealtime, 100 MHz) per launch slot
+  if (!g->d_diag) { HIP_TRY(hipMalloc((void**)&g->d_diag, (size_t)cap * 8)); HIP_TRY(hipMemset(g->d_diag, 0, (size_t)cap * 8)); return PG_OK; }
   HIP_TRY(hipStreamSynchronize(g->stream));
-  HIP_TRY(hipMemcpy(out, g->d_diag, (size_t)(n > 64 ? 64 : n) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, g->d_diag, (size_t)(n > cap ? cap : n) * 8, hipMemcpyDeviceToHost));
   return PG_OK;
 }
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
@@ -874,6 +885,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.unit_out = g->d_unit_out; L.out_stride = g->stride;
   L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
   L.diag = g->d_diag;
+  L.slot_info = g->d_slot_info.d;
   if (g->d_defer) { L.defer_count = g->d_defer + (g->launch_counter & 1); L.defer_reset = g->d_defer + ((g->launch_counter & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;

@@ -524,13 +524,19 @@ __device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& u
 // unit was deferred to the generic kernel.
 template <int TAG, bool RESIDENT>
 __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
-  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  // one load names the unit, its first voice and its reverb: their state blocks are then fetched side by side
+  const int4 si = L.slot_info[slot];
+  const int u = si.x;
   PgUnit& unit = L.units[u];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = (int)L.n_frames;
   float* out = L.unit_out + (size_t)slot * L.out_stride;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
-  PgFx& gfx = stage_reverb(L, unit);
+  PgFx& gfx = L.fx[si.z];
+  uint32_t voice_word = 0;
+  if (si.w > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
+  unsigned long long fxr_word = 0;  // the reverb's state block (one qword per lane), used after the source stage
+  if (tid < n_fx_words / 2) fxr_word = ((const unsigned long long*)&gfx)[tid];
   const StageLds m0 = stage_lds();
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
   float* sig = (float*)(m0.arena + STAGE1_UNION);
@@ -553,15 +559,12 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
   }
   __syncthreads();
   if (!ctl[5]) return false;
-  // prefetch the reverb's state block under the source stage (one qword per lane)
-  unsigned long long fxr_word = 0;
-  if (tid < n_fx_words / 2) fxr_word = ((const unsigned long long*)&gfx)[tid];
   for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
   __syncthreads();
   bool audible_input = false;
   for (int vi = 0; vi < unit.n_voices; ++vi) {
-    PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
-    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, L.pos, S, L.sched, L.sched_bank);
+    PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[unit.voice_off + vi]];
+    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, L.pos, S, L.sched, L.sched_bank, vi == 0, voice_word);
   }
   PG_STAMP(L.diag, 1);
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
@@ -734,13 +737,22 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
   for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
   __syncthreads();
   const int slot = blockIdx.x;
+#ifdef PG_DIAG
+#define PG_SLOT_STAMP(i) do { if (L.diag && threadIdx.x == 0 && slot < 4096) L.diag[64 + 4 * slot + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PG_SLOT_STAMP(i) do { } while (0)
+#endif
+  PG_SLOT_STAMP(0);
   if (!stage1_call(&sL, slot)) return;
   __syncthreads();
+  PG_SLOT_STAMP(1);
   const int u = sL.unit_order ? sL.unit_order[slot] : sL.unit_base + slot;
   const int flags = sL.units[u].stage_flags;
   stage2_call(&sL, slot, flags);
   __syncthreads();
+  PG_SLOT_STAMP(2);
   stage3_call(&sL, slot, flags);
+  PG_SLOT_STAMP(3);
 }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------

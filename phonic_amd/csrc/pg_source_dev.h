@@ -204,13 +204,26 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
     bool par_ok = false;
     int par_c = 0;
     float par_sp = 0.0f;
+    unsigned long long win_x[4] = {0ull, 0ull, 0ull, 0ull};  // prefetched stereo frames of the input window
+    int win_pref = 0;
     {
       const float ratio = v->ratio, sp0 = v->sub_pos[0];
       const uint64_t pp0 = v->playback_pos;
       const uint64_t num_in0 = (lr_end > pp0 ? lr_end - pp0 : 0) / C;
       const float t = sp0 * 16777216.0f;
-      if (ratio >= 0.5f && ratio < 1.0f && v->initialized[0] && num_in0 > (uint64_t)piece && sp0 >= 0.0f && sp0 < 2.0f && t == floorf(t) && nt == 256)
+      if (ratio >= 0.5f && ratio < 1.0f && v->initialized[0] && num_in0 > (uint64_t)piece && sp0 >= 0.0f && sp0 < 2.0f && t == floorf(t) && nt == 256) {
+        if (C == 2) {  // the input window goes out to HBM before the schedule is known: an upper bound of the consumed frames is
+          typedef __attribute__((address_space(1))) const unsigned long long gu64;
+          gu64* src = (gu64*)(v->pcm) + (uint64_t)(pp0 / 2);
+          int bound = (int)(sp0 + (float)piece * ratio) + 2;
+          if ((uint64_t)bound > num_in0) bound = (int)num_in0;
+          if (bound > 4 * nt) bound = 4 * nt;
+          win_pref = bound;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const int j = k * nt + tid; win_x[k] = j < bound ? src[j] : 0ull; }
+        }
         par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+      }
     }
     if (tid == 0) {
       float sub_pos = v->sub_pos[0];
@@ -349,6 +362,13 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       float* w0 = S.win;
       float* w1 = S.win + (SRC_WIN_CAP + 4);
       if (tid < 4) { w0[tid] = v->input[0][3 - tid]; w1[tid] = v->input[1][3 - tid]; }  // oldest first: input[3] .. input[0]
+      if (par_ok && c_total <= win_pref) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = k * nt + tid;
+          if (j < c_total) { w0[4 + j] = __uint_as_float((uint32_t)win_x[k]); w1[4 + j] = __uint_as_float((uint32_t)(win_x[k] >> 32)); }
+        }
+      } else
       for (int jb = 0; jb < c_total; jb += 4 * nt) {
         unsigned long long x[4];
 #pragma unroll
@@ -559,14 +579,16 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 // into `sig`. Returns true when the source produced output.
 template <bool GLIDE>
 DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
-                        const PgSchedEntry* sched, int sched_bank) {
+                        const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0) {
   SrcScratch S = S0;
   const int tid = threadIdx.x, nt = blockDim.x;
+  static_assert(sizeof(PgVoice) / 4 <= 256, "one dword per lane");
   __syncthreads();
-  {  // stage the voice state into LDS (uniform reads, lane-0 writes)
+  {  // stage the voice state into LDS (uniform reads, lane-0 writes); `word` = this lane's dword when the caller prefetched it
     const uint32_t* src = (const uint32_t*)gv;
     uint32_t* dst = (uint32_t*)lv;
-    for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
+    if (have_word) { if (tid < (int)(sizeof(PgVoice) / 4)) dst[tid] = word; }
+    else for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
   }
   __syncthreads();
   S.sched_rd = (sched && lv->sched_class >= 0) ? sched + (size_t)lv->sched_class * 2 + sched_bank : nullptr;

@@ -1,0 +1,33 @@
+# per-workgroup start / stage ends of the staged kernel's last launch (diagnostic build, -DPG_DIAG); s_memrealtime ticks = 10 ns
+import sys, ctypes as C, os
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+import numpy as np, torch
+from phonic_amd.graph import Graph
+from phonic_amd import _capi
+import workloads
+V=1024
+g=Graph(48000,2,1024,0)
+workloads.build_headline(g,V,0,V,2.0)
+lib=_capi.load()
+lib.pg_graph_diag.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.c_int]
+N=64+4*4096
+buf=(C.c_uint64*N)()
+lib.pg_graph_diag(g._h,buf,N)
+bus=torch.zeros(2048,device='cuda:0')
+pos=0
+for i in range(12):
+    g.write_device(bus.data_ptr(),2048,pos); pos+=1024
+g.synchronize()
+lib.pg_graph_diag(g._h,buf,N)
+a=np.array(buf[64:64+4*V],dtype=np.int64).reshape(V,4)
+t0=a[:,0].min()
+us=(a-t0)/100.0
+print("starts  us: min %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(us[:,0],[0,50,90,100])))
+for i,n in enumerate(["stage1","stage2","stage3"]):
+    d=us[:,i+1]-us[:,i]
+    print("%s dur us: min %.1f p50 %.1f p90 %.1f max %.1f" % ((n,)+tuple(np.percentile(d,[0,50,90,100]))))
+print("ends    us: min %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(us[:,3],[0,50,90,100])))
+tot=us[:,3]-us[:,0]
+print("per-WG total us: min %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(tot,[0,50,90,100])))
+late=np.argsort(us[:,0])[-8:]
+print("latest starters (slot, start, end):", [(int(s), round(float(us[s,0]),1), round(float(us[s,3]),1)) for s in late])
