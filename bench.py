@@ -13,8 +13,9 @@ Multi-GPU: voices are sharded over ranks (weak scaling: --voices per GPU), each 
 bus on its GPU, and the partial buses meet in one RCCL sum-reduce to rank 0 per block (the reference's caller-side
 sum of worker outputs, src/source/mixed.rs:522-536).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, hipEvent-timed) and `cpu_baseline` (the CPU
-oracle — a C++ port of the reference path, NOT the Rust binary — on this box's host cores, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel launch(es) of the graph, named in `roofline.kernel`, hipEvent-timed
+on the launching stream) and `cpu_baseline` (the CPU oracle — a C++ port of the reference path, NOT the Rust binary — on this
+box's host cores, bounded sample of about 12 s).
 """
 import argparse
 import json
@@ -68,8 +69,9 @@ def pmc_traffic(name, v_per_gpu, block):
     return best["traffic_bytes_per_launch"] if best else None
 
 
-def cpu_baseline(name, block, seconds_budget=5.0):
-    """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core chunk)."""
+def cpu_baseline(name, block, seconds_budget=12.0):
+    """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core). A short parallel
+    run calibrates the block count so that the timed sample takes about `seconds_budget` seconds on this host."""
     import ctypes as C
 
     import oracle
@@ -77,24 +79,23 @@ def cpu_baseline(name, block, seconds_budget=5.0):
     cores = os.cpu_count() or 1
     threads = cores
     lib = oracle.lib()
-    # calibrate with one small graph, then size the sample for ~seconds_budget of wall time
     per_graph = {"headline": 4, "c2": 16, "c3": 8, "c4": 32, "c5": 2}[name]
-    gcal = oracle.OracleGraph(48000, 2, block)
-    build_workload(gcal, name, per_graph, 0, per_graph, 0.5)
-    t0 = time.perf_counter()
-    gcal.render(8, block)
-    t_cal = (time.perf_counter() - t0) / 8.0  # s per block per graph on one core
     n_graphs = threads
-    # one graph per thread; sized from the single-thread calibration (contention on a many-core host stretches it 2-4x)
-    n_blocks = int(max(8, min(2000, seconds_budget / max(t_cal, 1e-6))))
-    graphs = [oracle.OracleGraph(48000, 2, block) for _ in range(n_graphs)]
-    for i, g in enumerate(graphs):
-        build_workload(g, name, per_graph, i * per_graph, per_graph * n_graphs, 0.5)
-    handles = (C.c_void_p * n_graphs)(*[g._h for g in graphs])
-    outs = np.zeros(n_graphs * n_blocks * block * 2, np.float32)
-    t0 = time.perf_counter()
-    lib.po_graphs_render_parallel(handles, n_graphs, threads, outs.ctypes.data_as(C.POINTER(C.c_float)), block * 2, n_blocks, 0)
-    dt = time.perf_counter() - t0
+
+    def run(n_blocks):
+        graphs = [oracle.OracleGraph(48000, 2, block) for _ in range(n_graphs)]
+        for i, g in enumerate(graphs):
+            build_workload(g, name, per_graph, i * per_graph, per_graph * n_graphs, 0.5)
+        handles = (C.c_void_p * n_graphs)(*[g._h for g in graphs])
+        outs = np.zeros(n_graphs * n_blocks * block * 2, np.float32)
+        t0 = time.perf_counter()
+        lib.po_graphs_render_parallel(handles, n_graphs, threads, outs.ctypes.data_as(C.POINTER(C.c_float)), block * 2, n_blocks, 0)
+        return time.perf_counter() - t0
+
+    cal_blocks = 16
+    t_cal = run(cal_blocks)
+    n_blocks = int(max(cal_blocks, min(4000, seconds_budget * cal_blocks / max(t_cal, 1e-6))))
+    dt = run(n_blocks)
     vf = n_graphs * per_graph * n_blocks * block
     return {
         "value": vf / dt,
@@ -245,7 +246,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(name, v_per_gpu, block),
-                "kernel": "pg_unit_kernel_fast",
+                "kernel": g.dominant_kernel(),
                 "kernel_ms": kernel_ms,
                 "launches": launches,
                 "bytes_per_voice_frame": B_ALG[name],

@@ -202,9 +202,11 @@ int pg_graph_synchronize(pg_graph* g);
 /* Introspection used by the harness */
 int pg_graph_voice_count(pg_graph* g);
 int pg_graph_is_voice_playing(pg_graph* g, int voice_id);
-/* Average device time (ms) of the dominant kernel (voice/sub-mixer chain kernel) over the launches
+/* Average device time (ms) of the dominant kernel launch(es) (see pg_graph_dominant_kernel) over the launches
  * since the last call with reset != 0, measured with hipEvents on the graph's stream; launches = count. */
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
+/* Name(s) of the kernel launch(es) the pg_graph_kernel_ms events bracket for this graph (static string). */
+const char* pg_graph_dominant_kernel(pg_graph* g);
 /* 0 = exact serial filters, 1 = time-parallel (blocked) evaluation of linear filters (default) */
 int pg_graph_set_fast_math(pg_graph* g, int level);
 /* How sub-mixers whose chain is [Gain|Panning]* -> Reverb are rendered: 1 (default) = staged kernel (three separately

@@ -409,6 +409,7 @@ struct pg_graph {
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline
+  int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceVec<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
   int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
@@ -535,8 +536,8 @@ static int rebuild_topology(pg_graph* g) {
     int rc0;
     if ((rc0 = g->d_slot_info.upload(info))) return rc0;
   }
-  g->n_staged = 0;
-  for (int slot : g->order) g->n_staged += topo[slot].staged ? 1 : 0;
+  g->n_staged = 0; g->n_static_defer = 0;
+  for (int slot : g->order) { g->n_staged += topo[slot].staged ? 1 : 0; g->n_static_defer += topo[slot].static_defer ? 1 : 0; }
   g->h_units = topo;
   int rc;
   if ((rc = g->d_voice_index.upload(vidx))) return rc;
@@ -840,6 +841,15 @@ int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic 
 }
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
 int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; return PG_OK; }
+const char* pg_graph_dominant_kernel(pg_graph* g) {
+  if (g->topo_dirty) (void)rebuild_topology(g);
+  if (!g->fast || g->n_static_defer * 2 > g->n_graph_units) return "pg_unit_kernel";
+  if (g->staged_mode && g->n_staged > 0) {
+    if (g->n_staged < g->n_graph_units) return g->staged_mode == 1 ? "pg_stage_fused_kernel + pg_unit_kernel_fast" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel + pg_unit_kernel_fast";
+    return g->staged_mode == 1 ? "pg_stage_fused_kernel" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel";
+  }
+  return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
+}
 int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
 int pg_graph_synchronize(pg_graph* g) {
@@ -896,7 +906,10 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     HIP_TRY(hipEventCreate(&b));
     g->ev_pool.emplace_back(a, b);
   }
-  if (timed) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
+  // The event pair brackets the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most
+  // units hold an effect without a time-parallel path — the generic kernel.
+  const bool time_generic = g->fast && g->n_static_defer * 2 > g->n_graph_units;
+  if (timed && !time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
   if (g->fast) {
     L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
     const bool staged = g->staged_mode && g->n_staged > 0 && g->d_stage && n <= 1024;
@@ -905,9 +918,11 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
       HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0));
     }
     if (!staged || g->n_staged < g->n_graph_units) HIP_TRY(pg_launch_units(L, stream));
-    if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+    if (timed && !time_generic) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+    if (timed && time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
     L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit
     HIP_TRY(pg_launch_units(L, stream));
+    if (timed && time_generic) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
   } else {
     L.mode = 0;
     if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean

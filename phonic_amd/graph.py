@@ -40,6 +40,10 @@ class Graph(GraphHandle):
         ms = self._lib.pg_graph_kernel_ms(self._h, 1 if reset else 0, C.byref(n))
         return ms, n.value
 
+    def dominant_kernel(self):
+        """Name(s) of the kernel launch(es) that `kernel_ms` brackets for this graph."""
+        return self._lib.pg_graph_dominant_kernel(self._h).decode()
+
     def set_fast_math(self, level):
         self._check(self._lib.pg_graph_set_fast_math(self._h, int(level)))
 
