@@ -417,7 +417,9 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
         // Order matters for latency: first everything that only needs the (known) vibrato phases — the 16 line taps of
         // the previous frame's `get` — and the 4 allpass taps go out to HBM; the f64 sin of the front end and the allpass
         // chain then run underneath those loads.
-        double tv1[8], tv2[8], tfr[8];
+        double tv1[8], tv2[8];
+        uint32_t tfr[8];  // interpolation fraction as 0.32 fixed point (2^-33 error): frees 8 VGPRs, which keeps the loop free of spills —
+                          // a spilled tap would put an `s_waitcnt vmcnt(0)` in the middle of the load issue
         if (n >= 1) {
           // sin(phase_n) ~= sin(pb + j*d): pb = the sub-chunk's exact anchor phase, j*d = tabulated rotation. The reference's
           // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 128 * 2^-52 * |p|
@@ -439,7 +441,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
             const double sn = fma(q_a0[i & 1], q_ct[i & 1], q_a1[i & 1] * q_st[i & 1]);
             const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;
             const double w_floor = floor(working);
-            tfr[i] = working - w_floor;
+            tfr[i] = (uint32_t)((working - w_floor) * 4294967296.0);
             const uint32_t w_int = (uint32_t)w_floor;                 // < count + 15 <= delay + 15 < 2 * (delay + 1)
             tv1[i] = *ring_ptr(ld, ring_wrap(w_int, ld.m), ch);       // `if read > delay { read -= delay + 1 }`
             tv2[i] = *ring_ptr(ld, ring_wrap(w_int + 1, ld.m), ch);
@@ -465,7 +467,8 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
           double g[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // interpolation + blend (reverb.rs:578-583)
-            const double interpol = tv1[i] * (1.0 - tfr[i]) + tv2[i] * tfr[i];
+            const double fr = (double)tfr[i] * 2.3283064365386963e-10;
+            const double interpol = tv1[i] * (1.0 - fr) + tv2[i] * fr;
             g[i] = (1.0 - blend) * interpol + (tv1[i] * blend);
           }
           F[0] = (g[0] - (g[1] + g[2] + g[3])) * regen; F[1] = (g[1] - (g[0] + g[2] + g[3])) * regen;   // reverb.rs:303-306
