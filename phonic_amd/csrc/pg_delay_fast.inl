@@ -1,0 +1,173 @@
+// Time-parallel steady-state DelayEffect (reference src/effect/delay.rs:334-454) for one workgroup.
+//
+// Why this is legal: with the three LFO modulation depths at zero and no parameter ramping, every per-frame control value
+// of the reference loop is a block constant (lfo_val * 0 = +-0, powf(2, +-0) = 1), and the only feedback path runs through the
+// delay line: frame n reads the line `delay_samples` behind the write head, so inside a chunk of T <= floor(delay_samples) - 1
+// frames every line READ hits data written before the chunk. Per chunk:
+//   1. all (frame, channel) items read their two taps and interpolate           (InterpolatedDelayLine::process, delay.rs:107-155)
+//   2. the wet path  SVF -> saturate -> DC filter -> clamp  over the chunk: the SVF (linear, 2 states) and the DC filter (linear,
+//      1 state) by blocked scans, the rational tanh and the clamp element-wise                     (process_feedback, delay.rs:226-237)
+//   3. all items write  input + previous frame's wet value * feedback  into the line and mix the output (dry/wet law, M/S width)
+// The LFO only advances its f32 phase; f32_phase_advance reproduces T accumulation steps exactly in closed form.
+// Same arithmetic as the serial loop up to the f64 rounding of the two scans (the wet value is rounded to f32 as in the reference).
+
+// DcFilter::process_sample (src/utils/dsp/filters/dc.rs:84-88) over the chunk, both channels, in place on the skewed LDS buffer:
+//   y_n = (x_n - x_{n-1}) + r * y_{n-1}.  Blocked like the biquad scan: 128 segments of 8 frames per channel.
+DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] */) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ch = wave & 1, half = wave >> 1;
+  const int seg = half * 64 + lane;
+  const int n0 = seg * 8;
+  const int len = n0 >= T ? 0 : (T - n0 < 8 ? T - n0 : 8);
+  const double r = dc[ch].r;
+  double x[8];
+  const double x_in = (n0 == 0) ? dc[ch].x1 : (len > 0 ? buf[REV_IDX(n0 - 1, ch)] : 0.0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = k < len ? buf[REV_IDX(n0 + k, ch)] : 0.0;
+  // pass 1: zero-state response of the segment (segment 0 starts from the carried state)
+  double y = (seg == 0) ? dc[ch].y1 : 0.0;
+  {
+    double xp = x_in;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < len) { y = (x[k] - xp) + r * y; xp = x[k]; }
+  }
+  double r2 = r * r, r4 = r2 * r2;
+  const double r8 = r4 * r4;
+  auto wave_scan = [&](double& z) {
+    double P = r8;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double zp = __shfl_up(z, off, 64);
+      if (lane >= off) z = z + P * zp;
+      P = P * P;
+    }
+  };
+  if (half == 0) { wave_scan(y); if (lane == 63) xchg[ch] = y; }
+  __syncthreads();  // also: every lane has read its inputs before pass 2 overwrites the buffer
+  double e = y;
+  if (half == 1) {
+    if (lane == 0) y = y + r8 * xchg[ch];
+    wave_scan(y);
+    e = y;
+  }
+  double ys = __shfl_up(e, 1, 64);  // start state of the segment = end state of the previous one
+  if (lane == 0) ys = (half == 0) ? dc[ch].y1 : xchg[ch];
+  // pass 2
+  {
+    double xp = x_in;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < len) { ys = (x[k] - xp) + r * ys; xp = x[k]; buf[REV_IDX(n0 + k, ch)] = ys; }
+    __syncthreads();
+    if (len > 0 && n0 + len == T) { dc[ch].y1 = ys; dc[ch].x1 = xp; }
+  }
+}
+
+DEVO bool delay_fast_eligible(const PgFx& fx) {
+  const PgDelay& d = fx.u.delay;
+  if (sm_need_ramp(d.delay_time) || sm_need_ramp(d.feedback) || sm_need_ramp(d.cutoff) || sm_need_ramp(d.drive) || sm_need_ramp(d.wet) ||
+      sm_need_ramp(d.width) || sm_need_ramp(d.lfo_rate) || sm_need_ramp(d.d_time) || sm_need_ramp(d.d_feedback) || sm_need_ramp(d.d_filter))
+    return false;
+  if (d.d_time.target != 0.0f || d.d_feedback.target != 0.0f || d.d_filter.target != 0.0f) return false;  // LFO modulation: serial path
+  const float delay_samples = fmaxf(d.delay_time.target, 1.0f) * 0.001f * (float)fx.sample_rate;
+  return delay_samples >= 66.0f && delay_samples < (float)(d.mask - 8);
+}
+
+DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  if (!delay_fast_eligible(fx)) return false;
+  PgDelay& d = fx.u.delay;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int frames = n_samples / 2;
+  if (frames == 0) return true;
+  double* buf = (double*)fc.scratch;                       // [T][2] f64, skewed (REV_IDX)
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  PgBiquadCoef* lco = (PgBiquadCoef*)(xchg + 4);           // the SVF as (a1, a2, a3, m0, m1, m2) for the blocked scan
+  const float srf = (float)fx.sample_rate;
+  // block constants: the reference's per-frame expressions with lfo_val * 0 folded (delay.rs:346-376)
+  const float delay_ms = fmaxf(d.delay_time.target + 0.0f, 1.0f);
+  const float delay_samples = delay_ms * 0.001f * srf;
+  const float fb = clampf(d.feedback.target + 0.0f, 0.0f, 0.999f);
+  const float drive = d.drive.target, wet = d.wet.target, width = d.width.target;
+  __syncthreads();
+  if (tid == 0) {
+    const float cutoff = clampf(d.cutoff.target * 1.0f, 20.0f, (float)fx.sample_rate / 2.0f);
+    svf_set(d.coef, delay_to_svf(d.filter_type), fx.sample_rate, cutoff, 0.302f);
+    PgBiquadCoef c;
+    c.a1 = d.coef.a1; c.a2 = d.coef.a2; c.a3 = d.coef.a3;
+    if (d.coef.type == 0) { c.m0 = 0.0; c.m1 = 0.0; c.m2 = 1.0; }            // Lowpass: v2
+    else if (d.coef.type == 2) { c.m0 = 0.0; c.m1 = 1.0; c.m2 = 0.0; }       // Bandpass: v1
+    else { c.m0 = 1.0; c.m1 = -d.coef.k; c.m2 = -1.0; }                      // Highpass: v0 - k v1 - v2
+    *lco = c;
+  }
+  __syncthreads();
+  const int t_max = (int)floorf(delay_samples) - 1;
+  const uint32_t mask = d.mask;
+  const float dry_gain = fminf((1.0f - wet) * 2.0f, 1.0f);
+  const float wet_gain = fminf(wet * 2.0f, 1.0f);
+  const int mode = d.mode;
+  int done = 0;
+  while (done < frames) {
+    int T = frames - done;
+    if (T > t_max) T = t_max;
+    if (T > 1024) T = 1024;
+    float* s0 = sig + 2 * done;
+    const uint32_t wp0[2] = {d.write_pos[0], d.write_pos[1]};
+    const float fb_in[2] = {d.fb[0], d.fb[1]};
+    __syncthreads();
+    // 1. taps + interpolation (delay.rs:118-134)
+    for (int s = tid; s < 2 * T; s += nt) {
+      const int nn = s >> 1, ch = s & 1;
+      const gdouble* line = (const gdouble*)d.line[ch];
+      const uint32_t wp = (wp0[ch] + (uint32_t)nn) & mask;
+      const double read_pos = (double)wp - (double)delay_samples;
+      const double read_pos_floor = floor(read_pos);
+      const double fraction = read_pos - read_pos_floor;
+      const long long index1 = (long long)read_pos_floor;
+      const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+      const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+      const double v1 = line[i1], v2 = line[i2];
+      buf[REV_IDX(nn, ch)] = (double)(float)(v1 + (v2 - v1) * fraction);
+    }
+    __syncthreads();
+    // 2. wet path
+    rev_biquad_scan(*lco, d.flt, buf, T, xchg);
+    __syncthreads();
+    for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); buf[bi] = delay_saturate(buf[bi], drive); }
+    __syncthreads();
+    dc_scan(d.dc, buf, T, xchg);
+    __syncthreads();
+    // 3. line writes and output. clean(n) = clamp((f32) y_n); the line of frame n takes the previous frame's clean value
+    for (int s = tid; s < 2 * T; s += nt) {
+      const int nn = s >> 1, ch = s & 1;
+      const float left_input = s0[2 * nn], right_input = s0[2 * nn + 1];
+      const float clean_l = clampf((float)buf[REV_IDX(nn, 0)], -4.0f, 4.0f), clean_r = clampf((float)buf[REV_IDX(nn, 1)], -4.0f, 4.0f);
+      float prev_l = fb_in[0], prev_r = fb_in[1];
+      if (nn > 0) { prev_l = clampf((float)buf[REV_IDX(nn - 1, 0)], -4.0f, 4.0f); prev_r = clampf((float)buf[REV_IDX(nn - 1, 1)], -4.0f, 4.0f); }
+      float line_in;
+      if (mode == 0) line_in = (ch == 0 ? left_input + prev_l * fb : right_input + prev_r * fb);       // stereo  :386-399
+      else line_in = (ch == 0 ? (left_input + right_input) * 0.5f + prev_r * fb : prev_l * fb);         // ping-pong :400-418
+      ((gdouble*)d.line[ch])[(wp0[ch] + (uint32_t)nn) & mask] = (double)line_in;
+      // dry/wet law and M/S width (delay.rs:424-452); the lane of channel `ch` writes its own output sample
+      const float out_l = left_input * dry_gain + clean_l * wet_gain;
+      const float out_r = right_input * dry_gain + clean_r * wet_gain;
+      const float mid = (out_l + out_r) * 0.5f;
+      const float side = (out_l - out_r) * 0.5f;
+      // both lanes of a frame read both inputs before either writes: the inputs were loaded above
+      const float res = ch == 0 ? mid + side * width : mid - side * width;
+      __builtin_amdgcn_wave_barrier();
+      s0[2 * nn + ch] = res;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      d.fb[0] = clampf((float)buf[REV_IDX(T - 1, 0)], -4.0f, 4.0f);
+      d.fb[1] = clampf((float)buf[REV_IDX(T - 1, 1)], -4.0f, 4.0f);
+      d.write_pos[0] = (wp0[0] + (uint32_t)T) & mask;
+      d.write_pos[1] = (wp0[1] + (uint32_t)T) & mask;
+    }
+    __syncthreads();
+    done += T;
+  }
+  if (tid == 0) f32_phase_advance(d.lfo.phase, d.lfo.phase_inc, frames);  // lfo.run() once per frame (delay.rs:343)
+  __syncthreads();
+  return true;
+}

@@ -175,3 +175,15 @@ def test_reverb_long_run_state():
     seeds = workloads.reverb_seeds(7)
     a, b, _, _ = run_pair(_capi.FX_REVERB, {"room": 0.3, "wet ": 0.6}, seeds, blocks=20, frames=1024, signal="sine")
     check(a, b)
+
+
+@pytest.mark.parametrize("mode,ftyp,dlay", [(0, 0, 2.0), (1, 1, 3.5), (0, 2, 1.4), (1, 0, 375.0)])
+def test_delay_time_parallel_path_short_delays_and_lfo_phase(mode, ftyp, dlay):
+    """The time-parallel DelayEffect path (LFO depths 0, nothing ramping): delays of a few ms force many chunks per block
+    (chunk <= floor(delay_samples) - 1), both routing modes and the three feedback-filter types. The LFO only advances its phase
+    there (closed-form f32 accumulation); switching the LFO depths on afterwards hands over to the serial path, which must
+    continue from exactly the phase the reference would have — any drift shows up in the modulated blocks."""
+    params = {"mode": mode, "dlay": dlay, "fdbk": 0.6, "ftyp": ftyp, "driv": 0.3, "lfor": 3.7}
+    updates = {4: [("lfdt", 0.02, False), ("lfdf", 0.3, False)]}
+    a, b, _, _ = run_pair(_capi.FX_DELAY, params, None, blocks=7, frames=1024, signal="noise", updates=updates)
+    check(a, b)
