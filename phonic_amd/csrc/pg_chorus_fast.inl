@@ -1,0 +1,159 @@
+// Time-parallel steady-state ChorusEffect (reference src/effect/chorus.rs:311-394) for one workgroup.
+//
+// With no parameter ramping the per-frame control values are block constants; the pre-filter (SVF) sees only the input; the
+// two LFOs only depend on their f32 phase accumulators; and the feedback runs through the delay line, which frame n reads
+// `2 + delay + (1 + lfo) * depth` frames behind the write head. Inside a chunk of T <= floor(2 + delay_in_samples) - 2 frames
+// every line read therefore hits pre-chunk data. Per piece (<= 1024 frames):
+//   0. LFO phases of every frame: the f32 accumulation  p += inc; if (p >= 1) p -= 1  is piecewise an exact arithmetic
+//      progression (per binade, see f32_phase_advance); one lane per LFO lists the pieces, all lanes fill the phase arrays
+//   1. SVF over the piece's input by the blocked scan
+//   2. per chunk: all (frame, channel) items evaluate the LFO (parabolic sine), read and interpolate their two taps; barrier;
+//      all items write  filtered + out * feedback  into the line and mix the output.
+// Same arithmetic as the serial loop up to the f64 rounding of the SVF scan.
+
+struct ChorusPiece { int k0; float p0; double du; };  // phases of frames k0 .. next piece: p0 + (k - k0) * du (exact in f64)
+constexpr int CHORUS_PIECE_CAP = 56;
+
+// One lane: lists the exact pieces of `steps` phase updates starting at p; frames beyond the piece capacity are written to
+// `ph` directly. Returns the number of pieces; *covered = frames described by pieces. Advances p.
+DEVO int chorus_phase_pieces(float& p, float d, int steps, ChorusPiece* rec, float* ph, int* covered) {
+  int n_rec = 0, k = 0;
+  while (k < steps && n_rec < CHORUS_PIECE_CAP) {
+    const uint32_t bits = __float_as_uint(p);
+    const int e = (int)((bits >> 23) & 0xff);
+    int m = 0;
+    double du = 0.0;
+    if (e > 24 && e < 0xff && p > 0.0f && d > 0.0f && p < 1.0f) {
+      const double u = __longlong_as_double((long long)((unsigned long long)(e - 127 - 23 + 1023) << 52));
+      const double D = (double)d / u;
+      const double Dr = rint(D);
+      if (D < 16777216.0 && Dr >= 1.0 && D - floor(D) != 0.5) {
+        const double top = __longlong_as_double((long long)((unsigned long long)(e - 127 + 1 + 1023) << 52));
+        const double q = floor(((top - u) - (double)p) / (Dr * u));
+        if (q >= 1.0) { m = q > (double)(steps - k) ? steps - k : (int)q; du = Dr * u; }
+      }
+    }
+    rec[n_rec].k0 = k; rec[n_rec].p0 = p; rec[n_rec].du = du;
+    ++n_rec;
+    if (m > 0) { p = (float)((double)p + (double)m * du); k += m; }   // frames k .. k+m-1 read p0 + j*du; the next piece starts at the value after m steps
+    else { p += d; if (p >= 1.0f) p -= 1.0f; k += 1; }                // the plain hardware step: this piece covers one frame
+  }
+  *covered = k;
+  for (; k < steps; ++k) { ph[k] = p; p += d; if (p >= 1.0f) p -= 1.0f; }
+  return n_rec;
+}
+
+DEVO bool chorus_fast_eligible(const PgFx& fx) {
+  const PgChorus& c = fx.u.chorus;
+  if (sm_need_ramp(c.rate) || sm_need_ramp(c.phase) || sm_need_ramp(c.depth) || sm_need_ramp(c.feedback) || sm_need_ramp(c.delay) ||
+      sm_need_ramp(c.wet) || sm_need_ramp(c.freq) || sm_need_ramp(c.res))
+    return false;
+  const float delay_in_samples = c.delay.target * (float)fx.sample_rate * 0.001f;
+  const float depth_in_samples = c.lfo_range * c.depth.target;
+  if (!(depth_in_samples >= 0.0f)) return false;
+  return floorf(2.0f + delay_in_samples) >= 66.0f && (2.0f + delay_in_samples + 2.0f * depth_in_samples) < (float)(c.mask - 8);
+}
+
+DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  if (!chorus_fast_eligible(fx)) return false;
+  PgChorus& c = fx.u.chorus;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int frames = n_samples / 2;
+  if (frames == 0) return true;
+  double* buf = (double*)fc.scratch;                       // [T][2] f64, skewed (REV_IDX)
+  char* lp = fc.scratch + REV_BUF_DOUBLES * 8;
+  double* xchg = (double*)lp;                 lp += 4 * 8;
+  PgBiquadCoef* lco = (PgBiquadCoef*)lp;      lp += sizeof(PgBiquadCoef);
+  ChorusPiece* rec = (ChorusPiece*)lp;        lp += 2 * CHORUS_PIECE_CAP * sizeof(ChorusPiece);
+  int* pctl = (int*)lp;                       lp += 16;   // [osc]: pieces, covered frames
+  float* ph = (float*)lp;                     lp += 2 * 1024 * 4;   // [osc][frame] LFO phase read by that frame
+  float* o32 = (float*)lp;                                         // [frame][2] interpolated line output
+  static_assert(REV_BUF_DOUBLES * 8 + 32 + sizeof(PgBiquadCoef) + 2 * CHORUS_PIECE_CAP * sizeof(ChorusPiece) + 16 + 2 * 1024 * 4 + 2 * 1024 * 4 <= FAST_SCRATCH_BYTES,
+                "chorus fast path: LDS arena too small");
+  const float srf = (float)fx.sample_rate;
+  const float delay_ms = c.delay.target, depth = c.depth.target;
+  const float feedback = clampf(c.feedback.target, -0.999f, 0.999f);
+  const float wet_amount = c.wet.target, dry_amount = 1.0f - c.wet.target;
+  const float delay_in_samples = delay_ms * srf * 0.001f;
+  const float depth_in_samples = c.lfo_range * depth;
+  const int t_max = (int)floorf(2.0f + delay_in_samples) - 4;  // margin: the parabolic sine may overshoot -1 by a hair
+  const uint32_t mask = c.mask;
+  __syncthreads();
+  if (tid == 0) {
+    PgBiquadCoef b;
+    b.a1 = c.coef.a1; b.a2 = c.coef.a2; b.a3 = c.coef.a3;
+    if (c.coef.type == 0) { b.m0 = 0.0; b.m1 = 0.0; b.m2 = 1.0; }
+    else if (c.coef.type == 2) { b.m0 = 0.0; b.m1 = 1.0; b.m2 = 0.0; }
+    else { b.m0 = 1.0; b.m1 = -c.coef.k; b.m2 = -1.0; }
+    *lco = b;
+  }
+  for (int p0 = 0; p0 < frames; p0 += 1024) {
+    const int P = frames - p0 < 1024 ? frames - p0 : 1024;
+    float* sp = sig + 2 * p0;
+    __syncthreads();
+    // 0. LFO phases (lfo.run() once per frame and oscillator, chorus.rs:353-354)
+    if (tid == 0 || tid == 64) {
+      const int o = tid >> 6;
+      pctl[2 * o] = chorus_phase_pieces(c.osc[o].phase, c.osc[o].phase_inc, P, rec + o * CHORUS_PIECE_CAP, ph + o * 1024, &pctl[2 * o + 1]);
+    }
+    // 1. pre-filter over the piece (svf.rs:211-222)
+    for (int s = tid; s < 2 * P; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sp[s];
+    __syncthreads();
+    for (int s = tid; s < 2 * P; s += nt) {
+      const int k = s >> 1, o = s & 1;
+      if (k < pctl[2 * o + 1]) {
+        const ChorusPiece* r = rec + o * CHORUS_PIECE_CAP;
+        int i = 0;
+        const int nr = pctl[2 * o];
+        while (i + 1 < nr && r[i + 1].k0 <= k) ++i;
+        ph[o * 1024 + k] = (float)((double)r[i].p0 + (double)(k - r[i].k0) * r[i].du);
+      }
+    }
+    rev_biquad_scan(*lco, c.flt, buf, P, xchg);
+    __syncthreads();
+    // 2. chunks
+    int done = 0;
+    while (done < P) {
+      int T = P - done;
+      if (T > t_max) T = t_max;
+      const uint32_t wp0[2] = {c.write_pos[0], c.write_pos[1]};
+      __syncthreads();
+      for (int s = tid; s < 2 * T; s += nt) {
+        const int nn = done + (s >> 1), ch = s & 1;
+        PgLfo l; l.phase = ph[ch * 1024 + nn]; l.phase_inc = 0.0f; l.waveform = c.osc[ch].waveform;
+        const float lfo = lfo_value(l);
+        const float delay_pos = 2.0f + delay_in_samples + (1.0f + lfo) * depth_in_samples;
+        const gdouble* line = (const gdouble*)c.line[ch];
+        const uint32_t wp = (wp0[ch] + (uint32_t)(s >> 1)) & mask;
+        const double read_pos = (double)wp - (double)delay_pos;
+        const double read_pos_floor = floor(read_pos);
+        const double fraction = read_pos - read_pos_floor;
+        const long long index1 = (long long)read_pos_floor;
+        const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+        const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+        const double v1 = line[i1], v2 = line[i2];
+        const float out = (float)(v1 + (v2 - v1) * fraction);
+        o32[2 * nn + ch] = out;
+        const int bi = REV_IDX(nn, ch);
+        buf[bi] = (double)(float)buf[bi] + (double)out * (double)feedback;   // what this frame writes into the line
+      }
+      __syncthreads();
+      for (int s = tid; s < 2 * T; s += nt) {
+        const int nn = done + (s >> 1), ch = s & 1;
+        ((gdouble*)c.line[ch])[(wp0[ch] + (uint32_t)(s >> 1)) & mask] = buf[REV_IDX(nn, ch)];
+        sp[2 * nn + ch] = sp[2 * nn + ch] * dry_amount + o32[2 * nn + ch] * wet_amount;
+      }
+      __syncthreads();
+      if (tid == 0) { c.write_pos[0] = (wp0[0] + (uint32_t)T) & mask; c.write_pos[1] = (wp0[1] + (uint32_t)T) & mask; }
+      __syncthreads();
+      done += T;
+    }
+  }
+  if (tid == 0) {  // block-end phase bookkeeping (chorus.rs:388-393)
+    const double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;
+    c.current_phase += (double)n_samples / 2.0 * phase_inc;
+    while (c.current_phase >= 2.0 * F64_PI) c.current_phase -= 2.0 * F64_PI;
+  }
+  __syncthreads();
+  return true;
+}

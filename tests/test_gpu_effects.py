@@ -187,3 +187,17 @@ def test_delay_time_parallel_path_short_delays_and_lfo_phase(mode, ftyp, dlay):
     updates = {4: [("lfdt", 0.02, False), ("lfdf", 0.3, False)]}
     a, b, _, _ = run_pair(_capi.FX_DELAY, params, None, blocks=7, frames=1024, signal="noise", updates=updates)
     check(a, b)
+
+
+@pytest.mark.parametrize("params", [
+    {"rate": 0.7, "dpth": 0.5, "fdbk": 0.5, "dlay": 12.0},
+    {"rate": 9.0, "dpth": 1.0, "fdbk": -0.8, "dlay": 3.0, "fltt": 1, "fltf": 400.0, "phas": 2.0},
+    {"rate": 0.05, "dpth": 0.2, "fdbk": 0.9, "dlay": 40.0, "wet_": 1.0},
+])
+def test_chorus_time_parallel_path(params):
+    """The time-parallel ChorusEffect path over 40 blocks: LFO phase arrays from the exact piecewise closed form (many wraps and
+    binade crossings at 9 Hz), chunking by the shortest line lag (3 ms -> chunks of ~140 frames), negative feedback, the
+    high-pass pre-filter; then a rate change (serial path while it ramps) that must continue from the exact LFO state."""
+    updates = {30: [("rate", 2.0, False)]}
+    a, b, _, _ = run_pair(_capi.FX_CHORUS, params, None, blocks=40, frames=1024, signal="noise", updates=updates)
+    check(a, b)
