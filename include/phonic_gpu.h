@@ -209,9 +209,9 @@ double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
 const char* pg_graph_dominant_kernel(pg_graph* g);
 /* 0 = exact serial filters, 1 = time-parallel (blocked) evaluation of linear filters (default) */
 int pg_graph_set_fast_math(pg_graph* g, int level);
-/* How sub-mixers whose chain is [Gain|Panning]* -> Reverb are rendered: 1 (default) = staged kernel (three separately
- * register-allocated stage functions in one launch, four workgroups per CU), 2 = one launch per stage (profiling), 0 = the
- * fused fast kernel. Same stage functions in every mode: results agree up to f64 rounding. */
+/* How sub-mixers whose chain ends in a Reverb behind Gain / Panning (and, in mode 1, Filter / Eq5 / Delay / Distortion) effects
+ * are rendered: 1 (default) = staged kernel (stage functions over a per-stage LDS plan in one launch, four workgroups per CU),
+ * 2 = one launch per stage (profiling; Gain / Panning chains only), 0 = the fused fast kernel. Same stage functions in every mode: results agree up to f64 rounding. */
 int pg_graph_set_staged(pg_graph* g, int mode);
 
 #ifdef __cplusplus

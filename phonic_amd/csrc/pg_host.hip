@@ -26,7 +26,7 @@ using namespace pgh;
 
 size_t pg_unit_lds_bytes(uint32_t n_frames);
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream);
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch);
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
                          const int32_t* order, int* audible_out, hipStream_t stream);
 
@@ -408,7 +408,8 @@ struct pg_graph {
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
-  int n_staged = 0;        // graph units eligible for the staged pipeline
+  int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
+  int n_staged_wide = 0;   // ... of level 2 (leading effects beyond Gain / Panning)
   int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceVec<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
@@ -507,8 +508,13 @@ static int rebuild_topology(pg_graph* g) {
     // staged pipeline: a sub-mixer whose chain is [Gain (no DC filter) | Panning]* -> Reverb
     u.staged = 0;
     if (m != 0 && !u.static_defer && !mx.fx.empty() && g->fx[mx.fx.back()]->kind == PG_FX_REVERB) {
-      u.staged = 1;
-      for (size_t i = 0; i + 1 < mx.fx.size(); ++i) { const int k = g->fx[mx.fx[i]]->kind; if (!(k == PG_FX_GAIN || k == PG_FX_PANNING)) u.staged = 0; }
+      u.staged = 1;  // 1: leading Gain / Panning only (lean staged kernel); 2: also Filter, Eq5, Delay, Distortion (wide staged kernel)
+      for (size_t i = 0; i + 1 < mx.fx.size(); ++i) {
+        const int k = g->fx[mx.fx[i]]->kind;
+        if (k == PG_FX_GAIN || k == PG_FX_PANNING) continue;
+        if (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_DISTORTION) { if (u.staged) u.staged = 2; }
+        else u.staged = 0;
+      }
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
@@ -536,8 +542,11 @@ static int rebuild_topology(pg_graph* g) {
     int rc0;
     if ((rc0 = g->d_slot_info.upload(info))) return rc0;
   }
-  g->n_staged = 0; g->n_static_defer = 0;
-  for (int slot : g->order) { g->n_staged += topo[slot].staged ? 1 : 0; g->n_static_defer += topo[slot].static_defer ? 1 : 0; }
+  g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
+  for (int slot : g->order) {
+    g->n_staged += topo[slot].staged ? 1 : 0; g->n_staged_wide += topo[slot].staged == 2 ? 1 : 0;
+    g->n_static_defer += topo[slot].static_defer ? 1 : 0;
+  }
   g->h_units = topo;
   int rc;
   if ((rc = g->d_voice_index.upload(vidx))) return rc;
@@ -844,9 +853,13 @@ int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; retur
 const char* pg_graph_dominant_kernel(pg_graph* g) {
   if (g->topo_dirty) (void)rebuild_topology(g);
   if (!g->fast || g->n_static_defer * 2 > g->n_graph_units) return "pg_unit_kernel";
-  if (g->staged_mode && g->n_staged > 0) {
-    if (g->n_staged < g->n_graph_units) return g->staged_mode == 1 ? "pg_stage_fused_kernel + pg_unit_kernel_fast" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel + pg_unit_kernel_fast";
-    return g->staged_mode == 1 ? "pg_stage_fused_kernel" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel";
+  const int n_lean = g->n_staged - g->n_staged_wide;
+  const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
+  if (g->staged_mode && n_handled > 0) {
+    if (g->staged_mode == 2) return n_handled < g->n_graph_units ? "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel + pg_unit_kernel_fast" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel";
+    if (n_handled < g->n_graph_units) return "pg_stage_fused_kernel + pg_unit_kernel_fast";
+    if (n_lean > 0 && g->n_staged_wide > 0) return "pg_stage_fused_kernel + pg_stage_fused_wide_kernel";
+    return g->n_staged_wide > 0 ? "pg_stage_fused_wide_kernel" : "pg_stage_fused_kernel";
   }
   return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
 }
@@ -912,12 +925,15 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   if (timed && !time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
   if (g->fast) {
     L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
-    const bool staged = g->staged_mode && g->n_staged > 0 && g->d_stage && n <= 1024;
-    if (staged) {  // [Gain|Panning]* -> Reverb units: three stage launches, each at its own occupancy
-      L.stage_buf = g->d_stage; L.staged_on = 1;
-      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0));
+    // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
+    const int n_lean = g->n_staged - g->n_staged_wide;
+    const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
+    const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
+    if (staged) {
+      L.stage_buf = g->d_stage; L.staged_on = g->staged_mode == 1 ? 2 : 1;
+      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, n_lean > 0, g->staged_mode == 1 && g->n_staged_wide > 0));
     }
-    if (!staged || g->n_staged < g->n_graph_units) HIP_TRY(pg_launch_units(L, stream));
+    if (!staged || n_handled < g->n_graph_units) HIP_TRY(pg_launch_units(L, stream));
     if (timed && !time_generic) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
     if (timed && time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
     L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit

@@ -304,7 +304,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
   if (FAST_ONLY) {
-    if (L.staged_on && unit.staged) return;  // rendered by the stage kernels of this round
+    if (unit.staged && unit.staged <= L.staged_on) return;  // rendered by the stage kernels of this round
     if (tid == 0) {
       // Ramps only start with a parameter command, and commands are always rendered (and the ramp state re-evaluated at the
       // end of the block) by the generic kernel: the unit record alone decides, no walk over the effect states.
@@ -462,6 +462,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
 #define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
 #define PG_KMASK_ALL 0x3ff
 #define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
+// leading effects of the wide staged kernel: every kind with a time-parallel path whose LDS needs fit stage 1's arena (no Chorus)
+#define PG_KMASK_LEADING ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 9))
 __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x); }
 __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) { pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x); }
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
@@ -578,8 +580,9 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&g1)[i];
       __syncthreads();
       bool is_active;
-      if (lfx->standalone) { fx_process_wg<true, PG_KMASK_GAINPAN>(*lfx, sig, N * 2, fc, L.fast); is_active = true; }
-      else is_active = fx_processor_process<true, PG_KMASK_GAINPAN>(*lfx, sig, N * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+      constexpr int KM = TAG == 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
+      if (lfx->standalone) { fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast); is_active = true; }
+      else is_active = fx_processor_process<true, KM>(*lfx, sig, N * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
       if (is_active) { input_bypassed = false; all_bypassed = false; }
       __syncthreads();
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&g1)[i] = ((const uint32_t*)lfx)[i];
@@ -703,9 +706,12 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
 #ifndef PG_STAGE_WAVES
 #define PG_STAGE_WAVES 4
 #endif
+// unit.staged: 0 no, 1 = leading effects are Gain / Panning only, 2 = any kind of PG_KMASK_LEADING. A launch renders the levels
+// up to L.staged_on; LEVEL selects which of them this kernel takes.
+template <int LEVEL>
 __device__ __forceinline__ bool stage_unit_staged(const PgLaunch& L, int slot) {
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
-  return L.units[u].staged != 0;
+  return L.units[u].staged == LEVEL;
 }
 __device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, bool& deferred) {
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
@@ -713,16 +719,16 @@ __device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, boo
   return L.units[u].stage_flags;
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage1_kernel(PgLaunch L) {
-  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
   (void)stage1_run<1, false>(L, blockIdx.x);
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage2_kernel(PgLaunch L) {
-  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
   bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
   if (!deferred) stage2_run<1, false>(L, blockIdx.x, flags);
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch L) {
-  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged(L, blockIdx.x)) return;
+  if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
   bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
   if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags);
 }
@@ -750,7 +756,7 @@ __device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int fla
 #endif
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units) return;
-  if (!stage_unit_staged(L, blockIdx.x)) return;
+  if (!stage_unit_staged<1>(L, blockIdx.x)) return;
   __shared__ PgLaunch sL;
   for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
   __syncthreads();
@@ -771,6 +777,24 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
   PG_SLOT_STAMP(2);
   stage3_call(&sL, slot, flags);
   PG_SLOT_STAMP(3);
+}
+
+// The same single launch for reverb units whose leading effects go beyond Gain / Panning (Filter, Eq5, Delay, Distortion:
+// C5's per-voice Filter -> Eq5 -> Delay -> Reverb). A kernel of its own so that the lean one keeps its register allocation.
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kernel(PgLaunch L) {
+  if ((int)blockIdx.x >= L.n_units) return;
+  if (!stage_unit_staged<2>(L, blockIdx.x)) return;
+  __shared__ PgLaunch sL;
+  for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
+  __syncthreads();
+  const int slot = blockIdx.x;
+  if (!stage1_run<3, true>(sL, slot)) return;
+  __syncthreads();
+  const int u = sL.unit_order ? sL.unit_order[slot] : sL.unit_base + slot;
+  const int flags = sL.units[u].stage_flags;
+  stage2_run<3, true>(sL, slot, flags);
+  __syncthreads();
+  stage3_call(&sL, slot, flags);
 }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
@@ -830,7 +854,7 @@ size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
 }
 // The staged pipeline of one round (units flagged `staged`): single_launch = pg_stage_fused_kernel, else three launches
 // (L.stage_buf must then hold n_units rows).
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch) {
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide) {
   if (L.n_units <= 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set) {
@@ -839,10 +863,12 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
     if ((e = hipFuncSetAttribute((const void*)pg_stage2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)pg_stage3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
     attr_set = true;
   }
   if (single_launch) {
-    hipLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
+    if (lean) hipLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
+    if (wide) hipLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
   } else {
     hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
     hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);

@@ -325,3 +325,22 @@ def test_resampler_schedule_bit_exact_over_many_blocks(rate, block, n_blocks):
     a, b = both(build, n_blocks, block, max_frames=1024)
     assert np.array_equal(a, b)
     assert np.abs(a).max() > 1e-3
+
+
+def test_wide_staged_kernel_filter_eq5_delay_reverb_chain():
+    """Reverb-terminated sub-mixers whose leading effects go beyond Gain / Panning (C5's Filter -> Eq5 -> Delay -> Reverb, plus a
+    Distortion -> Reverb one) are rendered by pg_stage_fused_wide_kernel; pg_graph_set_staged(0) keeps them in the fused wide
+    kernel. Same stage functions and effect paths: the two agree to f64 rounding, and both match the oracle."""
+    def build(g):
+        workloads.build_c5(g, 3, 0, 3, seconds=0.2)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_DISTORTION, params={"type": 0, "driv": 2.0})
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.5})
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.35}, reverb_seeds=workloads.reverb_seeds(42))
+        g.add_voice(m, workloads.tone_buffer(7, 44100, 0.2), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return {}
+    staged, _per_stage, fused, ref = _render_modes(build, 8, 1024)
+    assert float(np.abs(staged - fused).max()) <= 2e-6
+    compare(staged, ref)
+    compare(fused, ref)
+    assert np.abs(staged).max() > 1e-3
