@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
+    ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th step (the event pair costs ~8 us per step)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
@@ -143,6 +144,7 @@ def main():
     if args.exact:
         g.set_fast_math(0)
     g.set_staged(args.staged)
+    g.set_timing_period(args.time_every)
     bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
     if world > 1 and bus_on_root:
         g.set_defer_bus(True)
@@ -249,6 +251,7 @@ def main():
                 "kernel": g.dominant_kernel(),
                 "kernel_ms": kernel_ms,
                 "launches": launches,
+                "timed_every": args.time_every,
                 "bytes_per_voice_frame": B_ALG[name],
             },
         }

@@ -205,6 +205,9 @@ int pg_graph_is_voice_playing(pg_graph* g, int voice_id);
 /* Average device time (ms) of the dominant kernel launch(es) (see pg_graph_dominant_kernel) over the launches
  * since the last call with reset != 0, measured with hipEvents on the graph's stream; launches = count. */
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
+/* The hipEvent pair behind pg_graph_kernel_ms costs ~8 us of stream time per round: time every n-th round only (default 1 = every
+ * round, 0 = never). pg_graph_kernel_ms then averages over the timed rounds and reports their count. */
+int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds);
 /* Name(s) of the kernel launch(es) the pg_graph_kernel_ms events bracket for this graph (static string). */
 const char* pg_graph_dominant_kernel(pg_graph* g);
 /* 0 = exact serial filters, 1 = time-parallel (blocked) evaluation of linear filters (default) */

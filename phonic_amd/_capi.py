@@ -208,6 +208,8 @@ def load():
     lib.pg_graph_kernel_ms.argtypes = [vp, C.c_int, P(C.c_uint64)]
     lib.pg_graph_set_fast_math.restype = C.c_int
     lib.pg_graph_set_fast_math.argtypes = [vp, C.c_int]
+    lib.pg_graph_set_timing_period.restype = C.c_int
+    lib.pg_graph_set_timing_period.argtypes = [vp, C.c_int]
     lib.pg_graph_dominant_kernel.restype = C.c_char_p
     lib.pg_graph_dominant_kernel.argtypes = [vp]
     lib.pg_graph_set_staged.restype = C.c_int

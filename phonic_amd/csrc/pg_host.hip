@@ -25,8 +25,8 @@ using namespace pgd;
 using namespace pgh;
 
 size_t pg_unit_lds_bytes(uint32_t n_frames);
-hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream);
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide);
+hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
                          const int32_t* order, int* audible_out, hipStream_t stream);
 
@@ -407,6 +407,7 @@ struct pg_graph {
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
+  int timing_period = 1;   // time every n-th round with a hipEvent pair (0: never)
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
   int n_staged_wide = 0;   // ... of level 2 (leading effects beyond Gain / Panning)
@@ -863,6 +864,7 @@ const char* pg_graph_dominant_kernel(pg_graph* g) {
   }
   return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
 }
+int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) { g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds; return PG_OK; }
 int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
 int pg_graph_synchronize(pg_graph* g) {
@@ -912,39 +914,46 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   if (g->d_defer) { L.defer_count = g->d_defer + (g->launch_counter & 1); L.defer_reset = g->d_defer + ((g->launch_counter & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;
-  bool timed = g->ev_used < 8192 && L.n_units > 0;
+  // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
+  // average can time every n-th round (pg_graph_set_timing_period)
+  bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < 8192 && L.n_units > 0;
   if (timed && g->ev_used >= g->ev_pool.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     g->ev_pool.emplace_back(a, b);
   }
-  // The event pair brackets the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most
-  // units hold an effect without a time-parallel path — the generic kernel.
+  // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
+  // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
+  // dispatch itself (hipExtLaunchKernel: no marker packets in the stream); several launches are bracketed by event records.
   const bool time_generic = g->fast && g->n_static_defer * 2 > g->n_graph_units;
-  if (timed && !time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
+  hipEvent_t e0 = timed ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed ? g->ev_pool[g->ev_used].second : nullptr;
   if (g->fast) {
     L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
     // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
     const int n_lean = g->n_staged - g->n_staged_wide;
     const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
     const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
+    const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && g->n_staged_wide > 0;
+    const bool fused = !staged || n_handled < g->n_graph_units;
+    const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
+    const bool ride = timed && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
+    const bool bracket = timed && !time_generic && n_launches > 1;
+    if (bracket) HIP_TRY(hipEventRecord(e0, stream));
     if (staged) {
       L.stage_buf = g->d_stage; L.staged_on = g->staged_mode == 1 ? 2 : 1;
-      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, n_lean > 0, g->staged_mode == 1 && g->n_staged_wide > 0));
+      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
     }
-    if (!staged || n_handled < g->n_graph_units) HIP_TRY(pg_launch_units(L, stream));
-    if (timed && !time_generic) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
-    if (timed && time_generic) HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].first, stream));
+    if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
+    if (bracket) HIP_TRY(hipEventRecord(e1, stream));
     L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit
-    HIP_TRY(pg_launch_units(L, stream));
-    if (timed && time_generic) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+    HIP_TRY(pg_launch_units(L, stream, timed && time_generic ? e0 : nullptr, timed && time_generic ? e1 : nullptr));
   } else {
     L.mode = 0;
     if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
-    HIP_TRY(pg_launch_units(L, stream));
-    if (timed) { HIP_TRY(hipEventRecord(g->ev_pool[g->ev_used].second, stream)); g->ev_used++; }
+    HIP_TRY(pg_launch_units(L, stream, e0, e1));
   }
+  if (timed) g->ev_used++;
   L.mode = 0;
   HIP_TRY(pg_launch_mix(g->d_unit_out, g->stride, g->n_graph_units, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d, g->d_audible, stream));
   if (run_bus && !g->mixers[0].fx.empty()) {

@@ -11,6 +11,7 @@
 // Written for CDNA4 only: 64-wide wavefronts, LDS-resident signal, f64 vector ALU for the filter/delay
 // arithmetic the reference does in f64. No MFMA: nothing on this path is a dense contraction.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "pg_dev.h"
 #include "pg_dsp_dev.h"
@@ -854,7 +855,7 @@ size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
 }
 // The staged pipeline of one round (units flagged `staged`): single_launch = pg_stage_fused_kernel, else three launches
 // (L.stage_buf must then hold n_units rows).
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide) {
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set) {
@@ -867,8 +868,10 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
     attr_set = true;
   }
   if (single_launch) {
-    if (lean) hipLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
-    if (wide) hipLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(0, L.n_frames), stream, L);
+    // ev0/ev1 (only passed when exactly one of the two launches happens): start / stop timestamps taken from the dispatch itself —
+    // no marker packets in the stream, which cost ~7 us per round with hipEventRecord
+    if (lean) hipExtLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, ev0, ev1, 0, L);
+    if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, lean ? nullptr : ev0, lean ? nullptr : ev1, 0, L);
   } else {
     hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
     hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);
@@ -876,7 +879,7 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
   }
   return hipGetLastError();
 }
-hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
+hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   size_t lds = pg_unit_lds_bytes(L.n_frames);
   static bool attr_set = false;
@@ -889,9 +892,9 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (L.mode == 1 && L.wide) hipLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), lds, stream, L);
-  else if (L.mode == 1) hipLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), lds, stream, L);
-  else hipLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), lds, stream, L);
+  if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
+  else if (L.mode == 1) hipExtLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
+  else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   return hipGetLastError();
 }
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,

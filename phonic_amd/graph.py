@@ -40,6 +40,10 @@ class Graph(GraphHandle):
         ms = self._lib.pg_graph_kernel_ms(self._h, 1 if reset else 0, C.byref(n))
         return ms, n.value
 
+    def set_timing_period(self, every_n_rounds):
+        """Time every n-th round with a hipEvent pair (the pair costs ~8 us of stream time); 0 = never."""
+        self._check(self._lib.pg_graph_set_timing_period(self._h, int(every_n_rounds)))
+
     def dominant_kernel(self):
         """Name(s) of the kernel launch(es) that `kernel_ms` brackets for this graph."""
         return self._lib.pg_graph_dominant_kernel(self._h).decode()
