@@ -268,6 +268,8 @@ struct PgLaunch {
   int32_t* defer_count;   // fast kernels append the launch slots they defer: count of this round ...
   int32_t* defer_list;    // ... and the slots; the generic kernel (mode 2) walks the list
   int32_t* defer_reset;   // the other round's counter, zeroed by the generic kernel for the next round
+  unsigned long long* host_feedback;  // pinned host word: the generic kernel reports (round << 32 | units it found deferred)
+  uint32_t round;         // launch counter of this round
   int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
 };
 constexpr int PG_STAGE_BUF_DOUBLES = 2 * 1024 + 128 + 8;

@@ -446,6 +446,9 @@ struct pg_graph {
   float* d_bus = nullptr;               // [2*max_frames + 4]
   int* d_audible = nullptr;
   float* h_pinned = nullptr;
+  unsigned long long* h_feedback = nullptr;   // pinned, device-visible: (round << 32 | deferred units) written by the generic kernel
+  unsigned long long* d_feedback = nullptr;   // its device address
+  uint64_t last_change_round = 0;             // last round that may have left a unit out of steady state (topology, commands, mode switches)
   uint32_t stride = 0;
   unsigned long long* d_diag = nullptr;  // diagnostic builds
   // timing of the dominant kernel
@@ -587,6 +590,7 @@ static int rebuild_topology(pg_graph* g) {
     g->partial_rows = prow * 2;
   }
   g->topo_dirty = false;
+  g->last_change_round = g->launch_counter;  // the patch kernel marked every unit: the generic kernel must look at them again
   return PG_OK;
 }
 
@@ -629,6 +633,10 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     return nullptr;
   }
   (void)hipMemset(g->d_audible, 0, 16);
+  if (hipHostMalloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
+    *g->h_feedback = ~0ull;  // nothing reported yet
+    if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
+  }
   g->mixers.emplace_back();
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
   if (g->mixers[0].unit_slot < 0) return nullptr;
@@ -650,6 +658,7 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->d_bus) (void)hipFree(g->d_bus);
   if (g->d_audible) (void)hipFree(g->d_audible);
   if (g->h_pinned) (void)hipHostFree(g->h_pinned);
+  if (g->h_feedback) (void)hipHostFree(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(g->stream);
   delete g;
@@ -850,7 +859,7 @@ int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic 
   return PG_OK;
 }
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
-int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; return PG_OK; }
+int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; g->last_change_round = g->launch_counter; return PG_OK; }
 const char* pg_graph_dominant_kernel(pg_graph* g) {
   if (g->topo_dirty) (void)rebuild_topology(g);
   if (!g->fast || g->n_static_defer * 2 > g->n_graph_units) return "pg_unit_kernel";
@@ -865,7 +874,7 @@ const char* pg_graph_dominant_kernel(pg_graph* g) {
   return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
 }
 int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) { g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds; return PG_OK; }
-int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; return PG_OK; }
+int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; g->last_change_round = g->launch_counter; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
 int pg_graph_synchronize(pg_graph* g) {
   (void)hipSetDevice(g->device);
@@ -911,6 +920,16 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
   L.diag = g->d_diag;
   L.slot_info = g->d_slot_info.d;
+  const uint64_t round = g->launch_counter;
+  if (!cmds.empty()) g->last_change_round = round;
+  L.round = (uint32_t)round; L.host_feedback = g->d_feedback;
+  // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
+  // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.
+  bool generic_idle = false;
+  if (g->fast && g->n_static_defer == 0 && cmds.empty() && g->d_feedback) {
+    const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
+    generic_idle = fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
+  }
   if (g->d_defer) { L.defer_count = g->d_defer + (g->launch_counter & 1); L.defer_reset = g->d_defer + ((g->launch_counter & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;
@@ -946,8 +965,8 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     }
     if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
     if (bracket) HIP_TRY(hipEventRecord(e1, stream));
-    L.mode = 2;  // ... to the generic kernel, which exits immediately for every other unit
-    HIP_TRY(pg_launch_units(L, stream, timed && time_generic ? e0 : nullptr, timed && time_generic ? e1 : nullptr));
+    L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
+    if (!generic_idle) HIP_TRY(pg_launch_units(L, stream, timed && time_generic ? e0 : nullptr, timed && time_generic ? e1 : nullptr));
   } else {
     L.mode = 0;
     if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean

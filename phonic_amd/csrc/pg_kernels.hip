@@ -472,7 +472,11 @@ __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(P
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
     const int n = *L.defer_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *L.defer_reset = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *L.defer_reset = 0;
+      // tell the host how many units this round deferred: after a round with none (and no change since) it skips this launch
+      if (L.host_feedback) { *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n; __threadfence_system(); }
+    }
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
       pg_unit_body<false, PG_KMASK_ALL>(L, L.defer_list[i]);
       __syncthreads();
