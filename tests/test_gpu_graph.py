@@ -344,3 +344,29 @@ def test_wide_staged_kernel_filter_eq5_delay_reverb_chain():
     compare(staged, ref)
     compare(fused, ref)
     assert np.abs(staged).max() > 1e-3
+
+
+def test_staged_kernel_ragged_block_sizes():
+    """Blocks of 1, 7, 63, 64, 65, 333, 1000 and 1024 frames through reverb sub-mixers (staged kernel: partial scan segments,
+    partial sub-chunks, chunk cuts) and a Delay -> Reverb chain (wide staged kernel), against the oracle; then 2048-frame blocks,
+    which the staged kernel does not take (> 1024 frames): the fused kernel renders those."""
+    from phonic_amd.graph import Graph
+
+    sizes = [1, 7, 63, 64, 65, 333, 1000, 1024, 129, 1024, 2, 511] * 2 + [2048, 2048]
+    outs = []
+    for mode in ("gpu", "oracle"):
+        g = oracle.OracleGraph(SR, 2, 2048) if mode == "oracle" else Graph(SR, 2, 2048, 0)
+        workloads.build_headline(g, 3, seconds=0.2)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_DELAY, params={"dlay": 5.0, "fdbk": 0.5})
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.2}, reverb_seeds=workloads.reverb_seeds(8))
+        g.add_voice(m, workloads.tone_buffer(3, 44100, 0.15), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        chunks, pos = [], 0
+        for n in sizes:
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+    compare(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-3
