@@ -745,17 +745,17 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch
 #define PG_STAGE_OUTLINE 4
 #endif
 #if PG_STAGE_OUTLINE & 1
-__device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
+static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
 #else
 __device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
 #endif
 #if PG_STAGE_OUTLINE & 2
-__device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
+static __device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
 #else
 __device__ __forceinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
 #endif
 #if PG_STAGE_OUTLINE & 4
-__device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
+static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
 #else
 __device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
 #endif
