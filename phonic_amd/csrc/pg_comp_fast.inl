@@ -1,0 +1,118 @@
+// Time-parallel CompressorEffect / limiter (reference src/effect/compressor.rs:230-294) for one workgroup, makeup gain not ramping.
+//
+// The serial loop pays one dependent HBM read per frame (the look-ahead line): 1.2 ms per 1024-frame block on one lane. Here
+//   * the delayed frame is  line[wp + n - delay]  for n < delay and the block's own input for n >= delay: read in parallel;
+//   * the look-ahead peak (LookupDelayLine, delay.rs:206-265) is by construction the maximum of the frame peaks over the last
+//     `delay_frames` frames (a new peak >= the tracked one replaces it; when the tracked one leaves the window the window is
+//     rescanned), i.e. a sliding-window maximum: log-step doubling over [history | block] in LDS, exact (max is order-free);
+//   * dB conversion, knee / slope law, makeup and the multiplication are element-wise;
+//   * only the envelope follower (attack / release switch on the sign of input - envelope, envelope.rs:51-60) stays a serial
+//     recurrence: one lane walks the block in LDS, no memory access.
+// The tracked peak's position is left on the NEWEST frame holding the maximum; any frame holding it keeps the reference's expiry
+// logic exact (the value sequence is the window maximum either way).
+
+DEVO float comp_gain_reduction_db(const PgComp& c, float envelope) {  // compressor.rs:262-279
+  const float t = c.threshold, w = c.knee;
+  const float slope = (c.ratio >= 20.0f) ? 1.0f : 1.0f - 1.0f / c.ratio;
+  if (w > 0.0f && envelope > (t - w / 2.0f) && envelope < (t + w / 2.0f)) {
+    const float knee_lower = t - w / 2.0f;
+    const float x = (envelope - knee_lower) / w;
+    return x * x * slope * w / 2.0f;
+  }
+  if (envelope > (t + w / 2.0f)) return (envelope - t) * slope;
+  return 0.0f;
+}
+
+constexpr int COMP_FAST_CAP = 4096;  // history + block frames held in LDS
+
+DEVO bool comp_fast_eligible(const PgFx& fx) {
+  const PgComp& c = fx.u.comp;
+  return !sm_need_ramp(c.makeup) && c.delay_frames >= 1 && c.delay_frames <= c.mask && (int)c.delay_frames - 1 + 1024 <= COMP_FAST_CAP;
+}
+
+DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  if (!comp_fast_eligible(fx)) return false;
+  PgComp& c = fx.u.comp;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float* a0 = (float*)fc.scratch;              // [COMP_FAST_CAP] frame peaks: history (W - 1 frames) then the block
+  float* a1 = a0 + COMP_FAST_CAP;              // ping-pong partner of the doubling; later the copy of the block's input
+  float* env = a1 + COMP_FAST_CAP;             // [1024] input dB, then envelope
+  int* red = (int*)(env + 1024);               // [8] reductions
+  static_assert((2 * COMP_FAST_CAP + 1024 + 8) * 4 <= FAST_SCRATCH_BYTES, "compressor fast path: LDS arena too small");
+  const int W = (int)c.delay_frames, H = W - 1;
+  const uint32_t mask = c.mask;
+  gdouble* line = (gdouble*)c.line;
+  const bool limiter = c.ratio >= 20.0f;
+  const float makeup = c.makeup.target;
+  const int total = n_samples / 2;
+  for (int f0 = 0; f0 < total; f0 += 1024) {   // pieces of <= 1024 frames
+    const int N = total - f0 < 1024 ? total - f0 : 1024, TOT = H + N;
+    float* sp = sig + 2 * f0;
+    const uint32_t wp0 = c.write_pos;
+    __syncthreads();
+    // 1. frame peaks (delay.rs:245-247): history from the line, the block from the signal
+    for (int i = tid; i < TOT; i += nt) {
+      float p;
+      if (i < H) {
+        const uint32_t fi = (wp0 + (uint32_t)(i - H)) & mask;
+        p = (float)fmax(fmax(0.0, fabs(line[fi * 2])), fabs(line[fi * 2 + 1]));   // the stored samples are f32 values: exact
+      } else {
+        const int n = i - H;
+        p = fmaxf(fmaxf(0.0f, fabsf(sp[2 * n])), fabsf(sp[2 * n + 1]));
+      }
+      a0[i] = p;
+    }
+    if (tid == 0) { red[0] = 0; red[1] = -0x7fffffff; }
+    __syncthreads();
+    // 2. tracked peak after the piece: maximum of the last window and its newest holder (peaks are >= 0: their bits order like ints)
+    for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0) atomicMax(&red[0], (int)__float_as_uint(a0[i]));
+    __syncthreads();
+    { const float m = __uint_as_float((uint32_t)red[0]); for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0 && a0[i] == m) atomicMax(&red[1], i - H); }
+    // 3. input level in dB (compressor.rs:241-255)
+    if (limiter) {
+      float* src = a0; float* dst = a1;
+      int span = 1;
+      while (span * 2 <= W) {  // after level k: src[i] = max over the 2^k entries ending at i
+        __syncthreads();
+        for (int i = tid; i < TOT; i += nt) dst[i] = i >= span ? fmaxf(src[i], src[i - span]) : src[i];
+        float* t = src; src = dst; dst = t;
+        span *= 2;
+      }
+      __syncthreads();
+      for (int n = tid; n < N; n += nt) {   // window [i - W + 1, i] = [i - span + 1, i] U [i - W + 1, i - W + span]
+        const int i = n + H;
+        const float m = fmaxf(src[i], src[i - W + span]);
+        env[n] = (m > 1e-6f) ? 20.0f * log10f(m) : -120.0f;
+      }
+    } else {
+      __syncthreads();
+      for (int n = tid; n < N; n += nt) { const float fp = a0[n + H]; env[n] = (fp > 1e-6f) ? 20.0f * log10f(fp) : -120.0f; }
+    }
+    __syncthreads();
+    // 4. envelope follower: the one serial recurrence; meanwhile the other lanes stage the input (the output pass overwrites it)
+    if (tid == 0) {
+      float cur = c.env_current;
+      const float att = c.env_attack, rel = c.env_release;
+      for (int n = 0; n < N; ++n) env[n] = env_run(cur, att, rel, env[n]);
+      c.env_current = cur;
+      c.peak_value = (double)__uint_as_float((uint32_t)red[0]);
+      c.peak_pos = (wp0 + (uint32_t)red[1]) & mask;
+      c.write_pos = (wp0 + (uint32_t)N) & mask;
+    } else {
+      for (int i = tid - 1; i < 2 * N; i += nt - 1) a1[i] = sp[i];
+    }
+    __syncthreads();
+    // 5. gain and output (compressor.rs:257-292); 6. the block's input goes into the line
+    for (int s = tid; s < 2 * N; s += nt) {
+      const int n = s >> 1, ch = s & 1;
+      const float total_gain = db_to_linear(makeup - comp_gain_reduction_db(c, env[n]));
+      const float delayed = n < W ? (float)line[((wp0 + (uint32_t)(n - W)) & mask) * 2 + ch] : a1[2 * (n - W) + ch];
+      sp[s] = delayed * total_gain;
+    }
+    __syncthreads();  // every read of the line's history is done before its slots are rewritten
+    // (the ring is only next_pow2(delay) frames long: of the frames that share a slot, the last one stays — write only those)
+    for (int s = tid; s < 2 * N; s += nt) if ((s >> 1) >= N - (int)(mask + 1)) line[((wp0 + (uint32_t)(s >> 1)) & mask) * 2 + (s & 1)] = (double)a1[s];
+    __syncthreads();
+  }
+  return true;
+}

@@ -201,3 +201,20 @@ def test_chorus_time_parallel_path(params):
     updates = {30: [("rate", 2.0, False)]}
     a, b, _, _ = run_pair(_capi.FX_CHORUS, params, None, blocks=40, frames=1024, signal="noise", updates=updates)
     check(a, b)
+
+
+@pytest.mark.parametrize("params", [
+    {"thrs": -0.01, "rato": 20.0, "knee": 0.0, "attk": 0.02, "rels": 2.0, "gain": 0.0, "look": 0.02},   # brick-wall limiter
+    {"thrs": -18.0, "rato": 4.0, "knee": 6.0, "attk": 0.005, "rels": 0.1, "gain": 3.0, "look": 0.04},     # compressor with soft knee
+    {"thrs": -30.0, "rato": 20.0, "knee": 2.0, "attk": 0.001, "rels": 0.1, "gain": 6.0, "look": 0.001},  # 48-frame look-ahead
+])
+def test_compressor_time_parallel_path(params):
+    """The time-parallel compressor / limiter: sliding-window maximum by doubling (look-ahead windows of 48, 960 and 1920 frames),
+    parallel gain law, serial envelope only. 24 blocks of bursty input (the tracked peak expires and is re-found many times); then
+    the ratio crosses 20 (compressor <-> limiter switch uses the peak state the fast path maintained) and the makeup gain ramps."""
+    flip = 4.0 if params["rato"] >= 20.0 else 20.0
+    updates = {12: [("rato", flip, False)], 18: [("gain", -3.0, False)]}
+    a, b, _, _ = run_pair(_capi.FX_COMPRESSOR, params, None, blocks=24, frames=1024, signal="burst", updates=updates)
+    check(a, b)
+    a, b, _, _ = run_pair(_capi.FX_COMPRESSOR, params, None, blocks=9, frames=700, signal="noise")
+    check(a, b)
