@@ -238,15 +238,15 @@ DEV float lfo_run(PgLfo& l) {  // :122-169, :234-239
 // takes the plain hardware step. Checked against the serial loop on the host (200k random (p, d, steps): bit-identical).
 DEV void f32_phase_advance(float& p, float d, int steps) {
   while (steps > 0) {
-    const uint32_t bits = __float_as_uint(p);
+    const uint32_t bits = __builtin_bit_cast(uint32_t, p);
     const int e = (int)((bits >> 23) & 0xff);
     bool closed = false;
     if (e > 24 && e < 0xff && p > 0.0f && d > 0.0f && p < 1.0f) {
-      const double u = __longlong_as_double((long long)((unsigned long long)(e - 127 - 23 + 1023) << 52));   // ulp(p)
+      const double u = __builtin_bit_cast(double, (unsigned long long)(e - 127 - 23 + 1023) << 52);   // ulp(p)
       const double D = (double)d / u;                                                                        // exact (power of two)
       const double Dr = rint(D);
       if (D < 16777216.0 && Dr >= 1.0 && D - floor(D) != 0.5) {
-        const double top = __longlong_as_double((long long)((unsigned long long)(e - 127 + 1 + 1023) << 52));  // end of the binade
+        const double top = __builtin_bit_cast(double, (unsigned long long)(e - 127 + 1 + 1023) << 52);  // end of the binade
         const double room = (top - u) - (double)p;   // a multiple of u
         const double q = floor(room / (Dr * u));     // steps that stay inside the binade (small integers: exact)
         if (q >= 1.0) {
