@@ -397,6 +397,7 @@ struct HostMixer {
   std::vector<int> fx;             // effect ids in chain order
   std::vector<Event> events;       // sorted by sample_time (stable: insert after equal, event.rs:31-38)
   std::vector<PgCmd> messages;     // StopSource messages: applied at the start of the next write
+  std::vector<Event> bus_events;   // main mixer only, defer_bus mode: effect events waiting for pg_graph_process_bus_device
 };
 
 struct pg_graph {
@@ -1006,6 +1007,12 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
     HostMixer& main = g->mixers[0];
     while (!main.events.empty() && main.events.front().sample_time <= now) {
       PgCmd c = main.events.front().cmd;
+      if (g->defer_bus && (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET)) {  // the bus chain runs in pg_graph_process_bus_device
+        if (main.bus_events.size() >= 65536) main.bus_events.erase(main.bus_events.begin(), main.bus_events.begin() + 32768);  // a shard that never runs the bus
+        main.bus_events.push_back(main.events.front());
+        main.events.erase(main.events.begin());
+        continue;
+      }
       c.frame = 0;
       c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET) ? main.unit_slot : g->source_unit_of_voice[c.param];  // voice commands carry the voice id in `param`
       cmds.push_back(c);
@@ -1090,14 +1097,34 @@ int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uin
   if (g->mixers[0].fx.empty()) return PG_OK;
   if (g->topo_dirty && rebuild_topology(g)) return graph_fail(g, PG_ERR_DEVICE);
   size_t frames = n_samples / 2, done = 0;
+  HostMixer& main = g->mixers[0];
   while (done < frames) {
-    uint32_t n = (uint32_t)std::min<size_t>(frames - done, g->max_frames);
+    const uint64_t now = pos_in_frames + done;
+    // effect events of the main mixer (queued by write in defer_bus mode) split the bus block at their sample times, exactly
+    // like the event loop of MixedSource::write (mixed.rs:679-712)
+    std::vector<PgCmd> cmds;
+    while (!main.bus_events.empty() && main.bus_events.front().sample_time <= now) {
+      PgCmd c = main.bus_events.front().cmd;
+      c.frame = 0; c.unit = main.unit_slot;
+      cmds.push_back(c);
+      main.bus_events.erase(main.bus_events.begin());
+    }
+    uint64_t n64 = std::min<uint64_t>(frames - done, g->max_frames);
+    if (!main.bus_events.empty()) n64 = std::min<uint64_t>(n64, main.bus_events.front().sample_time - now);
+    if (n64 == 0) continue;
+    const uint32_t n = (uint32_t)n64;
+    if (!cmds.empty()) {
+      HIP_TRY(hipStreamSynchronize(s));
+      int rc = g->d_cmds.upload(cmds);
+      if (rc) return rc;
+    }
     PgLaunch B;
     memset(&B, 0, sizeof B);
     B.units = g->d_units.d; B.voices = g->d_voices.d; B.fx = g->d_fx.d;
     B.voice_index = g->d_voice_index.d; B.fx_index = g->d_fx_index.d;
-    B.n_frames = n; B.pos = pos_in_frames + done; B.sample_rate = g->sample_rate; B.fast = g->fast;
-    B.n_units = 1; B.unit_base = g->mixers[0].unit_slot;
+    B.cmds = g->d_cmds.d; B.n_cmds = (int)cmds.size();
+    B.n_frames = n; B.pos = now; B.sample_rate = g->sample_rate; B.fast = g->fast;
+    B.n_units = 1; B.unit_base = main.unit_slot;
     B.bus = d_bus + done * 2; B.bus_audible = nullptr;
     HIP_TRY(pg_launch_units(B, s));
     done += n;

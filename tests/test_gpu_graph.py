@@ -370,3 +370,60 @@ def test_staged_kernel_ragged_block_sizes():
         outs.append(np.concatenate(chunks))
     compare(outs[0], outs[1])
     assert np.abs(outs[0]).max() > 1e-3
+
+
+def test_sharded_voices_with_deferred_bus_and_bus_automation():
+    """The multi-GPU data path on one device: two graphs hold half of the voices each (pg_graph_set_defer_bus), their partial master
+    buses are summed (what the RCCL reduce does) and the root runs the bus chain — Eq5 -> Reverb -> limiter, with a parameter
+    event on the Eq5 in the middle of a block — through pg_graph_process_bus_device. Must match the single graph holding
+    everything (up to the f32 order of the voice sum) and the oracle."""
+    import torch
+    from phonic_amd.graph import Graph
+
+    n_voices, blocks, block = 6, 8, 1024
+
+    def build(g, lo, hi):
+        ids = []
+        ids.append(g.add_effect(0, _capi.FX_EQ5, params={"gan2": 4.0}))
+        g.add_effect(0, _capi.FX_REVERB, params={"room": 0.4, "wet ": 0.3}, reverb_seeds=workloads.reverb_seeds(50))
+        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -6.0, "rato": 20.0, "look": 0.02})
+        for i in range(lo, hi):
+            g.add_voice(0, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.4, panning=workloads.voice_pan(i), has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    def automate(g, ids, blk, pos):
+        if blk == 3:
+            g.schedule_param(ids[0], "gan4", -9.0, pos + 300)
+            g.schedule_param(ids[0], "frq2", 700.0, pos + 800)
+
+    # single graph (GPU) and oracle
+    outs = []
+    for g in (Graph(SR, 2, block, 0), oracle.OracleGraph(SR, 2, block)):
+        ids = build(g, 0, n_voices)
+        o = np.zeros((blocks, 2 * block), np.float32)
+        for b in range(blocks):
+            automate(g, ids, b, b * block)
+            assert g.write(o[b], b * block) == 2 * block
+        outs.append(o.reshape(-1))
+    # two shards + deferred bus on the root
+    shards = [Graph(SR, 2, block, 0) for _ in range(2)]
+    ids = [build(g, k * n_voices // 2, (k + 1) * n_voices // 2) for k, g in enumerate(shards)]
+    for g in shards:
+        g.set_defer_bus(True)
+    parts = [torch.zeros(2 * block, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    sharded = np.zeros((blocks, 2 * block), np.float32)
+    for b in range(blocks):
+        for g, i in zip(shards, ids):
+            automate(g, i, b, b * block)
+        for g, p in zip(shards, parts):
+            assert g.write_device(p.data_ptr(), 2 * block, b * block) == 2 * block
+            g.synchronize()
+        bus = parts[0] + parts[1]
+        shards[0].process_bus_device(bus.data_ptr(), 2 * block, b * block)
+        shards[0].synchronize()
+        sharded[b] = bus.cpu().numpy()
+    sharded = sharded.reshape(-1)
+    compare(outs[0], outs[1])
+    compare(sharded, outs[1])
+    assert float(np.abs(sharded - outs[0]).max()) <= 1e-5
+    assert np.abs(sharded).max() > 1e-3
