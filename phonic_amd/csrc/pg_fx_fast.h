@@ -23,6 +23,7 @@ constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 
 #include "pg_delay_fast.inl"
 #include "pg_chorus_fast.inl"
 #include "pg_comp_fast.inl"
+#include "pg_gate_fast.inl"
 
 // FilterEffect (filter.rs:193-200) and Eq5Effect (eq5.rs:297-326) in steady state: cascaded TPT-SVF biquads on the f32
 // signal, each stage a blocked scan over the block (see rev_biquad_scan_t). The block is staged as f64 in the skewed
@@ -68,6 +69,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx) {
     case 5: return reverb_fast_eligible(fx);
     case 6: return chorus_fast_eligible(fx);
     case 7: return comp_fast_eligible(fx);
+    case 8: return true;
     case 9: return !sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f);
     default: return false;
   }
@@ -125,6 +127,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     case 5: if constexpr ((KMASK >> 5) & 1) return reverb_fast(fx, sig, n, fc); else return false;
     case 6: if constexpr ((KMASK >> 6) & 1) return chorus_fast(fx, sig, n, fc); else return false;
     case 7: if constexpr ((KMASK >> 7) & 1) return comp_fast(fx, sig, n, fc); else return false;
+    case 8: if constexpr ((KMASK >> 8) & 1) return gate_fast(fx, sig, n, fc); else return false;
     case 9: if constexpr ((KMASK >> 9) & 1) {  // DistortionEffect, no ramps (distortion.rs:331-341)
       const PgDist& d = fx.u.dist;
       if (sm_need_ramp(d.mix) || sm_need_ramp(d.drive)) return false;

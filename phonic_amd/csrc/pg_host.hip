@@ -506,8 +506,8 @@ static int rebuild_topology(pg_graph* g) {
     for (int f : mx.fx) {
       fidx.push_back(f);
       const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)
-      if (m != 0 && (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DISTORTION || k == PG_FX_DELAY || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR)) g->wide = true;
-      if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_REVERB || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_DISTORTION)) u.static_defer = 1;
+      if (m != 0 && (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DISTORTION || k == PG_FX_DELAY || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE)) g->wide = true;
+      if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_REVERB || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE || k == PG_FX_DISTORTION)) u.static_defer = 1;
       if (k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) u.static_defer = 1;  // DC filter: serial recurrence
     }
     // staged pipeline: a sub-mixer whose chain is [Gain (no DC filter) | Panning]* -> Reverb
