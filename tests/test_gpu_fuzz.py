@@ -1,0 +1,95 @@
+"""Seeded random graphs against the oracle: random effect chains (every kind, random in-range parameters) on sub-mixers and on
+the bus, random source rates, ragged block sizes, a few scheduled parameter / voice events. Exercises the kernel selection logic
+(lean / wide fused kernels, staged kernels, generic kernel hand-over) and every time-parallel effect path in combination."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle
+import workloads
+from phonic_amd import _capi
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def fourcc_str(v):
+    return struct.pack(">I", v).decode("latin1")
+
+
+def random_params(rng, kind, descs):
+    params = {}
+    for d in descs:
+        if rng.random() < 0.5:
+            continue
+        lo, hi = d["min"], d["max"]
+        if d["type"] == 0:  # float
+            t = float(rng.random())
+            v = lo + (hi - lo) * (t * t if d["scaling"] else t)
+            if kind == _capi.FX_DELAY and fourcc_str(d["fourcc"]) in ("lfdt", "lfdf", "ldfb") and rng.random() < 0.7:
+                v = 0.0   # mostly leave the delay's LFO depths at zero (the time-parallel path); sometimes modulated (serial path)
+            params[fourcc_str(d["fourcc"])] = float(np.float32(v))
+        else:  # enum / bool / int: integral raw value
+            params[fourcc_str(d["fourcc"])] = float(int(rng.integers(int(lo), int(hi) + 1)))
+    if kind == _capi.FX_DELAY:
+        params.pop("lfos", None)  # Random LFO shapes are rejected (non-deterministic in the reference)
+    return params
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_graph_matches_oracle(seed):
+    from phonic_amd.graph import Graph, effect_parameters
+
+    rng = np.random.default_rng(1000 + seed)
+    descs = {k: effect_parameters(k) for k in range(10)}
+    plan = {"mixers": [], "bus": []}
+    for m in range(int(rng.integers(1, 5))):
+        chain = []
+        for _ in range(int(rng.integers(0, 4))):
+            k = int(rng.integers(0, 10))
+            chain.append((k, random_params(rng, k, descs[k]), int(rng.integers(0, 1000))))
+        if rng.random() < 0.5:
+            chain.append((_capi.FX_REVERB, random_params(rng, _capi.FX_REVERB, descs[_capi.FX_REVERB]), int(rng.integers(0, 1000))))
+        voices = [(int(rng.integers(0, 60)), int(rng.choice([44100, 48000, 32000, 22050, 96000])), float(rng.uniform(0.2, 0.8)), float(rng.uniform(-1, 1)))
+                  for _ in range(int(rng.integers(1, 4)))]
+        plan["mixers"].append((chain, voices))
+    for _ in range(int(rng.integers(0, 3))):
+        k = int(rng.integers(0, 10))
+        plan["bus"].append((k, random_params(rng, k, descs[k]), int(rng.integers(0, 1000))))
+    sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000])) for _ in range(10)]
+    ev_block = int(rng.integers(2, 8))
+
+    outs = []
+    for which in ("gpu", "oracle"):
+        g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
+        fx_ids, voice_ids = [], []
+        for chain, voices in plan["mixers"]:
+            m = g.add_mixer()
+            for (k, p, s) in chain:
+                fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+            for (ti, rate, vol, pan) in voices:
+                voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+        for (k, p, s) in plan["bus"]:
+            fx_ids.append((g.add_effect(0, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            if b == ev_block:
+                g.set_voice_volume(voice_ids[0], 0.3, pos + 17)
+                if fx_ids:
+                    fid, k = fx_ids[seed % len(fx_ids)]
+                    d = descs[k][0]
+                    if d["type"] == 0:
+                        g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos + n // 2, normalized=True)
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) in (0, 2 * n)
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+    a, b = outs
+    assert np.isfinite(a).all()
+    assert float(np.abs(b).max()) > 1e-4, "silent reference output: the case tests nothing"
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
+    assert float(np.abs(d).max()) <= 1e-4 * scale
