@@ -772,15 +772,16 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
 #define PG_SLOT_STAMP(i) do { } while (0)
 #endif
   PG_SLOT_STAMP(0);
-  if (!stage1_call(&sL, slot)) return;
+  // inlined stages read the launch structure from the kernel arguments (scalar registers), out-of-line ones from the LDS copy
+  if (!(((PG_STAGE_OUTLINE >> 0) & 1) ? stage1_call(&sL, slot) : (int)stage1_run<2, true>(L, slot))) return;
   __syncthreads();
   PG_SLOT_STAMP(1);
-  const int u = sL.unit_order ? sL.unit_order[slot] : sL.unit_base + slot;
-  const int flags = sL.units[u].stage_flags;
-  stage2_call(&sL, slot, flags);
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  const int flags = L.units[u].stage_flags;
+  if ((PG_STAGE_OUTLINE >> 1) & 1) stage2_call(&sL, slot, flags); else stage2_run<2, true>(L, slot, flags);
   __syncthreads();
   PG_SLOT_STAMP(2);
-  stage3_call(&sL, slot, flags);
+  if ((PG_STAGE_OUTLINE >> 2) & 1) stage3_call(&sL, slot, flags); else stage3_run<2, true>(L, slot, flags);
   PG_SLOT_STAMP(3);
 }
 
@@ -793,11 +794,11 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kerne
   for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
   __syncthreads();
   const int slot = blockIdx.x;
-  if (!stage1_run<3, true>(sL, slot)) return;
+  if (!stage1_run<3, true>(L, slot)) return;
   __syncthreads();
-  const int u = sL.unit_order ? sL.unit_order[slot] : sL.unit_base + slot;
-  const int flags = sL.units[u].stage_flags;
-  stage2_run<3, true>(sL, slot, flags);
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  const int flags = L.units[u].stage_flags;
+  stage2_run<3, true>(L, slot, flags);
   __syncthreads();
   stage3_call(&sL, slot, flags);
 }
