@@ -566,21 +566,23 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
   }
   __syncthreads();
   if (!ctl[5]) return false;
+  // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
+  const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
   for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
   __syncthreads();
   bool audible_input = false;
-  for (int vi = 0; vi < unit.n_voices; ++vi) {
-    PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[unit.voice_off + vi]];
+  for (int vi = 0; vi < n_voices; ++vi) {
+    PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[voice_off + vi]];
     audible_input |= voice_process<false>(gv, lv, sig, tmp, N, L.pos, S, L.sched, L.sched_bank, vi == 0, voice_word);
   }
   PG_STAMP(L.diag, 1);
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
   bool input_bypassed = !audible_input;
-  if (unit.effects_bypassed && input_bypassed) flags |= PG_STAGE_SKIPPED;  // process_effects (mixed.rs:627-655)
+  if (effects_bypassed && input_bypassed) flags |= PG_STAGE_SKIPPED;  // process_effects (mixed.rs:627-655)
   else {
     bool all_bypassed = true;
-    for (int fi = 0; fi + 1 < unit.n_fx; ++fi) {  // leading Gain / Panning effects
-      PgFx& g1 = L.fx[L.fx_index[unit.fx_off + fi]];
+    for (int fi = 0; fi + 1 < n_fx; ++fi) {  // leading effects
+      PgFx& g1 = L.fx[L.fx_index[fx_off + fi]];
       __syncthreads();
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&g1)[i];
       __syncthreads();
@@ -614,9 +616,11 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
   for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];  // the dry signal waits in the unit's output row
   if (tid == 0) unit.stage_flags = flags;
   PG_STAMP(L.diag, 14);
-  if (L.sched && tid == 0) {  // schedule cache: representatives replay the next block's resampler schedule
+  // schedule cache (ratio < 0.5 only): representatives replay the next block's resampler schedule. A single voice that took the
+  // time-parallel schedule needs nothing published — decided from its LDS copy, without a trip to the voice table.
+  if (L.sched && tid == 0 && !(n_voices == 1 && lv->sched_hit == 2)) {
     const int piece = N < SRC_OUT_CAP ? N : SRC_OUT_CAP;
-    for (int vi = 0; vi < unit.n_voices; ++vi) sched_publish(&L.voices[L.voice_index[unit.voice_off + vi]], L.sched, L.sched_bank, piece);
+    for (int vi = 0; vi < n_voices; ++vi) sched_publish(&L.voices[L.voice_index[voice_off + vi]], L.sched, L.sched_bank, piece);
   }
   PG_STAMP(L.diag, 13);
   return true;
