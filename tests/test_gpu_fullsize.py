@@ -61,3 +61,22 @@ def test_call_size_invariance_steady_state():
     a = a_g.render(2, 4096)
     b = b_g.render(8, 1024)
     assert rms(a - b) <= 1e-6
+
+
+def test_long_run_stays_on_the_oracle():
+    """32 s of audio (1500 blocks of 1024 frames) through 8 headline voices: the exact closed forms (vibrato phases, resampler
+    schedule) and the blocked scans must not drift — the last 100 blocks are held to the same 1e-5 RMS as the first."""
+    import oracle
+
+    blocks = 1500
+    g = gpu_graph()
+    gc = oracle.OracleGraph(48000, 2, 1024)
+    for x in (g, gc):
+        workloads.build_headline(x, 8, 0, 8, seconds=0.5)
+    a = g.render(blocks, 1024)
+    b = gc.render(blocks, 1024)
+    for sl in (slice(0, 100 * 2048), slice((blocks - 100) * 2048, blocks * 2048)):
+        d = a[sl].astype(np.float64) - b[sl].astype(np.float64)
+        assert float(np.sqrt(np.mean(d * d))) <= 1e-5
+        assert float(np.abs(d).max()) <= 1e-4
+    assert np.abs(a[-2048:]).max() > 1e-3
