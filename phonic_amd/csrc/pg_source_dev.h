@@ -63,15 +63,26 @@ DEVO float cubic_interp(float ym1, float y0, float y1, float y2, float fraction)
 // step k is a 4-entry increment table and the tables compose: one Kogge-Stone scan over the piece gives every d_k. Where a
 // decision differs (a value within |d| of the wrap threshold, ~0.6 % of 1024-frame pieces) the closed form restarts from the
 // exact state in front of it. Bit-identical to the serial recurrence (checked against it on the host model and by the parity tests).
-struct SchedTab { int t[4]; };
-DEVO int schedtab_at(const SchedTab& a, int m) { m &= 3; return m == 0 ? a.t[0] : (m == 1 ? a.t[1] : (m == 2 ? a.t[2] : a.t[3])); }
-DEVO SchedTab schedtab_compose(const SchedTab& a, const SchedTab& b) {  // a first, then b
-  SchedTab c;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) c.t[m] = a.t[m] + schedtab_at(b, m + a.t[m]);
-  return c;
+// A rounding table: the increment of d for each value of d mod 4, four signed 16-bit fields in one 64-bit word (|d| <= 1024).
+typedef unsigned long long SchedTab;
+DEVO int schedtab_at(SchedTab a, int m) { return (int)(short)(a >> (16 * (m & 3))); }
+DEVO SchedTab schedtab_pack(int t0, int t1, int t2, int t3) {
+  return (unsigned long long)(unsigned short)t0 | ((unsigned long long)(unsigned short)t1 << 16) | ((unsigned long long)(unsigned short)t2 << 32) |
+         ((unsigned long long)(unsigned short)t3 << 48);
+}
+DEVO SchedTab schedtab_compose(SchedTab a, SchedTab b) {  // a first, then b
+  const int a0 = schedtab_at(a, 0), a1 = schedtab_at(a, 1), a2 = schedtab_at(a, 2), a3 = schedtab_at(a, 3);
+  return schedtab_pack(a0 + schedtab_at(b, 0 + a0), a1 + schedtab_at(b, 1 + a1), a2 + schedtab_at(b, 2 + a2), a3 + schedtab_at(b, 3 + a3));
 }
 DEVO int sched_rho(int A) { return (A >= (1 << 24) && (A & 1)) ? ((A & 3) == 3 ? 1 : -1) : 0; }
+// table of one step whose unrounded pre-wrap value is u0 (>= 2^24): rho(u0 + m) for m = 0..3 = the pattern {0, -1, 0, +1} rotated by u0 mod 4
+DEVO SchedTab schedtab_step(int u0) {
+  const int r = u0 & 3;
+  int t[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const int x = (r + m) & 3; t[m] = (x & 1) ? x - 2 : 0; }
+  return schedtab_pack(t[0], t[1], t[2], t[3]);
+}
 
 // All lanes of the workgroup (256). `scr`: >= 32 ints of LDS. Returns false when it gave up (caller replays serially).
 DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
@@ -81,39 +92,36 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
   int* s_viol = scr;          // first element whose wrap decision differs from the closed form
   int* s_start = scr + 1;     // restart: element, exact U of that element, wraps counted in front of it
   int* s_res = scr + 4;       // c_total, sp_out bits
-  int* s_wave = scr + 8;      // [4 waves][4] wave totals
+  SchedTab* s_wave = (SchedTab*)(scr + 8);  // [4 waves] wave totals
   if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * 16777216.0f); s_start[2] = 0; }
   for (int iter = 0; iter < 16; ++iter) {
     __syncthreads();
     const int k0 = s_start[0], S = s_start[1], cc0 = s_start[2];
     if (tid == 0) *s_viol = 0x7fffffff;
-    // closed form of this lane's four elements
-    int U0[4]; int side[4]; SchedTab T[4];
+    // closed form of this lane's four elements: U0 = ((S + (j-1) R) mod 2^24) + R — the low 24 bits of a 32-bit product suffice
+    int U0[4]; int side[4];
+    SchedTab T[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = 4 * tid + e, j = k - k0;
       int u0 = S;
-      if (j >= 1) u0 = (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)(j - 1) * (unsigned)R) & (unsigned long long)(TWO24 - 1)) + R;
+      if (j >= 1) u0 = (int)(((unsigned)S + (unsigned)(j - 1) * (unsigned)R) & (unsigned)(TWO24 - 1)) + R;
       U0[e] = u0;
       side[e] = u0 >= TWO24;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { const int A = u0 + m; T[e].t[m] = (j >= 1 && k < piece && side[e] && (A & 1)) ? ((A & 3) == 3 ? 1 : -1) : 0; }
+      T[e] = (j >= 1 && k < piece && side[e]) ? schedtab_step(u0) : 0ull;
     }
     SchedTab incl = schedtab_compose(schedtab_compose(T[0], T[1]), schedtab_compose(T[2], T[3]));
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      SchedTab b;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) b.t[m] = __shfl_up(incl.t[m], off, 64);
+      const SchedTab b = __shfl_up(incl, off, 64);
       if (lane >= off) incl = schedtab_compose(b, incl);
     }
-    if (lane == 63) { for (int m = 0; m < 4; ++m) s_wave[wave * 4 + m] = incl.t[m]; }
-    SchedTab excl;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { excl.t[m] = __shfl_up(incl.t[m], 1, 64); if (lane == 0) excl.t[m] = 0; }
+    if (lane == 63) s_wave[wave] = incl;
+    SchedTab excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0ull;
     __syncthreads();
     int d = 0;  // d at the start element is 0; tables in front of it are identities
-    for (int w = 0; w < wave; ++w) { const int m = d & 3; d += s_wave[w * 4 + m]; }
+    for (int w = 0; w < wave; ++w) d += schedtab_at(s_wave[w], d);
     d += schedtab_at(excl, d);
     // walk the four elements with the true d
     int viol = 0x7fffffff;
