@@ -681,7 +681,9 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       RevBlock b;
       (void)rev_block_params(*lfx, m, ctl, b);
       rev_tail(lfx->u.reverb, sig, N, m, b, L.diag);
+      PG_STAMP(L.diag, 60);
       if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, L.sample_rate, ctl, red);
+      PG_STAMP(L.diag, 61);
       all_bypassed = false;
       __syncthreads();
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
@@ -690,6 +692,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
     if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
   }
   __syncthreads();
+  PG_STAMP(L.diag, 62);
   // ---- hand the block to the parent mixer (same as the fused kernel) ----
   if (unit.kind == UNIT_SUBMIXER) {
     float max_sample = wg_max_abs(sig, 2 * N, red);

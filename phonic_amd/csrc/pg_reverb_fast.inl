@@ -536,12 +536,16 @@ DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBloc
   const int tid = threadIdx.x, nt = blockDim.x;
   double* bufA = m.bufA;
   const double wet = b.wet;
+  PG_STAMP(diag, 56);
   rev_biquad_scan(r.cb, r.sb, bufA, T, m.xchg);
   __syncthreads();
+  PG_STAMP(diag, 57);
   for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = asin(clampd(bufA[bi], -1.0, 1.0)); }
   __syncthreads();
+  PG_STAMP(diag, 58);
   rev_biquad_scan(r.cc, r.sc, bufA, T, m.xchg);
   __syncthreads();
+  PG_STAMP(diag, 59);
   for (int s = tid; s < 2 * T; s += nt) {
     double y = bufA[REV_IDX(s >> 1, s & 1)];
     if (wet != 1.0) y += rev_guard(s0[s], (s & 1) ? r.fpd_r : r.fpd_l) * (1.0 - wet);

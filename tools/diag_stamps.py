@@ -29,3 +29,8 @@ for k in ([0,16,17,18,19,1,8,11,3,14,13,12,2,4,5,6,7,15] if '--staged' in sys.ar
 
 laps=[buf[50+i] for i in range(5)]
 print('phase-3 laps of wave 0, summed over 20 blocks (cycles/block):', {n: laps[i]//20 for i,n in enumerate(['line taps issued','ap loads+sin+chain','interp+householder','barrier wait','stores'])})
+
+if '--staged' in sys.argv:
+    t3=[buf[i] for i in (6,56,57,58,59,7,60,61,62,15)]
+    n3=['stage 2 done','sig reloaded / scan B starts','scan B done','asin done / scan C starts','scan C done','dry mix done','(post logic starts)','post logic done','state written back','unit output stored']
+    for i in range(1,len(t3)): print(f"stage 3: {n3[i]:34s} +{t3[i]-t3[i-1]:8d} cyc")
