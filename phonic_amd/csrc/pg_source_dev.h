@@ -161,6 +161,9 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
   return false;
 }
 
+// sample count -> frame count. A 64-bit division is a long software routine on this target; files are mono or stereo.
+DEVO uint64_t div_channels(uint64_t x, int C) { return C == 2 ? (x >> 1) : (C == 1 ? x : x / (uint64_t)C); }
+
 // PreloadedFileSource::write_buffer (src/source/file/preloaded.rs:270-332) for `out_frames` frames of the file's
 // channel layout into `out` (LDS). `v` is the unit's LDS copy of the voice. Returns frames written (uniform).
 // When `acc` is given (steady state), the finished samples are added straight into the mixer's block (add_buffers,
@@ -217,7 +220,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
     {
       const float ratio = v->ratio, sp0 = v->sub_pos[0];
       const uint64_t pp0 = v->playback_pos;
-      const uint64_t num_in0 = (lr_end > pp0 ? lr_end - pp0 : 0) / C;
+      const uint64_t num_in0 = div_channels(lr_end > pp0 ? lr_end - pp0 : 0, C);
       const float t = sp0 * 16777216.0f;
       if (ratio >= 0.5f && ratio < 1.0f && v->initialized[0] && num_in0 > (uint64_t)piece && sp0 >= 0.0f && sp0 < 2.0f && t == floorf(t) && nt == 256) {
         if (C == 2) {  // the input window goes out to HBM before the schedule is known: an upper bound of the consumed frames is
@@ -248,11 +251,11 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         // the input cannot run out (at most one push per output when ratio < 1), so the `consumed >= num_in` exits of
         // cubic.rs:75-77 are dead and the schedule is a branch-free f32 recurrence — the same operations in the same order.
         uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
-        uint64_t num_in = remaining_in / C;
+        uint64_t num_in = div_channels(remaining_in, C);
         const PgSchedEntry* se = S.sched_rd;
         if (se && !(se->valid && se->piece == piece && se->ratio_bits == __float_as_uint(ratio) && se->subpos_in_bits == __float_as_uint(sub_pos))) se = nullptr;
         if (par_ok) {
-          S.ctl[3] = (int)(uint32_t)(pp / C);
+          S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
           c = par_c;
           sub_pos = par_sp;
           pp += (uint64_t)c * C;
@@ -260,7 +263,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           linear = 1;
         } else if (ratio < 1.0f && initialized && num_in > (uint64_t)piece && se) {
           // schedule cache hit: the class representative replayed exactly this recurrence; lanes copy it below
-          S.ctl[3] = (int)(uint32_t)(pp / C);
+          S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
           c = se->c_total;
           sub_pos = __uint_as_float(se->subpos_out_bits);
           pp += (uint64_t)c * C;
@@ -294,7 +297,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           }
           sub_pos = sp;
           c = cc;
-          S.ctl[3] = (int)(uint32_t)(pp / C);
+          S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
           pp += (uint64_t)c * C;  // num_in > piece >= c: the loop end cannot be reached
           produced = piece;
           linear = 1;
@@ -305,10 +308,11 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       if (S.sched_rd) { PG_STAMP_VAL(S.diag, 42, S.sched_rd->valid); PG_STAMP_VAL(S.diag, 43, S.sched_rd->piece); PG_STAMP_VAL(S.diag, 44, piece); PG_STAMP_VAL(S.diag, 45, S.sched_rd->subpos_in_bits); PG_STAMP_VAL(S.diag, 46, __float_as_uint(v->sub_pos[0])); PG_STAMP_VAL(S.diag, 47, S.sched_rd->ratio_bits); PG_STAMP_VAL(S.diag, 48, __float_as_uint(ratio)); }
       while (produced < piece) {  // write_buffer loop :286-331; each iteration = one resampler.process call
         uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
-        int num_in = (int)((remaining_in / C) > 0x7fffffff ? 0x7fffffff : (remaining_in / C));
+        const uint64_t num_in64 = div_channels(remaining_in, C);
+        int num_in = (int)(num_in64 > 0x7fffffff ? 0x7fffffff : num_in64);
         int num_out = piece - produced;
         int consumed = 0, prod = 0;
-        uint32_t base_frame = (uint32_t)(pp / C);
+        uint32_t base_frame = (uint32_t)div_channels(pp, C);
         if (!initialized && num_in >= 3) {  // cubic.rs:61-69
           initialized = 1;
           for (int f = 0; f < 3; ++f) { S.posmap[c] = base_frame + consumed; ++c; ++consumed; }
