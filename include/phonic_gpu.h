@@ -159,6 +159,10 @@ void pg_graph_destroy(pg_graph* g);
 
 /* Player::add_mixer(parent = main) -> mixer id > 0 (src/player.rs:773-822). */
 int pg_graph_add_mixer(pg_graph* g);
+/* Player::add_mixer(parent_mixer_id) (src/player.rs:771-822): the new mixer is a child of `parent_mixer_id` (0 = main mixer); the
+ * parent sums its sub-mixers first, then its sources, then runs its effects (MixedSource::write, src/source/mixed.rs:696-703;
+ * SubMixerProcessor::process, src/source/mixed/submixer.rs:47-77). PG_ERR_NOT_FOUND for an unknown parent. */
+int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id);
 /* Player::add_effect(effect, mixer) -> effect id >= 0 (src/player.rs:893-939). */
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init);
 /* Player::play_file_source(PreloadedFileSource::from_shared_buffer(..), start_time)

@@ -103,18 +103,22 @@ po_graph* po_graph_create(uint32_t sample_rate, uint32_t channels, size_t, int) 
 }
 void po_graph_destroy(po_graph* g) { delete g; }
 
-int po_graph_add_mixer(po_graph* g) {  // Player::add_mixer(main)
+int po_graph_add_mixer_to(po_graph* g, int parent_mixer_id) {  // Player::add_mixer(parent)  src/player.rs:773-822
+  auto parent = g->mixers.find(parent_mixer_id);
+  if (parent == g->mixers.end()) return -PG_ERR_NOT_FOUND;
   int id = g->next_mixer++;
   std::unique_ptr<SubMixerProcessor> p(new SubMixerProcessor());
   p->mixer.reset(new MixedSource(g->channels, g->sample_rate));
-  g->mixers[id] = p->mixer.get();
+  MixedSource* child = p->mixer.get();
   MixedSource::Message m;
   m.kind = MixedSource::Message::AddMixer;
   m.id = id;
   m.mixer = std::move(p);
-  g->main->message_queue.push_back(std::move(m));
+  parent->second->message_queue.push_back(std::move(m));
+  g->mixers[id] = child;
   return id;
 }
+int po_graph_add_mixer(po_graph* g) { return po_graph_add_mixer_to(g, 0); }  // Player::add_mixer(None): child of the main mixer
 int po_graph_add_effect(po_graph* g, int mixer_id, int kind, const pg_effect_init* init) {  // Player::add_effect
   auto it = g->mixers.find(mixer_id);
   if (it == g->mixers.end()) return -PG_ERR_NOT_FOUND;

@@ -113,6 +113,7 @@ def declare(lib, prefix):
         "graph_create": (vp, [C.c_uint32, C.c_uint32, C.c_size_t, C.c_int]),
         "graph_destroy": (None, [vp]),
         "graph_add_mixer": (C.c_int, [vp]),
+        "graph_add_mixer_to": (C.c_int, [vp, C.c_int]),
         "graph_add_effect": (C.c_int, [vp, C.c_int, C.c_int, P(EffectInit)]),
         "graph_add_voice": (C.c_int, [vp, C.c_int, P(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, P(VoiceOptions)]),
         "graph_schedule_param": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_float, C.c_int, C.c_uint64]),

@@ -122,8 +122,11 @@ class GraphHandle:
             raise PhonicError(-v, self._err())
         return v
 
-    def add_mixer(self):
-        return self._id(self._fn("graph_add_mixer")(self._h))
+    def add_mixer(self, parent=None):
+        """Player::add_mixer(parent_mixer_id): None / 0 = child of the main mixer."""
+        if not parent:
+            return self._id(self._fn("graph_add_mixer")(self._h))
+        return self._id(self._fn("graph_add_mixer_to")(self._h, parent))
 
     def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None):
         init = _capi.make_init(params, reverb_seeds)

@@ -219,7 +219,10 @@ struct PgUnit {
   int32_t fx0;                  // host: device index of the unit's first effect (prefetched during the source stage)
   int32_t staged;               // host: the chain is [Gain|Panning]* -> Reverb: eligible for the staged pipeline (pg_stage*_kernel)
   int32_t stage_flags;          // device: hand-over between the stage kernels of one block (PG_STAGE_*)
+  int32_t child_off, n_children;  // host: nested sub-mixers of this mixer, entries of PgLaunch::child_rows (summed before the sources)
   int32_t pad4;
+  uint64_t call_audible;        // device: bit k = result of SubMixerProcessor::process for the k-th call of this round (a parent with
+                                // events mid-block calls its sub-mixers once per segment, mixed.rs:679-712)
 };
 enum { PG_STAGE_ACTIVE = 1, PG_STAGE_INPUT_BYPASSED = 2, PG_STAGE_ALL_BYPASSED = 4, PG_STAGE_AUDIBLE = 8, PG_STAGE_SKIPPED = 16 };
 
@@ -231,7 +234,9 @@ enum PgCmdType {
   CMD_VOICE_STOP = 4,   // sets stop_time = value64
   CMD_VOICE_SPEED = 5,  // value64 = f64 bits of the speed, value = glide (semitones/s, <= 0: none)
   CMD_VOICE_SEEK = 6,   // value64 = f64 bits of the position in seconds
+  CMD_CALL_SPLIT = 7,   // nested sub-mixers: an ancestor splits its block at `frame` -> this unit's write() call ends there and a new one begins
 };
+#define PG_MAX_CALLS 64  // calls of one sub-mixer per launch round (bits of PgUnit::call_audible); the host bounds the round accordingly
 struct PgCmd {
   int32_t type, unit, target, param;
   uint32_t frame;  // offset in frames from the start of this launch at which the command applies
@@ -271,5 +276,7 @@ struct PgLaunch {
   unsigned long long* host_feedback;  // pinned host word: the generic kernel reports (round << 32 | units it found deferred)
   uint32_t round;         // launch counter of this round
   int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
+  const float* rows_base; // nested sub-mixers: row 0 of the per-unit output table (unit_out points at this launch's level) ...
+  const int2* child_rows; // ... and {row, unit slot} of every nested sub-mixer, indexed by PgUnit::child_off
 };
 constexpr int PG_STAGE_BUF_DOUBLES = 2 * 1024 + 128 + 8;

@@ -398,7 +398,13 @@ struct HostMixer {
   std::vector<Event> events;       // sorted by sample_time (stable: insert after equal, event.rs:31-38)
   std::vector<PgCmd> messages;     // StopSource messages: applied at the start of the next write
   std::vector<Event> bus_events;   // main mixer only, defer_bus mode: effect events waiting for pg_graph_process_bus_device
+  int parent = 0;                  // Player::add_mixer(parent): 0 = the main mixer
+  int depth = 1;                   // main mixer 0, its sub-mixers 1, their sub-mixers 2 ...
+  std::vector<int> children;       // nested sub-mixers, in the order they were added
 };
+// Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
+// deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
+struct Level { int off = 0, cnt = 0, n_staged = 0, n_staged_wide = 0, n_static_defer = 0; };
 
 struct pg_graph {
   int device = 0;
@@ -415,6 +421,9 @@ struct pg_graph {
   int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceVec<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
+  DeviceVec<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
+  std::vector<Level> levels;    // deepest first
+  uint64_t defer_phase = 0;     // one deferral hand-shake per level launch (two counters, alternating)
   int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
   size_t defer_rows = 0;
   size_t stage_rows = 0;
@@ -471,6 +480,7 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].voice0 = topo[i].voice0;
   units[i].fx0 = topo[i].fx0;
   units[i].staged = topo[i].staged;
+  units[i].child_off = topo[i].child_off; units[i].n_children = topo[i].n_children;
   units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
 __global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
@@ -522,13 +532,34 @@ static int rebuild_topology(pg_graph* g) {
       }
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
+    if (!mx.children.empty()) { u.static_defer = 1; u.staged = 0; }  // sums its sub-mixers' rows first: exact serial kernel
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
   }
   // main-mixer sources: one unit each
   g->order.clear();
-  for (size_t m = 1; m < g->mixers.size(); ++m) g->order.push_back(g->mixers[m].unit_slot);
+  g->levels.clear();
+  int max_depth = 1;
+  for (size_t m = 1; m < g->mixers.size(); ++m) max_depth = std::max(max_depth, g->mixers[m].depth);
+  std::vector<int> row_of_mixer(g->mixers.size(), -1);
+  for (int d = max_depth; d >= 1; --d) {
+    Level lv;
+    lv.off = (int)g->order.size();
+    for (size_t m = 1; m < g->mixers.size(); ++m) {
+      if (g->mixers[m].depth != d) continue;
+      row_of_mixer[m] = (int)g->order.size();
+      g->order.push_back(g->mixers[m].unit_slot);
+    }
+    lv.cnt = (int)g->order.size() - lv.off;
+    g->levels.push_back(lv);
+  }
+  std::vector<int2> child_rows;
+  for (size_t m = 1; m < g->mixers.size(); ++m) {
+    PgUnit& u = topo[g->mixers[m].unit_slot];
+    u.child_off = (int)child_rows.size(); u.n_children = (int)g->mixers[m].children.size();
+    for (int c : g->mixers[m].children) child_rows.push_back(make_int2(row_of_mixer[c], g->mixers[c].unit_slot));
+  }
   for (int v : g->mixers[0].voices) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
@@ -538,6 +569,11 @@ static int rebuild_topology(pg_graph* g) {
     g->order.push_back(slot);
   }
   g->n_graph_units = (int)g->order.size();
+  g->levels.back().cnt = g->n_graph_units - g->levels.back().off;  // the main mixer's sources belong to the last level
+  {
+    int rc0;
+    if ((rc0 = g->d_child_rows.upload(child_rows))) return rc0;
+  }
   {
     std::vector<int4> info;
     for (int slot : g->order) {
@@ -548,9 +584,13 @@ static int rebuild_topology(pg_graph* g) {
     if ((rc0 = g->d_slot_info.upload(info))) return rc0;
   }
   g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
-  for (int slot : g->order) {
-    g->n_staged += topo[slot].staged ? 1 : 0; g->n_staged_wide += topo[slot].staged == 2 ? 1 : 0;
-    g->n_static_defer += topo[slot].static_defer ? 1 : 0;
+  for (Level& lv : g->levels) {
+    lv.n_staged = lv.n_staged_wide = lv.n_static_defer = 0;
+    for (int i = lv.off; i < lv.off + lv.cnt; ++i) {
+      const PgUnit& u = topo[g->order[i]];
+      lv.n_staged += u.staged ? 1 : 0; lv.n_staged_wide += u.staged == 2 ? 1 : 0; lv.n_static_defer += u.static_defer ? 1 : 0;
+    }
+    g->n_staged += lv.n_staged; g->n_staged_wide += lv.n_staged_wide; g->n_static_defer += lv.n_static_defer;
   }
   g->h_units = topo;
   int rc;
@@ -639,6 +679,7 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
   g->mixers.emplace_back();
+  g->mixers[0].depth = 0;
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
   if (g->mixers[0].unit_slot < 0) return nullptr;
   return g.release();
@@ -651,7 +692,7 @@ void pg_graph_destroy(pg_graph* g) {
   for (auto& v : g->voices) if (v.d_pcm) (void)hipFree(v.d_pcm);
   for (auto& f : g->fx) if (f->d_mem) (void)hipFree(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_cmds.release(); g->d_sched.release(); g->d_slot_info.release();
+  g->d_cmds.release(); g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release();
   if (g->d_unit_out) (void)hipFree(g->d_unit_out);
   if (g->d_partial) (void)hipFree(g->d_partial);
   if (g->d_stage) (void)hipFree(g->d_stage);
@@ -665,14 +706,20 @@ void pg_graph_destroy(pg_graph* g) {
   delete g;
 }
 
-int pg_graph_add_mixer(pg_graph* g) {
+int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id) {
   (void)hipSetDevice(g->device);
+  if (parent_mixer_id < 0 || parent_mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", parent_mixer_id);
   int slot = new_unit(g, UNIT_SUBMIXER);
   if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
+  const int id = (int)g->mixers.size();
   g->mixers.emplace_back();
   g->mixers.back().unit_slot = slot;
-  return (int)g->mixers.size() - 1;
+  g->mixers.back().parent = parent_mixer_id;
+  g->mixers.back().depth = g->mixers[parent_mixer_id].depth + 1;
+  if (parent_mixer_id != 0) g->mixers[parent_mixer_id].children.push_back(id);
+  return id;
 }
+int pg_graph_add_mixer(pg_graph* g) { return pg_graph_add_mixer_to(g, 0); }
 
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init) {
   (void)hipSetDevice(g->device);
@@ -917,65 +964,81 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.voice_index = g->d_voice_index.d; L.fx_index = g->d_fx_index.d;
   L.cmds = g->d_cmds.d; L.n_cmds = (int)cmds.size();
   L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
-  L.unit_out = g->d_unit_out; L.out_stride = g->stride;
-  L.n_units = g->n_graph_units; L.unit_order = g->d_order.d;
+  L.out_stride = g->stride;
+  L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
   L.diag = g->d_diag;
-  L.slot_info = g->d_slot_info.d;
   const uint64_t round = g->launch_counter;
   if (!cmds.empty()) g->last_change_round = round;
   L.round = (uint32_t)round; L.host_feedback = g->d_feedback;
+  const bool nested = g->levels.size() > 1;
   // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
   // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.
+  // (Graphs with nested sub-mixers always launch it: the parents are rendered there.)
   bool generic_idle = false;
-  if (g->fast && g->n_static_defer == 0 && cmds.empty() && g->d_feedback) {
+  if (g->fast && !nested && g->n_static_defer == 0 && cmds.empty() && g->d_feedback) {
     const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
     generic_idle = fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
   }
-  if (g->d_defer) { L.defer_count = g->d_defer + (g->launch_counter & 1); L.defer_reset = g->d_defer + ((g->launch_counter & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;
   // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
   // average can time every n-th round (pg_graph_set_timing_period)
-  bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < 8192 && L.n_units > 0;
+  bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < 8192 && g->n_graph_units > 0;
   if (timed && g->ev_used >= g->ev_pool.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     g->ev_pool.emplace_back(a, b);
   }
-  // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
-  // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
-  // dispatch itself (hipExtLaunchKernel: no marker packets in the stream); several launches are bracketed by event records.
-  const bool time_generic = g->fast && g->n_static_defer * 2 > g->n_graph_units;
-  hipEvent_t e0 = timed ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed ? g->ev_pool[g->ev_used].second : nullptr;
-  if (g->fast) {
-    L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
-    // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
-    const int n_lean = g->n_staged - g->n_staged_wide;
-    const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
-    const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
-    const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && g->n_staged_wide > 0;
-    const bool fused = !staged || n_handled < g->n_graph_units;
-    const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
-    const bool ride = timed && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
-    const bool bracket = timed && !time_generic && n_launches > 1;
-    if (bracket) HIP_TRY(hipEventRecord(e0, stream));
-    if (staged) {
-      L.stage_buf = g->d_stage; L.staged_on = g->staged_mode == 1 ? 2 : 1;
-      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
+  size_t timed_level = 0;  // the level holding most units carries the timing events
+  for (size_t li = 1; li < g->levels.size(); ++li) if (g->levels[li].cnt > g->levels[timed_level].cnt) timed_level = li;
+  for (size_t li = 0; li < g->levels.size(); ++li) {
+    const Level& lv = g->levels[li];
+    if (lv.cnt == 0) continue;
+    // this level's slice of the per-slot tables: launch slot b of the level = row lv.off + b
+    L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
+    L.unit_out = g->d_unit_out + (size_t)lv.off * g->stride;
+    L.slot_info = g->d_slot_info.d + lv.off;
+    if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
+    g->defer_phase++;
+    const bool timed_here = timed && li == timed_level;
+    // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
+    // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
+    // dispatch itself (hipExtLaunchKernel: no marker packets in the stream); several launches are bracketed by event records.
+    const bool time_generic = g->fast && lv.n_static_defer * 2 > lv.cnt;
+    hipEvent_t e0 = timed_here ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed_here ? g->ev_pool[g->ev_used].second : nullptr;
+    if (g->fast) {
+      L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+      // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
+      const int n_lean = lv.n_staged - lv.n_staged_wide;
+      const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;
+      const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
+      const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && lv.n_staged_wide > 0;
+      const bool fused = !staged || n_handled < lv.cnt;
+      const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
+      const bool ride = timed_here && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
+      const bool bracket = timed_here && !time_generic && n_launches > 1;
+      if (bracket) HIP_TRY(hipEventRecord(e0, stream));
+      L.stage_buf = nullptr; L.staged_on = 0;
+      if (staged) {
+        L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 2 : 1;
+        HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
+      }
+      if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
+      if (bracket) HIP_TRY(hipEventRecord(e1, stream));
+      L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
+      if (!generic_idle) HIP_TRY(pg_launch_units(L, stream, timed_here && time_generic ? e0 : nullptr, timed_here && time_generic ? e1 : nullptr));
+    } else {
+      L.mode = 0;
+      if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
+      HIP_TRY(pg_launch_units(L, stream, e0, e1));
     }
-    if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
-    if (bracket) HIP_TRY(hipEventRecord(e1, stream));
-    L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
-    if (!generic_idle) HIP_TRY(pg_launch_units(L, stream, timed && time_generic ? e0 : nullptr, timed && time_generic ? e1 : nullptr));
-  } else {
-    L.mode = 0;
-    if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
-    HIP_TRY(pg_launch_units(L, stream, e0, e1));
   }
   if (timed) g->ev_used++;
   L.mode = 0;
-  HIP_TRY(pg_launch_mix(g->d_unit_out, g->stride, g->n_graph_units, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d, g->d_audible, stream));
+  // the main mixer sums the rows of its own sub-mixers and sources: the last level
+  const Level& top = g->levels.back();
+  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d + top.off, g->d_audible, stream));
   if (run_bus && !g->mixers[0].fx.empty()) {
     PgLaunch B = L;
     B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
@@ -1032,6 +1095,34 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
         g->mixers[m].messages.clear();
       }
       first = false;
+    }
+    // Nested sub-mixers: a mixer that splits its block at an event calls its sub-mixers once per segment (mixed.rs:679-712), so
+    // every event of a mixer with sub-mixers is also a call boundary (CMD_CALL_SPLIT) for all its descendants. A sub-mixer keeps
+    // one result bit per call: the round is bounded so that at most PG_MAX_CALLS - 1 boundaries fall inside it.
+    if (g->levels.size() > 1) {
+      std::vector<uint64_t> cuts;
+      for (size_t m = 1; m < g->mixers.size(); ++m) {
+        if (g->mixers[m].children.empty()) continue;
+        for (const Event& e : g->mixers[m].events) { if (e.sample_time >= now + n) break; if (e.sample_time > now) cuts.push_back(e.sample_time); }
+      }
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+      if (cuts.size() > (size_t)(PG_MAX_CALLS - 1)) n = cuts[PG_MAX_CALLS - 1] - now;
+      for (size_t m = 1; m < g->mixers.size(); ++m) {
+        if (g->mixers[m].children.empty()) continue;
+        std::vector<int> desc(g->mixers[m].children);
+        for (size_t i = 0; i < desc.size(); ++i) for (int c : g->mixers[desc[i]].children) desc.push_back(c);
+        for (const Event& e : g->mixers[m].events) {
+          if (e.sample_time >= now + n) break;
+          if (e.sample_time <= now) continue;
+          for (int d : desc) {
+            PgCmd c;
+            memset(&c, 0, sizeof c);
+            c.type = CMD_CALL_SPLIT; c.unit = g->mixers[d].unit_slot; c.frame = (uint32_t)(e.sample_time - now);
+            cmds.push_back(c);
+          }
+        }
+      }
     }
     // sub-mixer events inside [now, now+n): each sub-mixer splits its own block on the device
     for (size_t m = 1; m < g->mixers.size(); ++m) {

@@ -280,6 +280,28 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
 // dynamic LDS: [sig 2*n_frames f32][tmp 2*n_frames f32][scratch]
 extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 
+// SubMixerProcessor::process (src/source/mixed/submixer.rs:47-77) for frames [a, b) of the block = one write() call of this
+// sub-mixer: silence gate on the call's peak, then the call's samples (or silence) go to the unit's output row. Returns whether the
+// call produced output. (A sub-mixer without sources, effects or events returns 0 samples: max over an empty slice = 0 -> silent.)
+__device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* sig, float* out, int a, int b, uint32_t sample_rate, int* ctl, float* red) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const float max_sample = wg_max_abs(sig + 2 * a, 2 * (b - a), red);
+  if (tid == 0) {
+    int audible;
+    if (max_sample < 0.001f) {
+      unit.silence_counter += (uint64_t)(b - a);
+      audible = unit.silence_counter < 2ull * (uint64_t)sample_rate ? 1 : 0;
+    } else { unit.silence_counter = 0; audible = 1; }
+    ctl[3] = audible;
+  }
+  __syncthreads();
+  const bool audible = ctl[3] != 0;
+  if (audible) { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = sig[i]; }
+  else { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = 0.0f; }
+  __syncthreads();
+  return audible;
+}
+
 template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) {
   if (slot >= L.n_units) return;
@@ -343,10 +365,25 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
   while (ci < L.n_cmds && L.cmds[ci].unit < u) ++ci;
   int frame0 = 0;
   bool any_audible = false;
+  // nested sub-mixers: an ancestor that splits its block at events calls this unit once per segment (CMD_CALL_SPLIT marks the
+  // boundaries); the silence gate and the `audible` result are per call. Only the generic kernel sees more than one call.
+  float* const out = external ? nullptr : L.unit_out + (size_t)slot * L.out_stride;
+  int call_start = 0, call_idx = 0, seg_idx = 0;
+  unsigned long long call_mask = 0;
   while (frame0 < N) {
     // apply all commands due at frame0 (process_events, event.rs:41-50)
     while (!FAST_ONLY && ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {  // (the fast kernel defers units with commands)
       const PgCmd cmd = L.cmds[ci];
+      if (cmd.type == CMD_CALL_SPLIT) {
+        if (frame0 > call_start && unit.kind == UNIT_SUBMIXER && call_idx < PG_MAX_CALLS - 1) {
+          __syncthreads();
+          if (submixer_finish_call(unit, sig, out, call_start, frame0, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
+          ++call_idx;
+          call_start = frame0;
+        }
+        ++ci;
+        continue;
+      }
       int flush = 0;
       __syncthreads();
       if (tid == 0) {
@@ -374,6 +411,17 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
       audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (*L.bus_audible != 0) : true);
     } else {
       audible_input = false;
+      if (!FAST_ONLY && unit.n_children > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
+        const int k = seg_idx < PG_MAX_CALLS - 1 ? seg_idx : PG_MAX_CALLS - 1;
+        for (int c = 0; c < unit.n_children; ++c) {
+          const int2 cr = L.child_rows[unit.child_off + c];
+          const float* row = L.rows_base + (size_t)cr.x * L.out_stride + 2 * frame0;
+          for (int i = tid; i < 2 * seg; i += nt) sseg[i] += row[i];
+          const PgUnit& cu = L.units[cr.y];
+          audible_input |= k == 0 ? cu.audible != 0 : ((cu.call_audible >> k) & 1ull) != 0;
+        }
+        __syncthreads();
+      }
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
         audible_input |= voice_process<!FAST_ONLY>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
@@ -408,6 +456,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
     }
     any_audible |= audible_input;
     frame0 = frame1;
+    ++seg_idx;
     __syncthreads();
   }
 
@@ -426,23 +475,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
     for (int i = tid; i < 2 * N; i += nt) ext[i] = sig[i];
     return;
   }
-  float* out = L.unit_out + (size_t)slot * L.out_stride;
   if (unit.kind == UNIT_SUBMIXER) {
-    // SubMixerProcessor::process  src/source/mixed/submixer.rs:47-77. (A sub-mixer without sources, effects or
-    // events returns 0 samples: max over an empty slice = 0 -> counts as silent.)
-    float max_sample = wg_max_abs(sig, 2 * N, red);
+    if (submixer_finish_call(unit, sig, out, call_start, N, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
     if (tid == 0) {
-      int audible;
-      if (max_sample < 0.001f) {
-        unit.silence_counter += (uint64_t)N;
-        audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
-      } else { unit.silence_counter = 0; audible = 1; }
-      unit.audible = audible;
-      ctl[3] = audible;
+      unit.audible = (int)(call_mask & 1ull);  // the first call; later calls of the round (nested sub-mixers only) in call_audible
+      if (!FAST_ONLY) unit.call_audible = call_mask;
     }
-    __syncthreads();
-    if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
-    else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
   } else {
     for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
     if (tid == 0) unit.audible = any_audible ? 1 : 0;

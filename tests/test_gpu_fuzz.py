@@ -95,3 +95,69 @@ def test_random_graph_matches_oracle(seed):
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
     assert float(np.abs(d).max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_nested_graph_matches_oracle(seed):
+    """Player::add_mixer(parent): random mixer trees up to depth 4. Events on a mixer with sub-mixers (effect parameters, voice
+    volume) split its block, and with it the write() calls its sub-mixers see (per-call silence gate and bypass logic)."""
+    from phonic_amd.graph import Graph, effect_parameters
+
+    rng = np.random.default_rng(5000 + seed)
+    descs = {k: effect_parameters(k) for k in range(10)}
+    mixers = []  # (parent index into `mixers` or -1 for main, chain, voices)
+    for m in range(int(rng.integers(2, 7))):
+        parent = -1 if m == 0 or rng.random() < 0.3 else int(rng.integers(0, m))
+        chain = []
+        for _ in range(int(rng.integers(0, 3))):
+            k = int(rng.integers(0, 10))
+            chain.append((k, random_params(rng, k, descs[k]), int(rng.integers(0, 1000))))
+        if rng.random() < 0.4:
+            chain.append((_capi.FX_REVERB, random_params(rng, _capi.FX_REVERB, descs[_capi.FX_REVERB]), int(rng.integers(0, 1000))))
+        voices = [(int(rng.integers(0, 60)), int(rng.choice([44100, 48000, 32000])), float(rng.uniform(0.2, 0.8)), float(rng.uniform(-1, 1)))
+                  for _ in range(int(rng.integers(0, 3)))]
+        mixers.append((parent, chain, voices))
+    if not any(v for _, _, v in mixers):
+        mixers[-1] = (mixers[-1][0], mixers[-1][1], [(5, 44100, 0.5, 0.0)])
+    sizes = [int(rng.choice([1024, 1024, 512, 700, 333])) for _ in range(8)]
+    n_events = int(rng.integers(2, 9))
+    ev_plan = [(int(rng.integers(1, len(sizes))), float(rng.random()), int(rng.integers(0, 1 << 30)), float(rng.uniform(0.1, 0.9))) for _ in range(n_events)]
+
+    outs = []
+    for which in ("gpu", "oracle"):
+        g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
+        ids, fx_ids, voice_ids = [], [], []
+        for parent, chain, voices in mixers:
+            m = g.add_mixer(None if parent < 0 else ids[parent])
+            ids.append(m)
+            for (k, p, s) in chain:
+                fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+            for (ti, rate, vol, pan) in voices:
+                voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            for (eb, frac, pick, val) in ev_plan:
+                if eb != b:
+                    continue
+                t = pos + int(frac * n)
+                if fx_ids and pick % 2 == 0:
+                    fid, k = fx_ids[(pick >> 1) % len(fx_ids)]
+                    d = descs[k][0]
+                    if d["type"] == 0:
+                        g.schedule_param(fid, fourcc_str(d["fourcc"]), val, t, normalized=True)
+                        continue
+                g.set_voice_volume(voice_ids[(pick >> 1) % len(voice_ids)], val, t)
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) in (0, 2 * n)
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+    a, b = outs
+    assert np.isfinite(a).all()
+    if float(np.abs(b).max()) <= 1e-4:
+        assert float(np.abs(a).max()) <= 1e-4
+        pytest.skip("silent case")
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
+    assert float(np.abs(d).max()) <= 1e-4 * scale

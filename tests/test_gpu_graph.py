@@ -427,3 +427,62 @@ def test_sharded_voices_with_deferred_bus_and_bus_automation():
     compare(sharded, outs[1])
     assert float(np.abs(sharded - outs[0]).max()) <= 1e-5
     assert np.abs(sharded).max() > 1e-3
+
+
+def test_nested_submixers_tree():
+    """Player::add_mixer(parent) (src/player.rs:771-822): main -> group (Eq5, Compressor, own voice) -> {reverb send, filter+chorus
+    lane} -> a third level under the lane. The parent sums its sub-mixers in the order they were added, then its sources, then
+    runs its chain (mixed.rs:696-703)."""
+    def build(g):
+        group = g.add_mixer()
+        g.add_effect(group, _capi.FX_EQ5, params={"gan1": 3.0, "gan4": -4.0})
+        g.add_effect(group, _capi.FX_COMPRESSOR, params={"thrs": -24.0, "rato": 4.0})
+        send = g.add_mixer(group)
+        g.add_effect(send, _capi.FX_GAIN, params={"gain": 0.7})
+        g.add_effect(send, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(3))
+        g.add_voice(send, workloads.tone_buffer(7, 44100, 0.2), 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        lane = g.add_mixer(group)
+        g.add_effect(lane, _capi.FX_FILTER, params={"cuto": 1800.0})
+        g.add_effect(lane, _capi.FX_CHORUS)
+        g.add_voice(lane, workloads.tone_buffer(19, 48000, 0.2), 2, 48000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        leaf = g.add_mixer(lane)
+        g.add_effect(leaf, _capi.FX_DISTORTION, params={"driv": 0.6})
+        g.add_voice(leaf, workloads.tone_buffer(31, 32000, 0.2), 2, 32000, panning=-0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_voice(group, workloads.tone_buffer(2, 48000, 0.2), 2, 48000, panning=0.4, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        other = g.add_mixer()
+        g.add_effect(other, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(9))
+        g.add_voice(other, workloads.tone_buffer(40, 44100, 0.2), 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_voice(0, workloads.tone_buffer(11, 48000, 0.1), 2, 48000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.9})
+        return {}
+    a, b = both(build, 12, 1024, max_frames=1024)
+    assert float(np.abs(b).max()) > 0.05
+    compare(a, b)
+
+
+def test_nested_submixer_events_split_child_calls():
+    """Events on a mixer with sub-mixers split its block (mixed.rs:679-712) and so the write() calls of its sub-mixers: the nested
+    one-shot voice ends, its delay tail runs out and the per-call silence gate (submixer.rs:47-77) closes while the parent keeps
+    receiving parameter and voice events at odd frames. Unknown parent ids are rejected."""
+    def build(g):
+        group = g.add_mixer()
+        fx = g.add_effect(group, _capi.FX_FILTER, params={"cuto": 4000.0})
+        own = g.add_voice(group, workloads.tone_buffer(12, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        child = g.add_mixer(group)
+        g.add_effect(child, _capi.FX_DELAY, params={"dlay": 40.0, "fdbk": 0.4})
+        g.add_voice(child, workloads.tone_buffer(4, 48000, 0.05), 2, 48000)
+        grand = g.add_mixer(child)
+        cfx = g.add_effect(grand, _capi.FX_GAIN, params={"gain": 0.5})
+        g.add_voice(grand, workloads.tone_buffer(25, 44100, 0.04), 2, 44100)
+        with pytest.raises(Exception):
+            g.add_mixer(99)
+        return {"fx": fx, "own": own, "cfx": cfx}
+
+    def ev(g, ids, pos):
+        g.schedule_param(ids["fx"], "cuto", 0.2 + 0.01 * (pos % 7), pos + 301, normalized=True)
+        g.set_voice_volume(ids["own"], 0.4, pos + 777)
+        g.set_voice_volume(ids["own"], 0.6, pos + 777)
+        g.schedule_param(ids["cfx"], "gain", 0.3, pos + 500, normalized=True)
+    actions = {k: ev for k in (1, 2, 5, 30, 60, 100, 101, 102, 110)}
+    a, b = both(build, 112, 1024, actions=actions, max_frames=1024)
+    compare(a, b)

@@ -103,3 +103,24 @@ def test_normalized_parameter_updates():
     y = workloads.test_signal(4096, seed=1)
     e2.process(y)
     np.testing.assert_allclose(x, y, atol=1e-6)
+
+
+def test_nested_mixers_without_effects_equal_the_flat_sum():
+    """Player::add_mixer(parent) (player.rs:771-822): a chain of effect-less sub-mixers only passes the block up (x + 0 is exact),
+    so main -> A -> B -> voice renders exactly what main -> voice does; unknown parents are rejected."""
+    buf = workloads.tone_buffer(9, 44100, 0.2)
+    flat, nested = oracle.OracleGraph(SR, 2), oracle.OracleGraph(SR, 2)
+    flat.add_voice(0, buf, 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    a = nested.add_mixer()
+    b = nested.add_mixer(a)
+    assert b != a
+    nested.add_voice(b, buf, 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    try:
+        nested.add_mixer(77)
+        assert False, "unknown parent accepted"
+    except Exception:
+        pass
+    for blk in range(4):
+        x, y = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+        assert flat.write(x, blk * 1024) == 2048 and nested.write(y, blk * 1024) == 2048
+        assert np.array_equal(x, y) and float(np.abs(x).max()) > 0.01
