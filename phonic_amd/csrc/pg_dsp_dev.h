@@ -280,6 +280,18 @@ DEV float env_run(float& current, float attack_coeff, float release_coeff, float
 DEV float env_coeff(float t, uint32_t sr) { return (t > 0.0f) ? expf(-1.0f / (t * (float)sr)) : 0.0f; }  // :27-42
 
 // workgroup max-reduction of |x| over an LDS buffer (max_abs_sample, src/utils/buffer.rs:150-173; order free)
+// Asynchronous global -> LDS copy of one dword per lane (global_load_lds_dword): lane l of the wave writes lds_wave_base[l]. The
+// instruction is issued from inline asm on purpose: the compiler counts a tracked LDS-DMA as pending LDS stores and drains it
+// (s_waitcnt vmcnt(0)) at the next workgroup barrier, which would turn the copy back into a blocking load. The caller waits with
+// lds_dma_wait() before a barrier that precedes the first read; in between the transfer is invisible to the compiler, whose own
+// vmcnt waits stay conservative (loads return in order). M0 is saved and restored around the transfer.
+__device__ __forceinline__ void lds_dma_dword(const float* g, float* lds_wave_base) {
+  const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(a), "v"(g));
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 DEVO float wg_max_abs(const float* buf, int n, float* red /* LDS, >= blockDim.x/64 floats */) {
   float m = 0.0f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(buf[i]));

@@ -554,9 +554,11 @@ constexpr size_t STAGE_FIXED = ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
 constexpr size_t STAGE1_UNION = ((SRC_SCRATCH_BYTES > STAGE_ARENA_PREFIX ? SRC_SCRATCH_BYTES : STAGE_ARENA_PREFIX) + 15) & ~15ull;
 
 struct StageLds { PgFx* lfx; int* ctl; float* red; char* arena; };
-__device__ __forceinline__ StageLds stage_lds() {
+// `base`: the dynamic LDS of the kernel. An out-of-line stage function gets it as an argument: naming pg_smem there makes the
+// compiler look the kernel's LDS offset up in a table in global memory — a dependent load at the top of the stage.
+__device__ __forceinline__ StageLds stage_lds(char* base = pg_smem) {
   StageLds m;
-  char* p = pg_smem;
+  char* p = base;
   m.lfx = (PgFx*)p;   p += (sizeof(PgFx) + 15) & ~15ull;
   m.ctl = (int*)p;    p += 128;
   m.red = (float*)p;  p += 64;
@@ -567,8 +569,10 @@ __device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& u
 
 // Stage 1. RESIDENT: the later stages run in the same launch (bufA and the effect state stay in LDS). Returns false when the
 // unit was deferred to the generic kernel.
+// Returns the unit's stage flags (PG_STAGE_*, also left in the unit record for the per-stage launches), or -1 when the unit was
+// deferred to the generic kernel.
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
+__device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot) {
   // one load names the unit, its first voice and its reverb: their state blocks are then fetched side by side
   const int4 si = L.slot_info[slot];
   const int u = si.x;
@@ -603,7 +607,7 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
     ctl[5] = ok;
   }
   __syncthreads();
-  if (!ctl[5]) return false;
+  if (!ctl[5]) return -1;
   // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
   const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
   for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
@@ -652,7 +656,7 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
     if (!RESIDENT || !(flags & PG_STAGE_ACTIVE)) for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
   }
   for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];  // the dry signal waits in the unit's output row
-  if (tid == 0) unit.stage_flags = flags;
+  if (!RESIDENT && tid == 0) unit.stage_flags = flags;  // (the single-launch kernels hand the flags over in registers)
   PG_STAMP(L.diag, 14);
   // schedule cache (ratio < 0.5 only): representatives replay the next block's resampler schedule. A single voice that took the
   // time-parallel schedule needs nothing published — decided from its LDS copy, without a trip to the voice table.
@@ -661,7 +665,7 @@ __device__ __forceinline__ bool stage1_run(const PgLaunch& L, int slot) {
     for (int vi = 0; vi < n_voices; ++vi) sched_publish(&L.voices[L.voice_index[voice_off + vi]], L.sched, L.sched_bank, piece);
   }
   PG_STAMP(L.diag, 13);
-  return true;
+  return flags;
 }
 
 template <int TAG, bool RESIDENT>
@@ -694,22 +698,31 @@ __device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flag
 }
 
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags) {
-  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
-  PgUnit& unit = L.units[u];
+__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags, char* smem = pg_smem) {
+  // one load names the unit and its reverb (as in stage 1); it is issued ahead of the dry-signal transfer below so that waiting
+  // for it does not wait for the transfer (loads return in order)
+  const int4 si = L.slot_info[slot];
+  PgUnit& unit = L.units[si.x];
+  PgFx& gfx = L.fx[si.z];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = (int)L.n_frames;
   float* out = L.unit_out + (size_t)slot * L.out_stride;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
-  const StageLds m0 = stage_lds();
+  const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
   float* sig = (float*)(m0.arena + ((STAGE_ARENA_PREFIX + 15) & ~15ull));
   __syncthreads();
-  for (int i = tid; i < 2 * N; i += nt) sig[i] = out[i];
+  // The dry signal (stage 1 left it in the unit's output row) is only needed at the end of the tail. It travels global -> LDS
+  // directly (lds_dma_dword: no registers, no wait here) while the two scans run; a dependent load at this point would cost a
+  // full trip through the loaded memory system. Lane l of wave w, trip k: sample k * 256 + w * 64 + l.
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid + k * 256;
+    if (i < 2 * N) lds_dma_dword(out + i, sig + k * 256 + (tid & ~63));
+  }
   if (!(flags & PG_STAGE_SKIPPED)) {
     bool all_bypassed = (flags & PG_STAGE_ALL_BYPASSED) != 0;
     if (flags & PG_STAGE_ACTIVE) {
-      PgFx& gfx = stage_reverb(L, unit);
       const RevLds m = rev_lds(m0.arena);
       if (!RESIDENT) {
         for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
@@ -718,7 +731,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       __syncthreads();
       RevBlock b;
       (void)rev_block_params(*lfx, m, ctl, b);
-      rev_tail(lfx->u.reverb, sig, N, m, b, L.diag);
+      rev_tail_impl<true>(lfx->u.reverb, sig, N, m, b, L.diag);
       PG_STAMP(L.diag, 60);
       if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, L.sample_rate, ctl, red);
       PG_STAMP(L.diag, 61);
@@ -729,27 +742,23 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
     __syncthreads();
     if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
   }
+  lds_dma_wait();  // (bypassed / skipped reverb: the dry signal is the output)
   __syncthreads();
   PG_STAMP(L.diag, 62);
-  // ---- hand the block to the parent mixer (same as the fused kernel) ----
-  if (unit.kind == UNIT_SUBMIXER) {
-    float max_sample = wg_max_abs(sig, 2 * N, red);
-    if (tid == 0) {
-      int audible;
-      if (max_sample < 0.001f) {
-        unit.silence_counter += (uint64_t)N;
-        audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
-      } else { unit.silence_counter = 0; audible = 1; }
-      unit.audible = audible;
-      ctl[3] = audible;
-    }
-    __syncthreads();
-    if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
-    else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
-  } else {
-    for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
-    if (tid == 0) unit.audible = (flags & PG_STAGE_AUDIBLE) ? 1 : 0;
+  // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77) ----
+  float max_sample = wg_max_abs(sig, 2 * N, red);
+  if (tid == 0) {
+    int audible;
+    if (max_sample < 0.001f) {
+      unit.silence_counter += (uint64_t)N;
+      audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
+    } else { unit.silence_counter = 0; audible = 1; }
+    unit.audible = audible;
+    ctl[3] = audible;
   }
+  __syncthreads();
+  if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
+  else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
   PG_STAMP(L.diag, 15);
 }
 
@@ -790,9 +799,9 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch
 #define PG_STAGE_OUTLINE 4
 #endif
 #if PG_STAGE_OUTLINE & 1
-static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
+static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot); }
 #else
-__device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot) ? 1 : 0; }
+__device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot); }
 #endif
 #if PG_STAGE_OUTLINE & 2
 static __device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
@@ -800,10 +809,19 @@ static __device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int
 __device__ __forceinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
 #endif
 #if PG_STAGE_OUTLINE & 4
-static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
+typedef __attribute__((address_space(3))) char* PgLdsPtr;
+static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem) { stage3_run<2, true>(*L, slot, flags, (char*)smem); }
 #else
-__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags) { stage3_run<2, true>(*L, slot, flags); }
+typedef __attribute__((address_space(3))) char* PgLdsPtr;
+__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem) { stage3_run<2, true>(*L, slot, flags, (char*)smem); }
 #endif
+// The kernel's dynamic LDS as an opaque value: handed to the out-of-line stage as is, constant propagation would put the name
+// pg_smem (and with it the offset-table lookup) back into the callee.
+__device__ __forceinline__ PgLdsPtr stage_smem_arg() {
+  uint32_t a = (uint32_t)(uintptr_t)(PgLdsPtr)pg_smem;
+  asm volatile("" : "+s"(a));
+  return (PgLdsPtr)(uintptr_t)a;
+}
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units) return;
   if (!stage_unit_staged<1>(L, blockIdx.x)) return;
@@ -818,15 +836,14 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
 #endif
   PG_SLOT_STAMP(0);
   // inlined stages read the launch structure from the kernel arguments (scalar registers), out-of-line ones from the LDS copy
-  if (!(((PG_STAGE_OUTLINE >> 0) & 1) ? stage1_call(&sL, slot) : (int)stage1_run<2, true>(L, slot))) return;
+  const int flags = ((PG_STAGE_OUTLINE >> 0) & 1) ? stage1_call(&sL, slot) : stage1_run<2, true>(L, slot);
+  if (flags < 0) return;  // deferred to the generic kernel
   __syncthreads();
   PG_SLOT_STAMP(1);
-  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
-  const int flags = L.units[u].stage_flags;
   if ((PG_STAGE_OUTLINE >> 1) & 1) stage2_call(&sL, slot, flags); else stage2_run<2, true>(L, slot, flags);
   __syncthreads();
   PG_SLOT_STAMP(2);
-  if ((PG_STAGE_OUTLINE >> 2) & 1) stage3_call(&sL, slot, flags); else stage3_run<2, true>(L, slot, flags);
+  if ((PG_STAGE_OUTLINE >> 2) & 1) stage3_call(&sL, slot, flags, stage_smem_arg()); else stage3_run<2, true>(L, slot, flags);
   PG_SLOT_STAMP(3);
 }
 
@@ -839,13 +856,12 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kerne
   for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
   __syncthreads();
   const int slot = blockIdx.x;
-  if (!stage1_run<3, true>(L, slot)) return;
+  const int flags = stage1_run<3, true>(L, slot);
+  if (flags < 0) return;
   __syncthreads();
-  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
-  const int flags = L.units[u].stage_flags;
   stage2_run<3, true>(L, slot, flags);
   __syncthreads();
-  stage3_call(&sL, slot, flags);
+  stage3_call(&sL, slot, flags, stage_smem_arg());
 }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------

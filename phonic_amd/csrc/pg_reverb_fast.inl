@@ -532,7 +532,10 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
 }
 
 // ---- tail: biquad B -> clamp -> asin -> biquad C -> dry mix (reverb.rs:340-368) ----
-DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
+// DRY_DMA: the dry signal is still on its way into s0 (lds_dma_dword transfers issued by the staged kernel when the stage began):
+// the wait sits behind the two scans, in front of the barrier that precedes the first read.
+template <bool DRY_DMA>
+DEVO void rev_tail_impl(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
   const int tid = threadIdx.x, nt = blockDim.x;
   double* bufA = m.bufA;
   const double wet = b.wet;
@@ -544,6 +547,7 @@ DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBloc
   __syncthreads();
   PG_STAMP(diag, 58);
   rev_biquad_scan(r.cc, r.sc, bufA, T, m.xchg);
+  if (DRY_DMA) lds_dma_wait();
   __syncthreads();
   PG_STAMP(diag, 59);
   for (int s = tid; s < 2 * T; s += nt) {
@@ -554,6 +558,7 @@ DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBloc
   __syncthreads();
   PG_STAMP(diag, 7);
 }
+DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) { rev_tail_impl<false>(r, s0, T, m, b, diag); }
 
 DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgReverb& r = fx.u.reverb;

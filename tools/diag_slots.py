@@ -31,3 +31,13 @@ tot=us[:,3]-us[:,0]
 print("per-WG total us: min %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(tot,[0,50,90,100])))
 late=np.argsort(us[:,0])[-8:]
 print("latest starters (slot, start, end):", [(int(s), round(float(us[s,0]),1), round(float(us[s,3]),1)) for s in late])
+# where do the slow workgroups sit? (dispatch order: workgroup i -> XCD i % 8)
+d2=us[:,2]-us[:,1]
+slots=np.arange(V)
+print("stage2 p50 by XCD (slot % 8):", [round(float(np.median(d2[slots%8==x])),1) for x in range(8)])
+print("end    p50 by XCD (slot % 8):", [round(float(np.median(us[slots%8==x,3])),1) for x in range(8)])
+print("stage2 p50 by dispatch quarter (slot // 256):", [round(float(np.median(d2[slots//256==q])),1) for q in range(4)])
+print("end    p50 by dispatch quarter:", [round(float(np.median(us[slots//256==q,3])),1) for q in range(4)])
+print("end    max by dispatch quarter:", [round(float(np.max(us[slots//256==q,3])),1) for q in range(4)])
+h,_=np.histogram(us[:,3],bins=np.arange(80,140,5)); print("ends histogram 80..135 step 5 us:", h.tolist())
+print("stage-1 end p50/p90/max: %.1f %.1f %.1f ; stage-2 end p50/p90/max: %.1f %.1f %.1f" % (tuple(np.percentile(us[:,1],[50,90,100]))+tuple(np.percentile(us[:,2],[50,90,100]))))
