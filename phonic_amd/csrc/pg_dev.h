@@ -269,7 +269,7 @@ struct PgLaunch {
   int32_t sched_bank;     // bank read by this launch; the representatives write bank ^ 1
   unsigned long long* diag;  // diagnostic builds (-DPG_DIAG): shader-clock stamps of workgroup 0, else unused
   double* stage_buf;      // [n_units][PG_STAGE_BUF_DOUBLES] f64 hand-over buffer of the staged pipeline (nullptr: pipeline off)
-  const int4* slot_info;  // [n_units] per launch slot: {unit slot, device index of the first voice, device index of the last effect, number of voices}
+  const int4* slot_info;  // [n_units] per launch slot: {unit slot, device index of the first voice, device index of the last effect, number of voices | PgUnit::staged << 24}
   int32_t* defer_count;   // fast kernels append the launch slots they defer: count of this round ...
   int32_t* defer_list;    // ... and the slots; the generic kernel (mode 2) walks the list
   int32_t* defer_reset;   // the other round's counter, zeroed by the generic kernel for the next round

@@ -578,7 +578,7 @@ static int rebuild_topology(pg_graph* g) {
     std::vector<int4> info;
     for (int slot : g->order) {
       const PgUnit& u = topo[slot];
-      info.push_back(make_int4(slot, u.voice0, u.n_fx > 0 ? fidx[u.fx_off + u.n_fx - 1] : 0, u.n_voices));
+      info.push_back(make_int4(slot, u.voice0, u.n_fx > 0 ? fidx[u.fx_off + u.n_fx - 1] : 0, (u.n_voices & 0xffffff) | (u.staged << 24)));
     }
     int rc0;
     if ((rc0 = g->d_slot_info.upload(info))) return rc0;

@@ -572,9 +572,9 @@ __device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& u
 // Returns the unit's stage flags (PG_STAGE_*, also left in the unit record for the per-stage launches), or -1 when the unit was
 // deferred to the generic kernel.
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot) {
-  // one load names the unit, its first voice and its reverb: their state blocks are then fetched side by side
-  const int4 si = L.slot_info[slot];
+__device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int4 si) {
+  // `si` = L.slot_info[slot], loaded by the kernel: one load names the unit, its first voice and its reverb (and the unit's staged
+  // level): their state blocks are then fetched side by side
   const int u = si.x;
   PgUnit& unit = L.units[u];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -583,7 +583,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot) {
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   PgFx& gfx = L.fx[si.z];
   uint32_t voice_word = 0;
-  if (si.w > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
+  if ((si.w & 0xffffff) > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
   unsigned long long fxr_word = 0;  // the reverb's state block (one qword per lane), used after the source stage
   if (tid < n_fx_words / 2) fxr_word = ((const unsigned long long*)&gfx)[tid];
   const StageLds m0 = stage_lds();
@@ -772,6 +772,13 @@ __device__ __forceinline__ bool stage_unit_staged(const PgLaunch& L, int slot) {
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   return L.units[u].staged == LEVEL;
 }
+// the same from the slot-info word (the single-launch kernels start from that one load)
+__device__ __forceinline__ int4 stage_slot_info(const PgLaunch& L, int slot) {
+  int4 si = L.slot_info[slot];
+  si.x = __builtin_amdgcn_readfirstlane(si.x); si.y = __builtin_amdgcn_readfirstlane(si.y);
+  si.z = __builtin_amdgcn_readfirstlane(si.z); si.w = __builtin_amdgcn_readfirstlane(si.w);
+  return si;
+}
 __device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, bool& deferred) {
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   deferred = L.units[u].deferred != 0;
@@ -779,7 +786,7 @@ __device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, boo
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage1_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
-  (void)stage1_run<1, false>(L, blockIdx.x);
+  (void)stage1_run<1, false>(L, blockIdx.x, stage_slot_info(L, blockIdx.x));
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage2_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
@@ -799,9 +806,9 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch
 #define PG_STAGE_OUTLINE 4
 #endif
 #if PG_STAGE_OUTLINE & 1
-static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot); }
+static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot, stage_slot_info(*L, slot)); }
 #else
-__device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot); }
+__device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot, stage_slot_info(*L, slot)); }
 #endif
 #if PG_STAGE_OUTLINE & 2
 static __device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
@@ -824,11 +831,13 @@ __device__ __forceinline__ PgLdsPtr stage_smem_arg() {
 }
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units) return;
-  if (!stage_unit_staged<1>(L, blockIdx.x)) return;
-  __shared__ PgLaunch sL;
-  for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
-  __syncthreads();
   const int slot = blockIdx.x;
+  const int4 si = stage_slot_info(L, slot);
+  if ((si.w >> 24) != 1) return;
+  // the launch structure for the out-of-line stage: written by one lane from the scalar registers the arguments arrive in (no
+  // trip to memory); the barriers in front of that stage make it visible
+  __shared__ PgLaunch sL;
+  if (threadIdx.x == 0) sL = L;
 #ifdef PG_DIAG
 #define PG_SLOT_STAMP(i) do { if (L.diag && threadIdx.x == 0 && slot < 4096) L.diag[64 + 4 * slot + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -836,7 +845,7 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
 #endif
   PG_SLOT_STAMP(0);
   // inlined stages read the launch structure from the kernel arguments (scalar registers), out-of-line ones from the LDS copy
-  const int flags = ((PG_STAGE_OUTLINE >> 0) & 1) ? stage1_call(&sL, slot) : stage1_run<2, true>(L, slot);
+  const int flags = stage1_run<2, true>(L, slot, si);
   if (flags < 0) return;  // deferred to the generic kernel
   __syncthreads();
   PG_SLOT_STAMP(1);
@@ -851,12 +860,12 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgL
 // C5's per-voice Filter -> Eq5 -> Delay -> Reverb). A kernel of its own so that the lean one keeps its register allocation.
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units) return;
-  if (!stage_unit_staged<2>(L, blockIdx.x)) return;
-  __shared__ PgLaunch sL;
-  for (int i = threadIdx.x; i < (int)(sizeof(PgLaunch) / 4); i += blockDim.x) ((uint32_t*)&sL)[i] = ((const uint32_t*)&L)[i];
-  __syncthreads();
   const int slot = blockIdx.x;
-  const int flags = stage1_run<3, true>(L, slot);
+  const int4 si = stage_slot_info(L, slot);
+  if ((si.w >> 24) != 2) return;
+  __shared__ PgLaunch sL;
+  if (threadIdx.x == 0) sL = L;
+  const int flags = stage1_run<3, true>(L, slot, si);
   if (flags < 0) return;
   __syncthreads();
   stage2_run<3, true>(L, slot, flags);
