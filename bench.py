@@ -155,7 +155,12 @@ def main():
     # the render of block b+1 on the compute stream
     buses = [torch.zeros(n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
     pending = [None, None]
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
+    # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
+    render_stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(render_stream)
+    stream = render_stream.cuda_stream
     pos = 0
     step_no = 0
 

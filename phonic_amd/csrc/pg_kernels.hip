@@ -913,6 +913,50 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
   *(float4*)(bus + (size_t)s4 * 4) = acc;
 }
 
+// Both stages in one launch (the usual case, <= 4096 units): a workgroup of 256 lanes owns PG_MIX_COLS float4 columns; lane
+// (sub, col) sums the 16 units of group sub, sub + 64, ... for its column — the same partial sums, in the same order, as
+// pg_mix_kernel_1 — into LDS, then the lanes of sub 0 add the groups' partials in order as pg_mix_kernel_2 does. Bit-identical to
+// the two-launch path; one launch gap and one trip of the partials through HBM less.
+#define PG_MIX_MAX_GROUPS 256
+#define PG_MIX_COLS 4
+__global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ unit_out, uint32_t stride, int n_units, int n_groups, float* __restrict__ bus,
+                                                      int n_vec4, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out) {
+  __shared__ float4 part[PG_MIX_MAX_GROUPS][PG_MIX_COLS];
+  const int t = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags
+    if (!audible_out || t >= 64) return;
+    int a = 0;
+    for (int u = t; u < n_units; u += 64) a |= units[order[u]].audible;
+    for (int off = 32; off > 0; off >>= 1) a |= __shfl_xor(a, off, 64);
+    if (t == 0) *audible_out = a;
+    return;
+  }
+  const int col = t & (PG_MIX_COLS - 1), sub = t / PG_MIX_COLS;  // 64 sub-groups
+  const int s4 = blockIdx.x * PG_MIX_COLS + col;
+  if (s4 < n_vec4) {
+    for (int g = sub; g < n_groups; g += 64) {
+      const int u0 = g * 16;
+      const int u1 = u0 + 16 < n_units ? u0 + 16 : n_units;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 16
+      for (int u = u0; u < u1; ++u) {
+        const float4 v = *(const float4*)(unit_out + (size_t)u * stride + (size_t)s4 * 4);
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+      }
+      part[g][col] = acc;
+    }
+  }
+  __syncthreads();
+  if (sub == 0 && s4 < n_vec4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < n_groups; ++g) {
+      const float4 v = part[g][col];
+      acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+    }
+    *(float4*)(bus + (size_t)s4 * 4) = acc;
+  }
+}
+
 // ---- host-callable launchers (C++ linkage, used by pg_host.cpp) ------------------------------------------
 size_t pg_unit_lds_bytes(uint32_t n_frames) {
   size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
@@ -978,6 +1022,10 @@ hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, fl
   int group = 16;
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
+  if (n_groups <= PG_MIX_MAX_GROUPS) {
+    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, n_vec4, units, order, audible_out);
+    return hipGetLastError();
+  }
   dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
   hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out, stride, n_units, group, partial, n_vec4);
   hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, n_vec4, units, order, n_units, audible_out);

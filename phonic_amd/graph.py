@@ -16,7 +16,9 @@ class Graph(GraphHandle):
 
     # -- device-side output (multi-GPU master-bus reduce, bench.py) ------------------------------------
     def write_device(self, d_out_ptr, n_samples, pos_in_frames, stream=None):
-        """`Source::write` into device memory (`d_out_ptr` = device pointer as int)."""
+        """`Source::write` into device memory (`d_out_ptr` = device pointer as int). Asynchronous on `stream` (a hipStream_t as int);
+        without one — and that includes the default stream, whose handle is 0 — the call renders on the graph's own stream and
+        returns when the block is complete."""
         return self._lib.pg_graph_write_device(self._h, C.c_void_p(d_out_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0))
 
     def set_defer_bus(self, defer):

@@ -9,7 +9,7 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith("pg_")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # pick two consecutive rounds late in the run
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("pg_mix_kernel_2")]
+idx = [i for i, r in enumerate(rows) if (r["Kernel_Name"].startswith("pg_mix_kernel_2") or r["Kernel_Name"].startswith("pg_mix_kernel("))]
 a = idx[-4] + 1; b = idx[-2] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
