@@ -128,10 +128,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # PHONIC_BENCH_SHARED_GPU=1 (test hook, 1-GPU boxes): every rank renders on GPU 0 and the ranks meet over gloo — exercises the
+    # multi-rank control flow (sharding, buffer ring, async reduce, timing) where RCCL cannot run (it refuses two ranks on one GPU)
+    shared_gpu = os.environ.get("PHONIC_BENCH_SHARED_GPU", "") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from phonic_amd.graph import Graph
     from phonic_amd.parallel import reduce_master_bus
@@ -151,10 +159,12 @@ def main():
     build_workload(g, name, v_per_gpu, rank * v_per_gpu, total_voices, 2.0)
 
     n_samples = block * 2
-    # two master-bus buffers: the RCCL reduce of block b (its own stream, ordered after the render by an event) overlaps
-    # the render of block b+1 on the compute stream
-    buses = [torch.zeros(n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
-    pending = [None, None]
+    # a ring of master-bus buffers: the RCCL reduce of block b (RCCL's own stream, ordered after the render by an event) overlaps the
+    # render of the following blocks. The render kernel fills every CU, so the reduce kernel only finds room when the next round's
+    # workgroups drain: with four buffers the render stream never waits for it.
+    N_BUS = 4
+    buses = [torch.zeros(n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(N_BUS)]
+    pending = [None] * N_BUS
     # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
     # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
     render_stream = torch.cuda.Stream(device=local_rank)
@@ -166,8 +176,8 @@ def main():
 
     def step():
         nonlocal pos, step_no
-        k = step_no & 1
-        if pending[k] is not None:  # buffer reuse: the reduce issued two blocks ago must have finished
+        k = step_no % N_BUS
+        if pending[k] is not None:  # buffer reuse: the reduce issued N_BUS blocks ago must have finished
             pending[k].wait()
             pending[k] = None
         bus = buses[k]
@@ -185,7 +195,7 @@ def main():
         step_no += 1
 
     def drain():
-        for k in range(2):
+        for k in range(N_BUS):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
