@@ -874,6 +874,12 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kerne
 }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
+// last float4 of a block with an odd frame count: only the samples that exist (the caller's buffer ends there)
+__device__ __forceinline__ void mix_store(float* bus, int s4, int n_samples, const float4& acc) {
+  if (s4 * 4 + 4 <= n_samples) { *(float4*)(bus + (size_t)s4 * 4) = acc; return; }
+  const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  for (int i = 0; i < 4; ++i) if (s4 * 4 + i < n_samples) bus[(size_t)s4 * 4 + i] = v[i];
+}
 // Stage 1: partial[g][s] = sum over the units of group g (in unit order) of unit_out[u][s].
 // Stage 2: bus[s] = sum over groups (in order) of partial[g][s]; audible = OR over units.
 // Lanes run over the sample index s (coalesced float4); the f32 sum order is fixed (deterministic).
@@ -892,7 +898,7 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_1(const float* __restrict__ 
   }
   *(float4*)(partial + (size_t)g * stride + (size_t)s4 * 4) = acc;
 }
-__global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_vec4,
+__global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_samples,
                                                       const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
                                                       int* __restrict__ audible_out) {
   int s4 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -903,6 +909,7 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
     if (threadIdx.x == 0) *audible_out = a;
     return;
   }
+  const int n_vec4 = (n_samples + 3) / 4;
   if (s4 >= n_vec4) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
@@ -910,7 +917,7 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
     float4 v = *(const float4*)(partial + (size_t)g * stride + (size_t)s4 * 4);
     acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
   }
-  *(float4*)(bus + (size_t)s4 * 4) = acc;
+  mix_store(bus, s4, n_samples, acc);
 }
 
 // Both stages in one launch (the usual case, <= 4096 units): a workgroup of 256 lanes owns PG_MIX_COLS float4 columns; lane
@@ -920,7 +927,8 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
 #define PG_MIX_MAX_GROUPS 256
 #define PG_MIX_COLS 4
 __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ unit_out, uint32_t stride, int n_units, int n_groups, float* __restrict__ bus,
-                                                      int n_vec4, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out) {
+                                                      int n_samples, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out) {
+  const int n_vec4 = (n_samples + 3) / 4;
   __shared__ float4 part[PG_MIX_MAX_GROUPS][PG_MIX_COLS];
   const int t = threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags
@@ -953,7 +961,7 @@ __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ u
       const float4 v = part[g][col];
       acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
     }
-    *(float4*)(bus + (size_t)s4 * 4) = acc;
+    mix_store(bus, s4, n_samples, acc);
   }
 }
 
@@ -1023,11 +1031,11 @@ hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, fl
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
   if (n_groups <= PG_MIX_MAX_GROUPS) {
-    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, n_vec4, units, order, audible_out);
+    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, units, order, audible_out);
     return hipGetLastError();
   }
   dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
   hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out, stride, n_units, group, partial, n_vec4);
-  hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, n_vec4, units, order, n_units, audible_out);
+  hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, (int)n_samples, units, order, n_units, audible_out);
   return hipGetLastError();
 }

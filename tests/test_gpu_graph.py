@@ -486,3 +486,23 @@ def test_nested_submixer_events_split_child_calls():
     actions = {k: ev for k in (1, 2, 5, 30, 60, 100, 101, 102, 110)}
     a, b = both(build, 112, 1024, actions=actions, max_frames=1024)
     compare(a, b)
+
+
+def test_write_device_does_not_touch_memory_past_the_block():
+    """An odd frame count ends in the middle of the mixer sum's last float4: the samples behind the block stay untouched."""
+    import torch
+    from phonic_amd.graph import Graph
+
+    g = Graph(SR, 2, 1024, 0)
+    m = g.add_mixer()
+    g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(1))
+    g.add_voice(m, workloads.tone_buffer(10, 44100, 0.2), 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    g.add_voice(0, workloads.tone_buffer(20, 48000, 0.2), 2, 48000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    pos = 0
+    for frames in (333, 1, 1023, 7):
+        buf = torch.full((2 * frames + 8,), 7.0, dtype=torch.float32, device="cuda:0")
+        assert g.write_device(buf.data_ptr(), 2 * frames, pos) == 2 * frames
+        h = buf.cpu().numpy()
+        assert np.all(h[2 * frames:] == 7.0), (frames, h[2 * frames:])
+        assert np.all(np.abs(h[:2 * frames]) < 1.0)
+        pos += frames
