@@ -609,7 +609,7 @@ static int rebuild_topology(pg_graph* g) {
   if (rows > g->unit_out_rows) {
     if (g->d_unit_out) (void)hipFree(g->d_unit_out);
     size_t nr = std::max(rows, g->unit_out_rows * 2);
-    HIP_TRY(hipMalloc((void**)&g->d_unit_out, nr * g->stride * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&g->d_unit_out, (nr * g->stride + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
     g->unit_out_rows = nr;
   }
   if (rows > g->defer_rows) {
@@ -627,7 +627,7 @@ static int rebuild_topology(pg_graph* g) {
   size_t prow = (rows + 15) / 16;
   if (prow > g->partial_rows) {
     if (g->d_partial) (void)hipFree(g->d_partial);
-    HIP_TRY(hipMalloc((void**)&g->d_partial, prow * 2 * g->stride * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&g->d_partial, (prow * 2 * g->stride + 4) * sizeof(float)));
     g->partial_rows = prow * 2;
   }
   g->topo_dirty = false;
