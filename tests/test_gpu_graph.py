@@ -506,3 +506,20 @@ def test_write_device_does_not_touch_memory_past_the_block():
         assert np.all(h[2 * frames:] == 7.0), (frames, h[2 * frames:])
         assert np.all(np.abs(h[:2 * frames]) < 1.0)
         pos += frames
+
+
+def test_odd_max_frames_graph():
+    """max_frames = 333: unit rows start 8-byte (not 16-byte) aligned, blocks end inside a float4 — staged reverb units, a plain
+    source, a bus effect, resampled voices."""
+    def build(g):
+        for i in range(3):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.8})
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(20 + i))
+            g.add_voice(m, workloads.tone_buffer(5 + 7 * i, 44100, 0.2), 2, 44100, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_voice(0, workloads.tone_buffer(33, 48000, 0.2), 2, 48000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_effect(0, _capi.FX_FILTER, params={"cuto": 5000.0})
+        return {}
+    a, b = both(build, 9, 333, max_frames=333)
+    assert float(np.abs(b).max()) > 0.05
+    compare(a, b)
