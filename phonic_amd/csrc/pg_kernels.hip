@@ -931,11 +931,12 @@ __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ u
   const int n_vec4 = (n_samples + 3) / 4;
   __shared__ float4 part[PG_MIX_MAX_GROUPS][PG_MIX_COLS];
   const int t = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags
-    if (!audible_out || t >= 64) return;
+  if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags (two dependent loads per unit: all 256
+    if (!audible_out) return;         // lanes take part so that few of those trips follow one another)
     int a = 0;
-    for (int u = t; u < n_units; u += 64) a |= units[order[u]].audible;
-    for (int off = 32; off > 0; off >>= 1) a |= __shfl_xor(a, off, 64);
+#pragma unroll 4
+    for (int u = t; u < n_units; u += 256) a |= units[order[u]].audible;
+    a = __syncthreads_or(a);
     if (t == 0) *audible_out = a;
     return;
   }
