@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
     ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th step (the event pair costs ~8 us per step)")
+    ap.add_argument("--reduce-every", type=int, default=8, help="multi-GPU: blocks per RCCL master-bus reduce (offline super-block; 1 = per block, the real-time setting)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
@@ -159,11 +160,14 @@ def main():
     build_workload(g, name, v_per_gpu, rank * v_per_gpu, total_voices, 2.0)
 
     n_samples = block * 2
-    # a ring of master-bus buffers: the RCCL reduce of block b (RCCL's own stream, ordered after the render by an event) overlaps the
-    # render of the following blocks. The render kernel fills every CU, so the reduce kernel only finds room when the next round's
-    # workgroups drain: with four buffers the render stream never waits for it.
+    # Master-bus buffers: a ring of N_BUS super-blocks of M blocks each. Offline rendering (the reference's WavOutput pull loop,
+    # src/output/wav.rs:210-250) has no deadline per block, so the partial buses of M consecutive blocks travel in ONE RCCL reduce
+    # (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own stream, ordered after the renders by an
+    # event) overlaps the renders of the following ones, and the render stream only waits when a buffer comes round again.
+    # --reduce-every 1 is the real-time setting (one reduce per block). Bus effects on the root (c2 / c4) run per block.
+    M = 1 if (world == 1 or bus_on_root) else max(1, args.reduce_every)
     N_BUS = 4
-    buses = [torch.zeros(n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(N_BUS)]
+    buses = [torch.zeros(M * n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(N_BUS)]
     pending = [None] * N_BUS
     # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
     # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
@@ -176,12 +180,13 @@ def main():
 
     def step():
         nonlocal pos, step_no
-        k = step_no % N_BUS
-        if pending[k] is not None:  # buffer reuse: the reduce issued N_BUS blocks ago must have finished
+        k = (step_no // M) % N_BUS
+        j = step_no % M
+        if j == 0 and pending[k] is not None:  # buffer reuse: the reduce issued N_BUS super-blocks ago must have finished
             pending[k].wait()
             pending[k] = None
         bus = buses[k]
-        w = g.write_device(bus.data_ptr(), n_samples, pos, stream)
+        w = g.write_device(bus.data_ptr() + j * n_samples * 4, n_samples, pos, stream)
         if w != n_samples:
             raise RuntimeError("graph write failed: " + str(w))
         if world > 1:
@@ -189,12 +194,19 @@ def main():
                 reduce_master_bus(bus, root=0)
                 if rank == 0:
                     g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
-            else:
+            elif j == M - 1:
                 pending[k] = dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM, async_op=True)
         pos += block
         step_no += 1
 
     def drain():
+        nonlocal step_no
+        # a super-block the loop left partly filled still owes its reduce (every rank has rendered the same number of blocks)
+        j = step_no % M
+        if world > 1 and not bus_on_root and j != 0:
+            k = (step_no // M) % N_BUS
+            pending[k] = dist.reduce(buses[k][: j * n_samples], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            step_no += M - j  # the next block opens a fresh super-block
         for k in range(N_BUS):
             if pending[k] is not None:
                 pending[k].wait()
@@ -252,7 +264,7 @@ def main():
                 "sample_rate": 48000,
                 "master_frames_per_s": value / total_voices,
                 "x_realtime": value / total_voices / 48000.0,
-                "sharding": f"voices/{world}" + (" + RCCL reduce(sum) of the master bus per block" if world > 1 else ""),
+                "sharding": f"voices/{world}" + (f" + RCCL reduce(sum) of the master bus per {M} block(s)" if world > 1 else ""),
                 "exact_mode": bool(args.exact),
                 "bus_peak": peak,
             },

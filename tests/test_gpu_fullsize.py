@@ -82,8 +82,10 @@ def test_long_run_stays_on_the_oracle():
     assert np.abs(a[-2048:]).max() > 1e-3
 
 
-def test_bench_two_ranks_on_one_gpu_control_flow():
-    """bench.py's multi-rank path (voice sharding, ring of bus buffers, asynchronous per-block reduce, barrier + max-over-ranks timing)
+@pytest.mark.parametrize("steps,warmup,reduce_every", [(6, 2, 8), (13, 3, 4), (6, 2, 1)])
+def test_bench_two_ranks_on_one_gpu_control_flow(steps, warmup, reduce_every):
+    """bench.py's multi-rank path (voice sharding, ring of super-block bus buffers, asynchronous reduce per `reduce_every` blocks incl.
+    the partly filled super-block at the end, barrier + max-over-ranks timing)
     with two ranks sharing GPU 0 over gloo (PHONIC_BENCH_SHARED_GPU=1; RCCL refuses two ranks on one GPU): one JSON line from rank 0,
     whole-job voice count, audible master bus."""
     import json
@@ -98,11 +100,11 @@ def test_bench_two_ranks_on_one_gpu_control_flow():
         port = s.getsockname()[1]
     env = dict(os.environ, PHONIC_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--voices", "64"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--voices", "64", "--reduce-every", str(reduce_every)]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["total_voices"] == 128 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["config"]["total_voices"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["config"]["bus_peak"] > 0.01 and "cpu_baseline" not in d
