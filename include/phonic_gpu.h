@@ -206,6 +206,11 @@ int pg_graph_synchronize(pg_graph* g);
 /* Introspection used by the harness */
 int pg_graph_voice_count(pg_graph* g);
 int pg_graph_is_voice_playing(pg_graph* g, int voice_id);
+/* Number of units (sub-mixers and main-mixer sources) the time-parallel kernels handed to the exact serial kernel in the last launch
+ * round that had any to hand over or to check (ramping parameters, a command inside the block, a chain without a time-parallel
+ * path); 0 in steady state. Synchronises the graph's own stream: call it after pg_graph_write, or after the caller synchronised the
+ * stream given to pg_graph_write_device. */
+int pg_graph_deferred_units(pg_graph* g);
 /* Average device time (ms) of the dominant kernel launch(es) (see pg_graph_dominant_kernel) over the launches
  * since the last call with reset != 0, measured with hipEvents on the graph's stream; launches = count. */
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);

@@ -203,6 +203,8 @@ def load():
     lib.pg_graph_synchronize.argtypes = [vp]
     lib.pg_graph_voice_count.restype = C.c_int
     lib.pg_graph_voice_count.argtypes = [vp]
+    lib.pg_graph_deferred_units.restype = C.c_int
+    lib.pg_graph_deferred_units.argtypes = [vp]
     lib.pg_graph_is_voice_playing.restype = C.c_int
     lib.pg_graph_is_voice_playing.argtypes = [vp, C.c_int]
     lib.pg_graph_kernel_ms.restype = C.c_double

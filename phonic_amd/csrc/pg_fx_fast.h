@@ -61,7 +61,7 @@ DEVO bool eq5_steady(const PgEq5& e) {
 // Must mirror the acceptance conditions of fx_fast_process exactly: the fast kernel has no serial code to fall back to.
 DEVO bool fx_fast_eligible(const PgFx& fx) {
   switch (fx.kind) {
-    case 0: return fx.u.gain.dc_mode == 0 && !sm_need_ramp(fx.u.gain.gain);
+    case 0: return !sm_need_ramp(fx.u.gain.gain);
     case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
     case 2: return !sm_need_ramp(fx.u.filter.cutoff) && !sm_need_ramp(fx.u.filter.q);
     case 3: return eq5_steady(fx.u.eq5);
@@ -82,10 +82,31 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   if (!((KMASK >> fx.kind) & 1)) return false;
   switch (fx.kind) {
-    case 0: {  // GainEffect without DC filter and without ramp: scale_buffer (gain.rs:162-165)
-      const PgGain& g = fx.u.gain;
-      if (g.dc_mode != 0 || sm_need_ramp(g.gain)) return false;
+    case 0: {  // GainEffect without ramp: optional DC filter per channel (gain.rs:147-153), then scale_buffer (gain.rs:162-165)
+      PgGain& g = fx.u.gain;
+      if (sm_need_ramp(g.gain)) return false;
       float v = g.gain.target;
+      if (g.dc_mode != 0) {
+        // DcFilter::process_sample per channel as a blocked scan over the block (dc_scan, shared with the DelayEffect's wet path),
+        // rounded to f32 and scaled as the serial loop does. Only in the kernel variants that carry the Delay code (bit 4): the host
+        // routes such chains to the wide kernels.
+        if constexpr ((KMASK >> 4) & 1) {
+          double* buf = (double*)fc.scratch;
+          double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+          const int frames = n / 2;
+          for (int done = 0; done < frames; done += 1024) {
+            const int T = frames - done < 1024 ? frames - done : 1024;
+            __syncthreads();
+            for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
+            __syncthreads();
+            dc_scan(g.dc, buf, T, xchg);
+            __syncthreads();
+            for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)] * v;
+          }
+          __syncthreads();
+          return true;
+        } else return false;
+      }
       __syncthreads();
       for (int i = tid; i < n; i += nt) sig[i] = sig[i] * v;
       __syncthreads();

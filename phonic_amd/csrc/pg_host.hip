@@ -518,7 +518,7 @@ static int rebuild_topology(pg_graph* g) {
       const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)
       if (m != 0 && (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DISTORTION || k == PG_FX_DELAY || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE)) g->wide = true;
       if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_REVERB || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE || k == PG_FX_DISTORTION)) u.static_defer = 1;
-      if (k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) u.static_defer = 1;  // DC filter: serial recurrence
+      if (m != 0 && k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) g->wide = true;  // DC filter: blocked scan, compiled into the wide variants only
     }
     // staged pipeline: a sub-mixer whose chain is [Gain (no DC filter) | Panning]* -> Reverb
     u.staged = 0;
@@ -526,8 +526,8 @@ static int rebuild_topology(pg_graph* g) {
       u.staged = 1;  // 1: leading Gain / Panning only (lean staged kernel); 2: also Filter, Eq5, Delay, Distortion (wide staged kernel)
       for (size_t i = 0; i + 1 < mx.fx.size(); ++i) {
         const int k = g->fx[mx.fx[i]]->kind;
-        if (k == PG_FX_GAIN || k == PG_FX_PANNING) continue;
-        if (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_DISTORTION) { if (u.staged) u.staged = 2; }
+        if ((k == PG_FX_GAIN && (int)g->fx[mx.fx[i]]->init_raw[1] == 0) || k == PG_FX_PANNING) continue;
+        if (k == PG_FX_GAIN || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_DISTORTION) { if (u.staged) u.staged = 2; }
         else u.staged = 0;
       }
     }
@@ -846,6 +846,8 @@ int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float v
   if (h.kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
     return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
   h.target[pi] = raw;
+  // a Gain whose DC filter gets switched on later needs the kernel variants that carry the DC scan: classify the chain again
+  if (h.kind == PG_FX_GAIN && pi != P_GAIN_GAIN && (int)raw != 0 && (int)h.init_raw[1] == 0) { h.init_raw[1] = raw; g->topo_dirty = true; }
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = CMD_FX_PARAM; c.target = effect_id; c.param = pi; c.value = raw;
@@ -936,6 +938,15 @@ int pg_graph_is_voice_playing(pg_graph* g, int voice_id) {
   PgVoice v;
   if (hipMemcpy(&v, g->d_voices.d + g->voices[voice_id].dev_index, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return v.active && !v.finished;
+}
+int pg_graph_deferred_units(pg_graph* g) {
+  (void)hipSetDevice(g->device);
+  (void)hipStreamSynchronize(g->stream);
+  if (!g->h_feedback) return 0;
+  // (round << 32 | deferred units) as the generic kernel of the last round that launched it reported; rounds that skipped the launch
+  // did so because this word said 0 and nothing had changed since
+  const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
+  return fb == ~0ull ? 0 : (int)(uint32_t)fb;
 }
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
   (void)hipSetDevice(g->device);

@@ -33,6 +33,10 @@ class Graph(GraphHandle):
     def voice_count(self):
         return self._lib.pg_graph_voice_count(self._h)
 
+    def deferred_units(self):
+        """Units the time-parallel kernels handed to the exact serial kernel in the last block (0 in steady state)."""
+        return self._id(self._lib.pg_graph_deferred_units(self._h))
+
     def is_voice_playing(self, voice):
         return bool(self._lib.pg_graph_is_voice_playing(self._h, voice))
 

@@ -523,3 +523,54 @@ def test_odd_max_frames_graph():
     a, b = both(build, 9, 333, max_frames=333)
     assert float(np.abs(b).max()) > 0.05
     compare(a, b)
+
+
+def test_gain_with_dc_filter_takes_the_time_parallel_path():
+    """GainEffect with its DC filter on (gain.rs:147-153) in sub-mixer chains: alone, in front of a Reverb (wide staged kernel) and
+    behind a Filter; the DC filter runs as a blocked scan (no deferral to the serial kernel in steady state). A fourth sub-mixer
+    starts as a plain [Gain -> Reverb] chain of the lean staged kernel and gets its DC filter switched on by a parameter event
+    in the middle of a block: the chain is classified again and moves to the wide variants."""
+    def build(g):
+        m1 = g.add_mixer()
+        g.add_effect(m1, _capi.FX_GAIN, params={"gain": 0.7, "dcfm": 2})
+        g.add_voice(m1, workloads.tone_buffer(3, 44100, 0.3) + 0.02, 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m2 = g.add_mixer()
+        g.add_effect(m2, _capi.FX_GAIN, params={"gain": 1.3, "dcfm": 3})
+        g.add_effect(m2, _capi.FX_REVERB, params={"room": 0.4}, reverb_seeds=workloads.reverb_seeds(11))
+        g.add_voice(m2, workloads.tone_buffer(8, 48000, 0.25) - 0.01, 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m3 = g.add_mixer()
+        g.add_effect(m3, _capi.FX_FILTER, params={"type": 0, "cuto": 3000.0})
+        g.add_effect(m3, _capi.FX_GAIN, params={"gain": 0.9, "dcfm": 1})
+        g.add_voice(m3, workloads.tone_buffer(15, 44100, 0.2), 2, 44100, volume=0.4, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m4 = g.add_mixer()
+        fx = g.add_effect(m4, _capi.FX_GAIN, params={"gain": 0.8})
+        g.add_effect(m4, _capi.FX_REVERB, params={"room": 0.5}, reverb_seeds=workloads.reverb_seeds(12))
+        g.add_voice(m4, workloads.tone_buffer(21, 44100, 0.3) + 0.03, 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return [fx]
+
+    def act(g, ids, pos):
+        g.schedule_param(ids[0], "dcfm", 2, pos + 2500)  # lands two blocks later, 452 frames into the block
+
+    a, b = both(build, 24, 1024, actions={6: act})
+    compare(a, b)
+    assert np.abs(a).max() > 1e-2
+    for blk in (512, 1000, 1023):  # ragged blocks through the same chains
+        a, b = both(build, 9, blk, actions={3: act})
+        compare(a, b)
+    # the time-parallel kernels keep these chains: nothing is handed to the serial kernel in steady state, the block that holds the
+    # parameter event is (one unit), and the re-classified chain is back on the time-parallel path afterwards
+    from phonic_amd.graph import Graph
+
+    g = Graph(SR, 2, 1024, 0)
+    ids = build(g)
+    out = np.zeros(2048, np.float32)
+    pos = 0
+    for _ in range(4):
+        g.write(out, pos); pos += 1024
+    assert g.deferred_units() == 0
+    g.schedule_param(ids[0], "dcfm", 2, pos + 100)
+    g.write(out, pos); pos += 1024
+    assert g.deferred_units() >= 1  # (the re-classification marks every unit of the graph for one block)
+    for _ in range(3):
+        g.write(out, pos); pos += 1024
+    assert g.deferred_units() == 0
