@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
     ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th step (the event pair costs ~8 us per step)")
-    ap.add_argument("--reduce-every", type=int, default=8, help="multi-GPU: blocks per RCCL master-bus reduce (offline super-block; 1 = per block, the real-time setting)")
+    ap.add_argument("--reduce-every", type=int, default=16, help="multi-GPU: blocks per RCCL master-bus reduce (offline super-block; 1 = per block, the real-time setting)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
@@ -165,6 +165,9 @@ def main():
     # (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own stream, ordered after the renders by an
     # event) overlaps the renders of the following ones, and the render stream only waits when a buffer comes round again.
     # --reduce-every 1 is the real-time setting (one reduce per block). Bus effects on the root (c2 / c4) run per block.
+    # The headline launch fills the chip exactly (1024 workgroups = 256 CUs x 4 resident): a block whose dispatch finds an RCCL
+    # workgroup resident on some CU leaves one render workgroup waiting for a second round, so fewer, larger reduces also mean fewer
+    # disturbed blocks.
     M = 1 if (world == 1 or bus_on_root) else max(1, args.reduce_every)
     N_BUS = 4
     buses = [torch.zeros(M * n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(N_BUS)]
