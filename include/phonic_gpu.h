@@ -165,6 +165,15 @@ int pg_graph_add_mixer(pg_graph* g);
 int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id);
 /* Player::add_effect(effect, mixer) -> effect id >= 0 (src/player.rs:893-939). */
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init);
+/* Player::remove_effect(effect_id) (src/player.rs:977-990 -> MixerMessage::RemoveEffect, src/source/mixed.rs:433-440): takes effect at
+ * the start of the next write; later calls with this id return PG_ERR_NOT_FOUND. */
+int pg_graph_remove_effect(pg_graph* g, int effect_id);
+/* Player::move_effect(movement, effect_id, mixer_id) (src/player.rs:942-972 -> MixerMessage::MoveEffect, src/source/mixed.rs:441-462):
+ * EffectMovement::Direction(offset) / Start / End (src/player.rs:75-82). PG_ERR_PARAMETER when the effect is not in `mixer_id`. */
+#define PG_MOVE_DIRECTION 0
+#define PG_MOVE_START 1
+#define PG_MOVE_END 2
+int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement, int offset);
 /* Player::play_file_source(PreloadedFileSource::from_shared_buffer(..), start_time)
  * (src/player.rs:519-602, src/source/file/preloaded.rs:71-117). `pcm` is the decoded interleaved
  * buffer INCLUDING the extra zero frame symphonia decoding appends (file/buffer.rs:103-104);

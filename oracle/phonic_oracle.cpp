@@ -178,6 +178,28 @@ static int push_event(MixedSource* mx, const MixedSource::MixerEvent& ev) {
   mx->message_queue.push_back(std::move(m));
   return PG_OK;
 }
+int po_graph_remove_effect(po_graph* g, int effect_id) {  // Player::remove_effect -> MixerMessage::RemoveEffect
+  auto it = g->effect_mixer.find(effect_id);
+  if (it == g->effect_mixer.end()) return PG_ERR_NOT_FOUND;
+  MixedSource::Message m;
+  m.kind = MixedSource::Message::RemoveEffect;
+  m.id = effect_id;
+  it->second->message_queue.push_back(std::move(m));
+  g->effect_mixer.erase(it);
+  return PG_OK;
+}
+int po_graph_move_effect(po_graph* g, int effect_id, int mixer_id, int movement, int offset) {  // Player::move_effect -> MixerMessage::MoveEffect
+  auto it = g->effect_mixer.find(effect_id);
+  if (it == g->effect_mixer.end()) return PG_ERR_NOT_FOUND;
+  auto mx = g->mixers.find(mixer_id);
+  if (mx == g->mixers.end() || mx->second != it->second) return PG_ERR_PARAMETER;  // "Effect does not belong to mixer" (player.rs:953-958)
+  if (movement < 0 || movement > 2) return PG_ERR_PARAMETER;
+  MixedSource::Message m;
+  m.kind = MixedSource::Message::MoveEffect;
+  m.id = effect_id; m.movement = movement; m.offset = offset;
+  it->second->message_queue.push_back(std::move(m));
+  return PG_OK;
+}
 int po_graph_schedule_param(po_graph* g, int effect_id, uint32_t id, float value, int normalized, uint64_t sample_time) {
   auto it = g->effect_mixer.find(effect_id);
   if (it == g->effect_mixer.end()) return PG_ERR_NOT_FOUND;

@@ -389,7 +389,8 @@ struct MixedSource : Source {
     uint32_t param_id = 0; ParamUpdate update{false, 0.0f};
   };
   struct Message {
-    enum Kind { AddSource, StopSource, RemoveSource, AddMixer, AddEffect, Event } kind;
+    enum Kind { AddSource, StopSource, RemoveSource, AddMixer, AddEffect, RemoveEffect, MoveEffect, Event } kind;
+    int movement = 0, offset = 0;  // EffectMovement: 0 = Direction(offset), 1 = Start, 2 = End (src/player.rs)
     std::unique_ptr<PlayingSource> source;
     int id = 0; uint64_t sample_time = 0;
     std::unique_ptr<SubMixerProcessor> mixer;
@@ -461,6 +462,27 @@ struct MixedSource : Source {
           break;
         case Message::AddMixer: mixers.emplace_back(m.id, std::move(m.mixer)); break;
         case Message::AddEffect: effects.emplace_back(m.id, std::move(m.effect)); effects_bypassed = false; break;
+        case Message::RemoveEffect: {  // :433-440
+          for (size_t pos = 0; pos < effects.size(); ++pos) if (effects[pos].first == m.id) {
+            effects.erase(effects.begin() + pos);
+            if (effects.empty()) effects_bypassed = true;
+            break;
+          }
+        } break;
+        case Message::MoveEffect: {  // :441-462
+          for (size_t current_pos = 0; current_pos < effects.size(); ++current_pos) if (effects[current_pos].first == m.id) {
+            auto effect = std::move(effects[current_pos]);
+            effects.erase(effects.begin() + current_pos);
+            size_t new_pos;
+            if (m.movement == 0) {
+              int target = (int)current_pos + m.offset;
+              int hi = (int)effects.size();
+              new_pos = (size_t)(target < 0 ? 0 : (target > hi ? hi : target));
+            } else new_pos = m.movement == 1 ? 0 : effects.size();
+            effects.insert(effects.begin() + new_pos, std::move(effect));
+            break;
+          }
+        } break;
         case Message::Event: insert_event(m.event); break;
       }
     }

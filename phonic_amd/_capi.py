@@ -12,6 +12,7 @@ FX_GAIN, FX_PANNING, FX_FILTER, FX_EQ5, FX_DELAY, FX_REVERB, FX_CHORUS, FX_COMPR
 FX_NAMES = ["Gain", "Panning", "Filter", "Eq5", "Delay", "Reverb", "Chorus", "Compressor", "Gate", "Distortion"]
 
 PG_MAX_INIT_PARAMS = 16
+MOVE_DIRECTION, MOVE_START, MOVE_END = 0, 1, 2  # EffectMovement (src/player.rs:75-82)
 PG_REPEAT_FOREVER = 2**64 - 1
 INT64_MAX = 2**63 - 1
 
@@ -118,6 +119,8 @@ def declare(lib, prefix):
         "graph_add_voice": (C.c_int, [vp, C.c_int, P(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, P(VoiceOptions)]),
         "graph_schedule_param": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_float, C.c_int, C.c_uint64]),
         "graph_schedule_reset": (C.c_int, [vp, C.c_int, C.c_uint64]),
+        "graph_remove_effect": (C.c_int, [vp, C.c_int]),
+        "graph_move_effect": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "graph_set_voice_volume": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_set_voice_panning": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_stop_voice": (C.c_int, [vp, C.c_int, C.c_uint64]),

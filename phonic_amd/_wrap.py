@@ -140,6 +140,14 @@ class GraphHandle:
             self._fn("graph_add_voice")(self._h, mixer_id, _f32p(pcm), pcm.size // src_channels, src_channels, src_rate, C.byref(o))
         )
 
+    def remove_effect(self, effect_id):
+        """Player::remove_effect (src/player.rs:977-990)."""
+        self._check(self._fn("graph_remove_effect")(self._h, effect_id))
+
+    def move_effect(self, effect_id, mixer_id, movement, offset=0):
+        """Player::move_effect (src/player.rs:942-972): movement = MOVE_DIRECTION (with offset) / MOVE_START / MOVE_END."""
+        self._check(self._fn("graph_move_effect")(self._h, effect_id, mixer_id, movement, offset))
+
     def schedule_param(self, effect_id, id4, value, sample_time, normalized=False):
         self._check(self._fn("graph_schedule_param")(self._h, effect_id, fourcc(id4), float(value), 1 if normalized else 0, sample_time))
 

@@ -740,6 +740,40 @@ int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_ini
   return idx;
 }
 
+// Player::remove_effect -> MixerMessage::RemoveEffect (src/player.rs:977-990, src/source/mixed.rs:433-440): the effect leaves its mixer's
+// chain at the start of the next write; events still queued for it would find no effect when they fire (mixed.rs:880-924) and are
+// dropped here. The id is never reused; its device state stays allocated until the graph is destroyed (the reference drops the
+// effect on the collector thread, never on the audio thread).
+int pg_graph_remove_effect(pg_graph* g, int effect_id) {
+  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  HostMixer& mx = g->mixers[g->fx_mixer[effect_id]];
+  mx.fx.erase(std::remove(mx.fx.begin(), mx.fx.end(), effect_id), mx.fx.end());
+  auto addressed = [effect_id](const Event& e) { return (e.cmd.type == CMD_FX_PARAM || e.cmd.type == CMD_FX_RESET) && e.cmd.target == effect_id; };
+  mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), addressed), mx.events.end());
+  mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), addressed), mx.bus_events.end());
+  g->fx_mixer[effect_id] = -1;
+  g->topo_dirty = true;
+  return PG_OK;
+}
+// Player::move_effect -> MixerMessage::MoveEffect (src/player.rs:942-972, src/source/mixed.rs:441-462). movement: PG_MOVE_DIRECTION
+// (offset < 0 towards the start, clamped to the chain), PG_MOVE_START, PG_MOVE_END; mixer_id must be the effect's mixer.
+int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement, int offset) {
+  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  if (g->fx_mixer[effect_id] != mixer_id) return set_error(PG_ERR_PARAMETER, "Effect %d does not belong to mixer %d", effect_id, mixer_id);
+  if (movement < PG_MOVE_DIRECTION || movement > PG_MOVE_END) return set_error(PG_ERR_PARAMETER, "unknown effect movement %d", movement);
+  std::vector<int>& fx = g->mixers[mixer_id].fx;
+  const auto it = std::find(fx.begin(), fx.end(), effect_id);
+  if (it == fx.end()) return PG_OK;  // (logged and ignored in the reference)
+  const int current_pos = (int)(it - fx.begin());
+  fx.erase(it);
+  int new_pos;
+  if (movement == PG_MOVE_DIRECTION) new_pos = std::max(0, std::min((int)fx.size(), current_pos + offset));
+  else new_pos = movement == PG_MOVE_START ? 0 : (int)fx.size();
+  fx.insert(fx.begin() + new_pos, effect_id);
+  g->topo_dirty = true;
+  return PG_OK;
+}
+
 int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
                        const pg_voice_options* opt) {
   (void)hipSetDevice(g->device);
@@ -837,7 +871,7 @@ static int push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd&
 }
 
 int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
-  if (effect_id < 0 || effect_id >= (int)g->fx.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
   HostFx& h = *g->fx[effect_id];
   int pi = find_param(h.kind, fourcc);
   if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[h.kind].name);
@@ -854,7 +888,7 @@ int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float v
   return push_event(g, g->fx_mixer[effect_id], sample_time, c);
 }
 int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time) {
-  if (effect_id < 0 || effect_id >= (int)g->fx.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
   int kind = g->fx[effect_id]->kind;
   if (kind != PG_FX_DELAY && kind != PG_FX_REVERB && kind != PG_FX_CHORUS)
     return set_error(PG_ERR_PARAMETER, "%sEffect: Invalid/unknown message payload", KINDS[kind].name);

@@ -574,3 +574,48 @@ def test_gain_with_dc_filter_takes_the_time_parallel_path():
     for _ in range(3):
         g.write(out, pos); pos += 1024
     assert g.deferred_units() == 0
+
+
+def test_remove_and_move_effects_between_blocks():
+    """Player::move_effect / remove_effect (MixerMessage::MoveEffect / RemoveEffect, mixed.rs:433-462) on a sub-mixer chain and on the
+    main mixer's bus chain: the chain order changes at the start of the next write, every effect keeps its state (filters, delay
+    lines, bypass counters) across the move; a removed effect's pending parameter events vanish and its id is gone."""
+    def build(g):
+        m = g.add_mixer()
+        a = g.add_effect(m, _capi.FX_DISTORTION, params={"type": 1, "driv": 4.0})
+        b = g.add_effect(m, _capi.FX_FILTER, params={"type": 0, "cuto": 900.0})
+        c = g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.5})
+        d = g.add_effect(m, _capi.FX_REVERB, params={"room": 0.3}, reverb_seeds=workloads.reverb_seeds(21))
+        g.add_voice(m, workloads.tone_buffer(6, 44100, 0.3), 2, 44100, volume=0.9, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        e = g.add_effect(0, _capi.FX_EQ5, params=None)
+        f = g.add_effect(0, _capi.FX_DELAY, params={"dlay": 20.0})
+        g.add_voice(0, workloads.tone_buffer(12, 48000, 0.2), 2, 48000, volume=0.3, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return dict(m=m, a=a, b=b, c=c, d=d, e=e, f=f)
+
+    def act3(g, ids, pos):   # filter in front of the distortion: [b a c d]
+        g.move_effect(ids["b"], ids["m"], _capi.MOVE_START)
+    def act5(g, ids, pos):   # reverb one step towards the start: [b a d c] (no longer reverb-terminated), bus: [f e]
+        g.move_effect(ids["d"], ids["m"], _capi.MOVE_DIRECTION, -1)
+        g.move_effect(ids["e"], 0, _capi.MOVE_END)
+        g.schedule_param(ids["a"], "driv", 1.0, pos + 5000)  # never fires: the effect is removed first
+    def act7(g, ids, pos):   # distortion leaves, the move of a removed / foreign effect is refused
+        g.remove_effect(ids["a"])
+        for call in (lambda: g.remove_effect(ids["a"]), lambda: g.schedule_param(ids["a"], "driv", 2.0, pos), lambda: g.move_effect(ids["a"], ids["m"], _capi.MOVE_END),
+                     lambda: g.move_effect(ids["b"], 0, _capi.MOVE_END)):
+            with pytest.raises(Exception):
+                call()
+    def act9(g, ids, pos):   # clamped direction moves, reverb back to the end: [b c d]; bus delay removed: [e]
+        g.move_effect(ids["d"], ids["m"], _capi.MOVE_DIRECTION, 7)
+        g.move_effect(ids["b"], ids["m"], _capi.MOVE_DIRECTION, -3)
+        g.remove_effect(ids["f"])
+    def act12(g, ids, pos):  # chain emptied
+        for k in ("b", "c", "d"):
+            g.remove_effect(ids[k])
+
+    actions = {3: act3, 5: act5, 7: act7, 9: act9, 12: act12}
+    a, b = both(build, 16, 1024, actions=actions)
+    compare(a, b)
+    assert np.abs(a[-2048:]).max() > 1e-3
+    # each rearrangement is audible: the same graph without the actions differs block for block after the first one
+    a0, _ = both(build, 16, 1024)
+    assert np.array_equal(a[: 3 * 2048], a0[: 3 * 2048]) and np.abs(a[3 * 2048 :] - a0[3 * 2048 :]).max() > 1e-3

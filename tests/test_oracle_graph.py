@@ -124,3 +124,52 @@ def test_nested_mixers_without_effects_equal_the_flat_sum():
         x, y = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
         assert flat.write(x, blk * 1024) == 2048 and nested.write(y, blk * 1024) == 2048
         assert np.array_equal(x, y) and float(np.abs(x).max()) > 0.01
+
+
+def test_move_and_remove_effect_messages():
+    """MixerMessage::MoveEffect / RemoveEffect (mixed.rs:433-462) with memoryless effects and a constant input: a hard-clip Distortion
+    (clamp to +-1/gain, then x gain, then the RMS compensation factor c of that drive; distortion.rs hard_clip) and a Gain of 0.1.
+    [Distortion, Gain]: 0.5 clips -> 1.0 c -> 0.1 c.   [Gain, Distortion]: 0.05 stays under the threshold -> 0.05 gain c.
+    The moved chain must give exactly what a chain built in that order gives. Direction offsets clamp to the chain; a removed
+    effect's id is unknown afterwards; the emptied chain passes the input through."""
+    import pytest
+
+    buf = np.concatenate([np.full(2 * 20000, 0.5, np.float32), np.zeros(2, np.float32)])
+    out = np.zeros(2 * 1024, np.float32)
+
+    def fresh(order):
+        g = oracle.OracleGraph(SR, 2)
+        g.add_voice(0, buf, 2, SR)
+        ids = {}
+        for k in order:
+            ids[k] = g.add_effect(0, _capi.FX_DISTORTION, params={"type": 1, "driv": 1.0, "mix ": 1.0}) if k == "dist" else g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.1})
+        return g, ids
+
+    def level(g, pos):
+        g.write(out, pos)
+        return float(out[-1])
+
+    dg = level(fresh(["dist", "gain"])[0], 0)
+    gd = level(fresh(["gain", "dist"])[0], 0)
+    assert 0.005 < dg < 0.1 and gd > dg * 1.01  # 0.1 c against 0.05 gain c with gain > 2
+    g, ids = fresh(["dist", "gain"])
+    dist, gain = ids["dist"], ids["gain"]
+    assert level(g, 0) == dg
+    g.move_effect(gain, 0, _capi.MOVE_START)            # [Gain, Distortion]
+    assert level(g, 1024) == gd
+    g.move_effect(gain, 0, _capi.MOVE_DIRECTION, 5)     # clamped to the end: [Distortion, Gain]
+    assert level(g, 2048) == dg
+    g.move_effect(dist, 0, _capi.MOVE_END)              # [Gain, Distortion]
+    assert level(g, 3072) == gd
+    g.move_effect(dist, 0, _capi.MOVE_DIRECTION, -9)    # clamped to the start: [Distortion, Gain]
+    assert level(g, 4096) == dg
+    g.remove_effect(dist)                               # [Gain]
+    assert abs(level(g, 5120) - 0.05) < 1e-7
+    with pytest.raises(Exception):
+        g.remove_effect(dist)
+    with pytest.raises(Exception):
+        g.schedule_param(dist, "driv", 0.5, 6000)
+    with pytest.raises(Exception):
+        g.move_effect(gain, 1, _capi.MOVE_END)          # not that mixer's effect
+    g.remove_effect(gain)                               # []
+    assert level(g, 6144) == 0.5
