@@ -165,6 +165,10 @@ int pg_graph_add_mixer(pg_graph* g);
 int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id);
 /* Player::add_effect(effect, mixer) -> effect id >= 0 (src/player.rs:893-939). */
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init);
+/* Player::remove_mixer(mixer_id) (src/player.rs:825-867 -> MixerMessage::RemoveMixer to the parent, src/source/mixed.rs:422-424): the
+ * sub-mixer leaves its parent at the start of the next write, with its effects, sources and nested sub-mixers (their ids return
+ * PG_ERR_NOT_FOUND afterwards). PG_ERR_PARAMETER for the main mixer. */
+int pg_graph_remove_mixer(pg_graph* g, int mixer_id);
 /* Player::remove_effect(effect_id) (src/player.rs:977-990 -> MixerMessage::RemoveEffect, src/source/mixed.rs:433-440): takes effect at
  * the start of the next write; later calls with this id return PG_ERR_NOT_FOUND. */
 int pg_graph_remove_effect(pg_graph* g, int effect_id);

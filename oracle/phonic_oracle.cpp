@@ -53,6 +53,7 @@ struct po_graph {
   std::map<int, MixedSource*> mixers;            // id -> mixer (0 = main)
   std::map<int, MixedSource*> effect_mixer;      // effect id -> owning mixer
   std::map<int, MixedSource*> voice_mixer;       // voice id -> owning mixer
+  std::map<int, int> mixer_parent;               // mixer id -> parent mixer id
   int next_mixer = 1, next_effect = 0, next_voice = 0;
   uint32_t sample_rate;
   size_t channels;
@@ -116,6 +117,7 @@ int po_graph_add_mixer_to(po_graph* g, int parent_mixer_id) {  // Player::add_mi
   m.mixer = std::move(p);
   parent->second->message_queue.push_back(std::move(m));
   g->mixers[id] = child;
+  g->mixer_parent[id] = parent_mixer_id;
   return id;
 }
 int po_graph_add_mixer(po_graph* g) { return po_graph_add_mixer_to(g, 0); }  // Player::add_mixer(None): child of the main mixer
@@ -176,6 +178,25 @@ static int push_event(MixedSource* mx, const MixedSource::MixerEvent& ev) {
   m.kind = MixedSource::Message::Event;
   m.event = ev;
   mx->message_queue.push_back(std::move(m));
+  return PG_OK;
+}
+int po_graph_remove_mixer(po_graph* g, int mixer_id) {  // Player::remove_mixer (src/player.rs:825-867)
+  if (mixer_id == 0) return PG_ERR_PARAMETER;
+  auto it = g->mixers.find(mixer_id);
+  if (it == g->mixers.end()) return PG_ERR_NOT_FOUND;
+  MixedSource::Message m;
+  m.kind = MixedSource::Message::RemoveMixer;
+  m.id = mixer_id;
+  g->mixers[g->mixer_parent[mixer_id]]->message_queue.push_back(std::move(m));
+  // tracking maps: the mixer, everything nested under it, their effects and sources (the objects die with the SubMixerProcessor)
+  std::vector<int> gone(1, mixer_id);
+  for (size_t i = 0; i < gone.size(); ++i) for (auto& kv : g->mixer_parent) if (kv.second == gone[i] && g->mixers.count(kv.first)) gone.push_back(kv.first);
+  for (int id : gone) {
+    MixedSource* ms = g->mixers[id];
+    for (auto e = g->effect_mixer.begin(); e != g->effect_mixer.end();) { if (e->second == ms) e = g->effect_mixer.erase(e); else ++e; }
+    for (auto v = g->voice_mixer.begin(); v != g->voice_mixer.end();) { if (v->second == ms) v = g->voice_mixer.erase(v); else ++v; }
+    g->mixers.erase(id);
+  }
   return PG_OK;
 }
 int po_graph_remove_effect(po_graph* g, int effect_id) {  // Player::remove_effect -> MixerMessage::RemoveEffect

@@ -389,7 +389,7 @@ struct MixedSource : Source {
     uint32_t param_id = 0; ParamUpdate update{false, 0.0f};
   };
   struct Message {
-    enum Kind { AddSource, StopSource, RemoveSource, AddMixer, AddEffect, RemoveEffect, MoveEffect, Event } kind;
+    enum Kind { AddSource, StopSource, RemoveSource, AddMixer, RemoveMixer, AddEffect, RemoveEffect, MoveEffect, Event } kind;
     int movement = 0, offset = 0;  // EffectMovement: 0 = Direction(offset), 1 = Start, 2 = End (src/player.rs)
     std::unique_ptr<PlayingSource> source;
     int id = 0; uint64_t sample_time = 0;
@@ -461,6 +461,9 @@ struct MixedSource : Source {
           for (size_t i = 0; i < playing_sources.size();) { if (playing_sources[i]->playback_id == m.id) playing_sources.erase(playing_sources.begin() + i); else ++i; }
           break;
         case Message::AddMixer: mixers.emplace_back(m.id, std::move(m.mixer)); break;
+        case Message::RemoveMixer:  // :422-424
+          for (size_t i = 0; i < mixers.size();) { if (mixers[i].first == m.id) mixers.erase(mixers.begin() + i); else ++i; }
+          break;
         case Message::AddEffect: effects.emplace_back(m.id, std::move(m.effect)); effects_bypassed = false; break;
         case Message::RemoveEffect: {  // :433-440
           for (size_t pos = 0; pos < effects.size(); ++pos) if (effects[pos].first == m.id) {

@@ -140,6 +140,10 @@ class GraphHandle:
             self._fn("graph_add_voice")(self._h, mixer_id, _f32p(pcm), pcm.size // src_channels, src_channels, src_rate, C.byref(o))
         )
 
+    def remove_mixer(self, mixer_id):
+        """Player::remove_mixer (src/player.rs:825-867)."""
+        self._check(self._fn("graph_remove_mixer")(self._h, mixer_id))
+
     def remove_effect(self, effect_id):
         """Player::remove_effect (src/player.rs:977-990)."""
         self._check(self._fn("graph_remove_effect")(self._h, effect_id))

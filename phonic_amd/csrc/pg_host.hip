@@ -401,6 +401,7 @@ struct HostMixer {
   int parent = 0;                  // Player::add_mixer(parent): 0 = the main mixer
   int depth = 1;                   // main mixer 0, its sub-mixers 1, their sub-mixers 2 ...
   std::vector<int> children;       // nested sub-mixers, in the order they were added
+  bool removed = false;            // Player::remove_mixer: gone from its parent (with everything under it)
 };
 // Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
 // deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
@@ -541,13 +542,13 @@ static int rebuild_topology(pg_graph* g) {
   g->order.clear();
   g->levels.clear();
   int max_depth = 1;
-  for (size_t m = 1; m < g->mixers.size(); ++m) max_depth = std::max(max_depth, g->mixers[m].depth);
+  for (size_t m = 1; m < g->mixers.size(); ++m) if (!g->mixers[m].removed) max_depth = std::max(max_depth, g->mixers[m].depth);
   std::vector<int> row_of_mixer(g->mixers.size(), -1);
   for (int d = max_depth; d >= 1; --d) {
     Level lv;
     lv.off = (int)g->order.size();
     for (size_t m = 1; m < g->mixers.size(); ++m) {
-      if (g->mixers[m].depth != d) continue;
+      if (g->mixers[m].depth != d || g->mixers[m].removed) continue;
       row_of_mixer[m] = (int)g->order.size();
       g->order.push_back(g->mixers[m].unit_slot);
     }
@@ -708,7 +709,7 @@ void pg_graph_destroy(pg_graph* g) {
 
 int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id) {
   (void)hipSetDevice(g->device);
-  if (parent_mixer_id < 0 || parent_mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", parent_mixer_id);
+  if (parent_mixer_id < 0 || parent_mixer_id >= (int)g->mixers.size() || g->mixers[parent_mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", parent_mixer_id);
   int slot = new_unit(g, UNIT_SUBMIXER);
   if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
   const int id = (int)g->mixers.size();
@@ -723,7 +724,7 @@ int pg_graph_add_mixer(pg_graph* g) { return pg_graph_add_mixer_to(g, 0); }
 
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init) {
   (void)hipSetDevice(g->device);
-  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
   std::unique_ptr<HostFx> h(new HostFx());
   int rc = host_fx_from_init(kind, init, *h);
   if (rc) return -rc;
@@ -738,6 +739,27 @@ int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_ini
   g->mixers[mixer_id].fx.push_back(idx);
   g->topo_dirty = true;
   return idx;
+}
+
+// Player::remove_mixer -> MixerMessage::RemoveMixer to the parent (src/player.rs:825-867, src/source/mixed.rs:422-424): from the next write
+// on the parent no longer sums this sub-mixer; its effects, sources, nested sub-mixers and their pending events go with it (dropped
+// with the SubMixerProcessor in the reference). Ids are never reused.
+int pg_graph_remove_mixer(pg_graph* g, int mixer_id) {
+  if (mixer_id == 0) return set_error(PG_ERR_PARAMETER, "Cannot remove the main mixer");
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  std::vector<int>& siblings = g->mixers[g->mixers[mixer_id].parent].children;
+  siblings.erase(std::remove(siblings.begin(), siblings.end(), mixer_id), siblings.end());
+  std::vector<int> gone(1, mixer_id);
+  for (size_t i = 0; i < gone.size(); ++i) {
+    HostMixer& mx = g->mixers[gone[i]];
+    for (int c : mx.children) gone.push_back(c);
+    for (int f : mx.fx) g->fx_mixer[f] = -1;
+    for (int v : mx.voices) g->voices[v].mixer = -1;
+    mx.children.clear(); mx.fx.clear(); mx.voices.clear(); mx.events.clear(); mx.messages.clear(); mx.bus_events.clear();
+    mx.removed = true;
+  }
+  g->topo_dirty = true;
+  return PG_OK;
 }
 
 // Player::remove_effect -> MixerMessage::RemoveEffect (src/player.rs:977-990, src/source/mixed.rs:433-440): the effect leaves its mixer's
@@ -777,7 +799,7 @@ int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement,
 int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
                        const pg_voice_options* opt) {
   (void)hipSetDevice(g->device);
-  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size()) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
   // AudioFileBuffer::new validation (file/buffer.rs:22-60)
   if (src_rate == 0) return -set_error(PG_ERR_PARAMETER, "file buffer sample rate must be > 0");
   if (src_channels != 1 && src_channels != 2) return -set_error(PG_ERR_PARAMETER, "only mono and stereo file buffers are supported");
@@ -898,7 +920,7 @@ int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time) {
   return push_event(g, g->fx_mixer[effect_id], sample_time, c);
 }
 static int voice_event(pg_graph* g, int voice_id, int type, float value, uint64_t sample_time) {
-  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = type; c.target = g->voices[voice_id].dev_index; c.value = value;
@@ -909,7 +931,7 @@ int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t 
 int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_PAN, panning, sample_time); }
 int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glide, uint64_t sample_time) {
   if (!(speed > 0.0)) return set_error(PG_ERR_PARAMETER, "speed must be > 0");
-  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = CMD_VOICE_SPEED; c.target = g->voices[voice_id].dev_index; c.value = glide; c.param = voice_id;
@@ -917,7 +939,7 @@ int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glid
   return push_event(g, g->voices[voice_id].mixer, sample_time, c);
 }
 int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint64_t sample_time) {
-  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   if (!(position_seconds >= 0.0)) return set_error(PG_ERR_PARAMETER, "seek position must be >= 0");
   PgCmd c;
   memset(&c, 0, sizeof c);
@@ -926,7 +948,7 @@ int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint
   return push_event(g, g->voices[voice_id].mixer, sample_time, c);
 }
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // MixerMessage::StopSource (mixed.rs:389-400): not an event
-  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = CMD_VOICE_STOP; c.target = g->voices[voice_id].dev_index; c.value64 = sample_time; c.param = voice_id;
@@ -966,7 +988,7 @@ int pg_graph_synchronize(pg_graph* g) {
   return PG_OK;
 }
 int pg_graph_is_voice_playing(pg_graph* g, int voice_id) {
-  if (voice_id < 0 || voice_id >= (int)g->voices.size()) return 0;
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return 0;
   (void)hipSetDevice(g->device);
   (void)hipStreamSynchronize(g->stream);
   PgVoice v;
@@ -1103,7 +1125,9 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
   bool any_events = false;
   for (auto& m : g->mixers) any_events |= !m.events.empty();
   bool main_sources_empty = g->main_active_voices == 0;
-  if (main_sources_empty && g->mixers[0].fx.empty() && g->mixers.size() == 1 && g->mixers[0].events.empty()) return 0;
+  bool no_sub_mixers = true;  // self.mixers.is_empty(): sub-mixers that were removed again do not count
+  for (size_t m = 1; m < g->mixers.size(); ++m) no_sub_mixers &= g->mixers[m].removed;
+  if (main_sources_empty && g->mixers[0].fx.empty() && no_sub_mixers && g->mixers[0].events.empty()) return 0;
   (void)any_events;
   const uint64_t frames = n_samples / 2;
   uint64_t done = 0;

@@ -619,3 +619,57 @@ def test_remove_and_move_effects_between_blocks():
     # each rearrangement is audible: the same graph without the actions differs block for block after the first one
     a0, _ = both(build, 16, 1024)
     assert np.array_equal(a[: 3 * 2048], a0[: 3 * 2048]) and np.abs(a[3 * 2048 :] - a0[3 * 2048 :]).max() > 1e-3
+
+
+def test_remove_mixer_with_nested_children_and_pending_events():
+    """Player::remove_mixer (MixerMessage::RemoveMixer, mixed.rs:422-424): a sub-mixer of the main mixer, a nested sub-mixer (its parent
+    goes back to the time-parallel kernels once it has no children left) and a whole branch with children, effects, voices and
+    pending events leave between blocks; their ids are unknown afterwards; with the last sub-mixer gone and no sources the main
+    mixer writes nothing."""
+    def build(g):
+        m1 = g.add_mixer()
+        g.add_effect(m1, _capi.FX_REVERB, params={"room": 0.4}, reverb_seeds=workloads.reverb_seeds(31))
+        v1 = g.add_voice(m1, workloads.tone_buffer(2, 44100, 0.3), 2, 44100, volume=0.7, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m2 = g.add_mixer()
+        f2 = g.add_effect(m2, _capi.FX_FILTER, params={"type": 0, "cuto": 1500.0})
+        g.add_voice(m2, workloads.tone_buffer(9, 48000, 0.3), 2, 48000, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m3 = g.add_mixer(m2)
+        g.add_effect(m3, _capi.FX_CHORUS)
+        g.add_voice(m3, workloads.tone_buffer(14, 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m4 = g.add_mixer(m2)
+        f4 = g.add_effect(m4, _capi.FX_GAIN, params={"gain": 0.8})
+        v4 = g.add_voice(m4, workloads.tone_buffer(17, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return dict(m1=m1, m2=m2, m3=m3, m4=m4, v1=v1, v4=v4, f2=f2, f4=f4)
+
+    def act2(g, ids, pos):
+        g.schedule_param(ids["f4"], "gain", 0.2, pos + 3000)   # dies with m4
+        g.set_voice_volume(ids["v4"], 0.1, pos + 2500)
+        g.remove_mixer(ids["m4"])
+        for call in (lambda: g.remove_mixer(ids["m4"]), lambda: g.add_effect(ids["m4"], _capi.FX_GAIN), lambda: g.schedule_param(ids["f4"], "gain", 0.3, pos),
+                     lambda: g.set_voice_volume(ids["v4"], 0.3, pos), lambda: g.remove_mixer(0), lambda: g.add_mixer(ids["m4"])):
+            with pytest.raises(Exception):
+                call()
+    def act4(g, ids, pos):
+        g.remove_mixer(ids["m3"])       # m2 has no children left
+    def act7(g, ids, pos):
+        g.remove_mixer(ids["m1"])
+    def act9(g, ids, pos):
+        g.schedule_param(ids["f2"], "cuto", 400.0, pos + 100)
+
+    a, b = both(build, 12, 1024, actions={2: act2, 4: act4, 7: act7, 9: act9})
+    compare(a, b)
+    assert np.abs(a[-2048:]).max() > 1e-3
+
+    def act_all(g, ids, pos):
+        g.remove_mixer(ids["m2"])       # the whole branch: m2, m3, m4
+        g.remove_mixer(ids["m1"])
+        with pytest.raises(Exception):
+            g.remove_mixer(ids["m3"])
+    gg, gc = graphs()
+    for g in (gg, gc):
+        ids = build(g)
+        out = np.full(2048, 5.0, np.float32)
+        assert g.write(out, 0) == 2048
+        act_all(g, ids, 1024)
+        out[:] = 5.0
+        assert g.write(out, 1024) == 0 and np.all(out == 5.0)
