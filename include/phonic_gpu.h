@@ -194,6 +194,10 @@ int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time);
 int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time);
 int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time);
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time);
+/* Player::stop_all_sources() (src/player.rs:1012-1045): stops every playing source from the next write on (with its fade-out) and sends
+ * MixerMessage::RemoveAllPendingEvents to every mixer (src/source/mixed.rs:298-305): sources that have not started by then and events
+ * scheduled after that write's position are dropped. */
+int pg_graph_stop_all_voices(pg_graph* g);
 /* FilePlaybackHandle::set_speed(speed, glide) / seek(position) (src/player/handles/file.rs -> MixerMessage::SetSourceSpeed /
  * SeekSource, src/source/mixed.rs:338-383; PreloadedFileSource::set_speed / seek, src/source/file/preloaded.rs:139-192).
  * glide_semitones_per_second <= 0 = no glide (Option<f32>::None). */

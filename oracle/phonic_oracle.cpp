@@ -180,6 +180,20 @@ static int push_event(MixedSource* mx, const MixedSource::MixerEvent& ev) {
   mx->message_queue.push_back(std::move(m));
   return PG_OK;
 }
+int po_graph_stop_all_voices(po_graph* g) {  // Player::stop_all_sources (src/player.rs:1012-1045)
+  for (auto& kv : g->voice_mixer) {  // send_stop() to every transient source: it stops when it is asked for output next
+    MixedSource::Message m;
+    m.kind = MixedSource::Message::StopSource;
+    m.id = kv.first; m.sample_time = 0;
+    kv.second->message_queue.push_back(std::move(m));
+  }
+  for (auto& kv : g->mixers) {  // scheduled sources and events of every mixer
+    MixedSource::Message m;
+    m.kind = MixedSource::Message::RemoveAllPendingEvents;
+    kv.second->message_queue.push_back(std::move(m));
+  }
+  return PG_OK;
+}
 int po_graph_remove_mixer(po_graph* g, int mixer_id) {  // Player::remove_mixer (src/player.rs:825-867)
   if (mixer_id == 0) return PG_ERR_PARAMETER;
   auto it = g->mixers.find(mixer_id);

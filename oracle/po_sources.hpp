@@ -389,7 +389,7 @@ struct MixedSource : Source {
     uint32_t param_id = 0; ParamUpdate update{false, 0.0f};
   };
   struct Message {
-    enum Kind { AddSource, StopSource, RemoveSource, AddMixer, RemoveMixer, AddEffect, RemoveEffect, MoveEffect, Event } kind;
+    enum Kind { RemoveAllPendingEvents, AddSource, StopSource, RemoveSource, AddMixer, RemoveMixer, AddEffect, RemoveEffect, MoveEffect, Event } kind;
     int movement = 0, offset = 0;  // EffectMovement: 0 = Direction(offset), 1 = Start, 2 = End (src/player.rs)
     std::unique_ptr<PlayingSource> source;
     int id = 0; uint64_t sample_time = 0;
@@ -446,11 +446,15 @@ struct MixedSource : Source {
       process_event(ev);
     }
   }
-  void process_messages(uint64_t) {  // :294-499
+  void process_messages(uint64_t pos_in_frames) {  // :294-499
     std::vector<Message> q;
     q.swap(message_queue);
     for (auto& m : q) {
       switch (m.kind) {
+        case Message::RemoveAllPendingEvents: {  // :298-305 (every played file source is transient)
+          for (size_t i = 0; i < playing_sources.size();) { if (playing_sources[i]->start_time > pos_in_frames) playing_sources.erase(playing_sources.begin() + i); else ++i; }
+          for (size_t i = 0; i < events.size();) { if (events[i].sample_time > pos_in_frames) events.erase(events.begin() + i); else ++i; }
+        } break;
         case Message::AddSource: {
           size_t insert_pos = 0;  // partition_point(|e| e.start_time < sample_time) :326-329
           while (insert_pos < playing_sources.size() && playing_sources[insert_pos]->start_time < m.source->start_time) ++insert_pos;

@@ -121,6 +121,7 @@ def declare(lib, prefix):
         "graph_schedule_reset": (C.c_int, [vp, C.c_int, C.c_uint64]),
         "graph_remove_effect": (C.c_int, [vp, C.c_int]),
         "graph_remove_mixer": (C.c_int, [vp, C.c_int]),
+        "graph_stop_all_voices": (C.c_int, [vp]),
         "graph_move_effect": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "graph_set_voice_volume": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_set_voice_panning": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),

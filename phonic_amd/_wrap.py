@@ -140,6 +140,10 @@ class GraphHandle:
             self._fn("graph_add_voice")(self._h, mixer_id, _f32p(pcm), pcm.size // src_channels, src_channels, src_rate, C.byref(o))
         )
 
+    def stop_all_voices(self):
+        """Player::stop_all_sources (src/player.rs:1012-1045)."""
+        self._check(self._fn("graph_stop_all_voices")(self._h))
+
     def remove_mixer(self, mixer_id):
         """Player::remove_mixer (src/player.rs:825-867)."""
         self._check(self._fn("graph_remove_mixer")(self._h, mixer_id))

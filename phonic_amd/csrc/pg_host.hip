@@ -402,6 +402,7 @@ struct HostMixer {
   int depth = 1;                   // main mixer 0, its sub-mixers 1, their sub-mixers 2 ...
   std::vector<int> children;       // nested sub-mixers, in the order they were added
   bool removed = false;            // Player::remove_mixer: gone from its parent (with everything under it)
+  bool remove_pending = false;     // MixerMessage::RemoveAllPendingEvents waiting for the next write (it needs that write's position)
 };
 // Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
 // deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
@@ -739,6 +740,39 @@ int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_ini
   g->mixers[mixer_id].fx.push_back(idx);
   g->topo_dirty = true;
   return idx;
+}
+
+// Player::stop_all_sources (src/player.rs:1012-1045): every playing file source is told to stop (fades out from the next write on,
+// like pg_graph_stop_voice at "now"), and every mixer gets MixerMessage::RemoveAllPendingEvents (src/source/mixed.rs:298-305), which
+// at the start of the next write drops the sources that have not started yet and the events scheduled after that write's position.
+int pg_graph_stop_all_voices(pg_graph* g) {
+  for (size_t v = 0; v < g->voices.size(); ++v) {
+    if (g->voices[v].mixer < 0) continue;
+    PgCmd c;
+    memset(&c, 0, sizeof c);
+    c.type = CMD_VOICE_STOP; c.target = g->voices[v].dev_index; c.value64 = 0; c.param = (int)v;
+    g->mixers[g->voices[v].mixer].messages.push_back(c);
+  }
+  for (HostMixer& mx : g->mixers) if (!mx.removed) mx.remove_pending = true;
+  return PG_OK;
+}
+static void apply_remove_pending(pg_graph* g, uint64_t pos) {
+  for (HostMixer& mx : g->mixers) {
+    if (!mx.remove_pending) continue;
+    mx.remove_pending = false;
+    for (size_t i = 0; i < mx.voices.size();) {
+      const int v = mx.voices[i];
+      if (g->voices[v].start_time > pos) {
+        mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [v](const PgCmd& c) { return c.param == v; }), mx.messages.end());
+        g->voices[v].mixer = -1;
+        mx.voices.erase(mx.voices.begin() + i);
+        if (&mx == &g->mixers[0] && g->main_active_voices > 0) g->main_active_voices -= 1;
+        g->topo_dirty = true;
+      } else ++i;
+    }
+    mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), [pos](const Event& e) { return e.sample_time > pos; }), mx.events.end());
+    mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), [pos](const Event& e) { return e.sample_time > pos; }), mx.bus_events.end());
+  }
 }
 
 // Player::remove_mixer -> MixerMessage::RemoveMixer to the parent (src/player.rs:825-867, src/source/mixed.rs:422-424): from the next write
@@ -1120,6 +1154,7 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
   if (g->failed) return 0;
   if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   (void)hipSetDevice(g->device);
+  apply_remove_pending(g, pos);
   if (g->topo_dirty && rebuild_topology(g)) { g->failed = true; return 0; }
   // "Return early and avoid touching the buffer if there's nothing to do" (:664-670)
   bool any_events = false;

@@ -673,3 +673,32 @@ def test_remove_mixer_with_nested_children_and_pending_events():
         act_all(g, ids, 1024)
         out[:] = 5.0
         assert g.write(out, 1024) == 0 and np.all(out == 5.0)
+
+
+def test_stop_all_voices_and_pending_events():
+    """Player::stop_all_sources (player.rs:1012-1045): playing sources fade out from the next block on (default 50 ms fade-out), a
+    source scheduled for later never starts, events scheduled after the next write's position are dropped (MixerMessage::
+    RemoveAllPendingEvents, mixed.rs:298-305) while one due exactly at that position still fires; sources added afterwards play."""
+    def build(g):
+        m = g.add_mixer()
+        fx = g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.9})
+        v0 = g.add_voice(m, workloads.tone_buffer(4, 44100, 0.5), 2, 44100, volume=0.8, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        v1 = g.add_voice(0, workloads.tone_buffer(10, 48000, 0.5), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        late_sub = g.add_voice(m, workloads.tone_buffer(7, 44100, 0.5), 2, 44100, start_time=6000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        late_main = g.add_voice(0, workloads.tone_buffer(8, 48000, 0.5), 2, 48000, start_time=9000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return dict(m=m, fx=fx, v0=v0, v1=v1, late_sub=late_sub, late_main=late_main)
+
+    def act3(g, ids, pos):
+        g.schedule_param(ids["fx"], "gain", 0.3, pos)          # due at the next write's position: survives
+        g.schedule_param(ids["fx"], "gain", 2.0, pos + 10)     # later: dropped
+        g.set_voice_volume(ids["v1"], 1.0, pos + 700)          # dropped
+        g.stop_all_voices()
+    def act9(g, ids, pos):
+        g.add_voice(ids["m"], workloads.tone_buffer(20, 44100, 0.2), 2, 44100, volume=0.4, start_time=pos + 100)
+
+    a, b = both(build, 14, 1024, actions={3: act3, 9: act9})
+    compare(a, b)
+    blk = lambda i: a[i * 2048 : (i + 1) * 2048]
+    assert np.abs(blk(2)).max() > 0.02 and np.abs(blk(3)).max() > 1e-3    # fading
+    assert np.abs(blk(7)).max() < 1e-4 and np.abs(blk(8)).max() < 1e-4    # 50 ms later: silence; the late sources never start
+    assert np.abs(blk(10)).max() > 1e-3                                     # the source added afterwards plays
