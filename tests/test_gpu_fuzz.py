@@ -63,16 +63,19 @@ def test_random_graph_matches_oracle(seed):
     outs = []
     for which in ("gpu", "oracle"):
         g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
-        fx_ids, voice_ids = [], []
+        fx_ids, voice_ids, fx_mixer = [], [], {}
         for chain, voices in plan["mixers"]:
             m = g.add_mixer()
             for (k, p, s) in chain:
                 fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+                fx_mixer[fx_ids[-1][0]] = m
             for (ti, rate, vol, pan) in voices:
                 voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
         for (k, p, s) in plan["bus"]:
             fx_ids.append((g.add_effect(0, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+            fx_mixer[fx_ids[-1][0]] = 0
         chunks, pos = [], 0
+        rng2 = np.random.default_rng(9000 + seed)  # chain mutations (Player::move_effect / remove_effect): the same draws for both sides
         for b, n in enumerate(sizes):
             if b == ev_block:
                 g.set_voice_volume(voice_ids[0], 0.3, pos + 17)
@@ -81,6 +84,14 @@ def test_random_graph_matches_oracle(seed):
                     d = descs[k][0]
                     if d["type"] == 0:
                         g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos + n // 2, normalized=True)
+            if b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
+                fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
+                if fid in fx_mixer:
+                    if rng2.random() < 0.6:
+                        g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
+                    else:
+                        g.remove_effect(fid)
+                        del fx_mixer[fid]
             o = np.zeros(2 * n, np.float32)
             assert g.write(o, pos) in (0, 2 * n)
             chunks.append(o)
@@ -126,12 +137,14 @@ def test_random_nested_graph_matches_oracle(seed):
     outs = []
     for which in ("gpu", "oracle"):
         g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
-        ids, fx_ids, voice_ids = [], [], []
+        ids, fx_ids, voice_ids, fx_mixer = [], [], [], {}
+        rng2 = np.random.default_rng(7000 + seed)  # chain mutations: the same draws for both sides
         for parent, chain, voices in mixers:
             m = g.add_mixer(None if parent < 0 else ids[parent])
             ids.append(m)
             for (k, p, s) in chain:
                 fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+                fx_mixer[fx_ids[-1][0]] = m
             for (ti, rate, vol, pan) in voices:
                 voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
         chunks, pos = [], 0
@@ -143,10 +156,18 @@ def test_random_nested_graph_matches_oracle(seed):
                 if fx_ids and pick % 2 == 0:
                     fid, k = fx_ids[(pick >> 1) % len(fx_ids)]
                     d = descs[k][0]
-                    if d["type"] == 0:
+                    if d["type"] == 0 and fid in fx_mixer:
                         g.schedule_param(fid, fourcc_str(d["fourcc"]), val, t, normalized=True)
                         continue
                 g.set_voice_volume(voice_ids[(pick >> 1) % len(voice_ids)], val, t)
+            if b in (3, 5) and fx_ids and seed % 2 == 1:  # Player::move_effect / remove_effect between blocks
+                fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
+                if fid in fx_mixer:
+                    if rng2.random() < 0.6:
+                        g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
+                    else:
+                        g.remove_effect(fid)
+                        del fx_mixer[fid]
             o = np.zeros(2 * n, np.float32)
             assert g.write(o, pos) in (0, 2 * n)
             chunks.append(o)
