@@ -68,9 +68,13 @@ DEVO bool delay_fast_eligible(const PgFx& fx) {
   if (sm_need_ramp(d.delay_time) || sm_need_ramp(d.feedback) || sm_need_ramp(d.cutoff) || sm_need_ramp(d.drive) || sm_need_ramp(d.wet) ||
       sm_need_ramp(d.width) || sm_need_ramp(d.lfo_rate) || sm_need_ramp(d.d_time) || sm_need_ramp(d.d_feedback) || sm_need_ramp(d.d_filter))
     return false;
-  if (d.d_time.target != 0.0f || d.d_feedback.target != 0.0f || d.d_filter.target != 0.0f) return false;  // LFO modulation: serial path
-  const float delay_samples = fmaxf(d.delay_time.target, 1.0f) * 0.001f * (float)fx.sample_rate;
-  return delay_samples >= 66.0f && delay_samples < (float)(d.mask - 8);
+  if (d.d_filter.target != 0.0f) return false;  // LFO -> filter cutoff: per-frame SVF coefficients, serial path
+  // LFO -> time moves the tap by up to +-|depth| * 50 ms (delay.rs:349-352; |lfo| <= 1 up to the parabolic sine's overshoot, covered
+  // by the margin): the chunk length follows the shortest delay the block can see
+  const float dev_ms = fabsf(d.d_time.target) * 50.0f * 1.01f + 0.01f;
+  const float min_samples = fmaxf(d.delay_time.target - (d.d_time.target != 0.0f ? dev_ms : 0.0f), 1.0f) * 0.001f * (float)fx.sample_rate;
+  const float max_samples = fmaxf(d.delay_time.target + (d.d_time.target != 0.0f ? dev_ms : 0.0f), 1.0f) * 0.001f * (float)fx.sample_rate;
+  return min_samples >= 66.0f && max_samples < (float)(d.mask - 8);
 }
 
 DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
@@ -88,6 +92,11 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   const float delay_samples = delay_ms * 0.001f * srf;
   const float fb = clampf(d.feedback.target + 0.0f, 0.0f, 0.999f);
   const float drive = d.drive.target, wet = d.wet.target, width = d.width.target;
+  // LFO -> time / feedback: the LFO's value differs per frame. Its f32 phase sequence is laid out per chunk by one lane (the plain
+  // accumulation, exact by construction) in the first floats of the free `tmp` rows; everything that depends on it is element-wise.
+  const float time_depth = d.d_time.target, fb_depth = d.d_feedback.target;
+  const bool lfo_mod = time_depth != 0.0f || fb_depth != 0.0f;
+  float* ph = fc.tmp;
   __syncthreads();
   if (tid == 0) {
     const float cutoff = clampf(d.cutoff.target * 1.0f, 20.0f, (float)fx.sample_rate / 2.0f);
@@ -100,7 +109,9 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     *lco = c;
   }
   __syncthreads();
-  const int t_max = (int)floorf(delay_samples) - 1;
+  int t_max = (int)floorf(delay_samples) - 1;
+  if (time_depth != 0.0f) t_max = (int)floorf(fmaxf(d.delay_time.target - (fabsf(time_depth) * 50.0f * 1.01f + 0.01f), 1.0f) * 0.001f * srf) - 2;
+  if (lfo_mod && t_max > fc.tmp_floats) t_max = fc.tmp_floats;
   const uint32_t mask = d.mask;
   const float dry_gain = fminf((1.0f - wet) * 2.0f, 1.0f);
   const float wet_gain = fminf(wet * 2.0f, 1.0f);
@@ -114,12 +125,27 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     const uint32_t wp0[2] = {d.write_pos[0], d.write_pos[1]};
     const float fb_in[2] = {d.fb[0], d.fb[1]};
     __syncthreads();
+    if (lfo_mod) {
+      if (tid == 0) {  // lfo.run() once per frame (delay.rs:343): the phase each frame reads, then the update
+        float p = d.lfo.phase;
+        const float inc = d.lfo.phase_inc;
+        for (int k = 0; k < T; ++k) { ph[k] = p; p += inc; if (p >= 1.0f) p -= 1.0f; }
+        d.lfo.phase = p;
+      }
+      __syncthreads();
+    }
     // 1. taps + interpolation (delay.rs:118-134)
     for (int s = tid; s < 2 * T; s += nt) {
       const int nn = s >> 1, ch = s & 1;
       const gdouble* line = (const gdouble*)d.line[ch];
       const uint32_t wp = (wp0[ch] + (uint32_t)nn) & mask;
-      const double read_pos = (double)wp - (double)delay_samples;
+      float delay_samples_n = delay_samples;
+      if (time_depth != 0.0f) {  // delay.rs:349-352
+        PgLfo l; l.phase = ph[nn]; l.phase_inc = 0.0f; l.waveform = d.lfo.waveform;
+        const float time_mod_ms = lfo_value(l) * time_depth * 50.0f;
+        delay_samples_n = fmaxf(d.delay_time.target + time_mod_ms, 1.0f) * 0.001f * srf;
+      }
+      const double read_pos = (double)wp - (double)delay_samples_n;
       const double read_pos_floor = floor(read_pos);
       const double fraction = read_pos - read_pos_floor;
       const long long index1 = (long long)read_pos_floor;
@@ -143,9 +169,15 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const float clean_l = clampf((float)buf[REV_IDX(nn, 0)], -4.0f, 4.0f), clean_r = clampf((float)buf[REV_IDX(nn, 1)], -4.0f, 4.0f);
       float prev_l = fb_in[0], prev_r = fb_in[1];
       if (nn > 0) { prev_l = clampf((float)buf[REV_IDX(nn - 1, 0)], -4.0f, 4.0f); prev_r = clampf((float)buf[REV_IDX(nn - 1, 1)], -4.0f, 4.0f); }
+      float fb_n = fb;
+      if (fb_depth != 0.0f) {  // delay.rs:366-372
+        PgLfo l; l.phase = ph[nn]; l.phase_inc = 0.0f; l.waveform = d.lfo.waveform;
+        const float base_feedback = d.feedback.target;
+        fb_n = clampf(base_feedback + lfo_value(l) * fb_depth * (1.0f - fabsf(base_feedback)), 0.0f, 0.999f);
+      }
       float line_in;
-      if (mode == 0) line_in = (ch == 0 ? left_input + prev_l * fb : right_input + prev_r * fb);       // stereo  :386-399
-      else line_in = (ch == 0 ? (left_input + right_input) * 0.5f + prev_r * fb : prev_l * fb);         // ping-pong :400-418
+      if (mode == 0) line_in = (ch == 0 ? left_input + prev_l * fb_n : right_input + prev_r * fb_n);       // stereo  :386-399
+      else line_in = (ch == 0 ? (left_input + right_input) * 0.5f + prev_r * fb_n : prev_l * fb_n);         // ping-pong :400-418
       ((gdouble*)d.line[ch])[(wp0[ch] + (uint32_t)nn) & mask] = (double)line_in;
       // dry/wet law and M/S width (delay.rs:424-452); the lane of channel `ch` writes its own output sample
       const float out_l = left_input * dry_gain + clean_l * wet_gain;
@@ -167,7 +199,7 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     __syncthreads();
     done += T;
   }
-  if (tid == 0) f32_phase_advance(d.lfo.phase, d.lfo.phase_inc, frames);  // lfo.run() once per frame (delay.rs:343)
+  if (tid == 0 && !lfo_mod) f32_phase_advance(d.lfo.phase, d.lfo.phase_inc, frames);  // lfo.run() once per frame (delay.rs:343)
   __syncthreads();
   return true;
 }
