@@ -63,12 +63,86 @@ DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] 
   }
 }
 
+// The TPT-SVF with coefficients that change every frame (LFO -> filter cutoff), over the chunk, both channels, in place:
+//   s_{n+1} = A_n s_n + B_n x_n   — still linear in the state, so the blocked scan of rev_biquad_scan_t carries over with one change:
+// a segment's transition is the product of its eight A_n (accumulated in pass 1) instead of a power of one matrix, and the
+// Kogge-Stone scan combines (matrix, offset) pairs:  (Mc, zc) after (Mp, zp)  =  (Mc Mp,  zc + Mc zp).
+// `coef(n, a1, a2, a3, k)` recomputes frame n's coefficients (the same expressions as svf_apply, so the same values as the serial
+// loop's per-frame svf_set); type = SvfFilterType of the output tap.
+template <typename CoefFn>
+DEVO void svf_scan_time_varying(CoefFn coef, int type, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ch = wave & 1, half = wave >> 1;
+  const int seg = half * 64 + lane;
+  const int n0 = seg * 8;
+  const int len = n0 >= T ? 0 : (T - n0 < 8 ? T - n0 : 8);
+  // pass 1: zero-state response (segment 0: from the carried state) and the segment's transition matrix
+  double s1 = 0.0, s2 = 0.0;
+  if (seg == 0) { s1 = st[ch].ic1eq; s2 = st[ch].ic2eq; }
+  Mat2 M{1.0, 0.0, 0.0, 1.0};
+  for (int k = 0; k < len; ++k) {
+    double a1, a2, a3, kk;
+    coef(n0 + k, a1, a2, a3, kk);
+    const double v0 = buf[REV_IDX(n0 + k, ch)];
+    const double v3 = v0 - s2;
+    const double v1 = a1 * s1 + a2 * v3;
+    const double v2 = s2 + a2 * s1 + a3 * v3;
+    s1 = 2.0 * v1 - s1;
+    s2 = 2.0 * v2 - s2;
+    M = mat2_mul(Mat2{2.0 * a1 - 1.0, -2.0 * a2, 2.0 * a2, 1.0 - 2.0 * a3}, M);
+  }
+  const Mat2 Mseg = M;
+  auto wave_scan = [&](Mat2& Ma, double& z1, double& z2) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double y1 = __shfl_up(z1, off, 64), y2 = __shfl_up(z2, off, 64);
+      const Mat2 Y{__shfl_up(Ma.a, off, 64), __shfl_up(Ma.b, off, 64), __shfl_up(Ma.c, off, 64), __shfl_up(Ma.d, off, 64)};
+      if (lane >= off) {
+        z1 = z1 + (Ma.a * y1 + Ma.b * y2);
+        const double z2n = z2 + (Ma.c * y1 + Ma.d * y2);
+        z2 = z2n;
+        Ma = mat2_mul(Ma, Y);
+      }
+    }
+  };
+  if (half == 0) {
+    wave_scan(M, s1, s2);
+    if (lane == 63) { xchg[ch * 2] = s1; xchg[ch * 2 + 1] = s2; }
+  }
+  __syncthreads();
+  double e1 = s1, e2 = s2;
+  if (half == 1) {
+    if (lane == 0) { const double x1 = xchg[ch * 2], x2 = xchg[ch * 2 + 1]; const double t1 = s1 + (Mseg.a * x1 + Mseg.b * x2); s2 = s2 + (Mseg.c * x1 + Mseg.d * x2); s1 = t1; }
+    wave_scan(M, s1, s2);
+    e1 = s1; e2 = s2;
+  }
+  double b1 = __shfl_up(e1, 1, 64), b2 = __shfl_up(e2, 1, 64);
+  if (lane == 0) {
+    if (half == 0) { b1 = st[ch].ic1eq; b2 = st[ch].ic2eq; }
+    else { b1 = xchg[ch * 2]; b2 = xchg[ch * 2 + 1]; }
+  }
+  // pass 2: every segment again from its true start state, writing the outputs (svf_tick, svf.rs:211-222)
+  for (int k = 0; k < len; ++k) {
+    double a1, a2, a3, kk;
+    coef(n0 + k, a1, a2, a3, kk);
+    const double v0 = buf[REV_IDX(n0 + k, ch)];
+    const double v3 = v0 - b2;
+    const double v1 = a1 * b1 + a2 * v3;
+    const double v2 = b2 + a2 * b1 + a3 * v3;
+    b1 = 2.0 * v1 - b1;
+    b2 = 2.0 * v2 - b2;
+    buf[REV_IDX(n0 + k, ch)] = type == 0 ? v2 : (type == 2 ? v1 : v0 - kk * v1 - v2);
+  }
+  __syncthreads();
+  if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
+}
+
 DEVO bool delay_fast_eligible(const PgFx& fx) {
   const PgDelay& d = fx.u.delay;
   if (sm_need_ramp(d.delay_time) || sm_need_ramp(d.feedback) || sm_need_ramp(d.cutoff) || sm_need_ramp(d.drive) || sm_need_ramp(d.wet) ||
       sm_need_ramp(d.width) || sm_need_ramp(d.lfo_rate) || sm_need_ramp(d.d_time) || sm_need_ramp(d.d_feedback) || sm_need_ramp(d.d_filter))
     return false;
-  if (d.d_filter.target != 0.0f) return false;  // LFO -> filter cutoff: per-frame SVF coefficients, serial path
   // LFO -> time moves the tap by up to +-|depth| * 50 ms (delay.rs:349-352; |lfo| <= 1 up to the parabolic sine's overshoot, covered
   // by the margin): the chunk length follows the shortest delay the block can see
   const float dev_ms = fabsf(d.d_time.target) * 50.0f * 1.01f + 0.01f;
@@ -94,8 +168,8 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   const float drive = d.drive.target, wet = d.wet.target, width = d.width.target;
   // LFO -> time / feedback: the LFO's value differs per frame. Its f32 phase sequence is laid out per chunk by one lane (the plain
   // accumulation, exact by construction) in the first floats of the free `tmp` rows; everything that depends on it is element-wise.
-  const float time_depth = d.d_time.target, fb_depth = d.d_feedback.target;
-  const bool lfo_mod = time_depth != 0.0f || fb_depth != 0.0f;
+  const float time_depth = d.d_time.target, fb_depth = d.d_feedback.target, filter_depth = d.d_filter.target;
+  const bool lfo_mod = time_depth != 0.0f || fb_depth != 0.0f || filter_depth != 0.0f;
   float* ph = fc.tmp;
   __syncthreads();
   if (tid == 0) {
@@ -156,7 +230,29 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     }
     __syncthreads();
     // 2. wet path
-    rev_biquad_scan(*lco, d.flt, buf, T, xchg);
+    if (filter_depth != 0.0f) {
+      // LFO -> filter (delay.rs:354-363): frame n's cutoff = clamp(cutoff * 2^(lfo_n * depth * 2)), its SVF coefficients as svf_apply
+      const float cutoff_base = d.cutoff.target, nyq = (float)fx.sample_rate / 2.0f;
+      const double srd = (double)fx.sample_rate;
+      const double kq = fmax(2.0 * (1.0 - (double)0.302f * 0.97), 0.03);
+      const int wf = d.lfo.waveform;
+      auto coef = [&](int n, double& a1, double& a2, double& a3, double& kk) {
+        PgLfo l; l.phase = ph[n]; l.phase_inc = 0.0f; l.waveform = wf;
+        const float filter_mod = powf(2.0f, lfo_value(l) * filter_depth * 2.0f);
+        const float cutoff = clampf(cutoff_base * filter_mod, 20.0f, nyq);
+        const double g = tan(F64_PI * (double)cutoff / srd);
+        kk = kq;
+        a1 = 1.0 / (1.0 + g * (g + kq));
+        a2 = g * a1;
+        a3 = g * a2;
+      };
+      svf_scan_time_varying(coef, delay_to_svf(d.filter_type), d.flt, buf, T, xchg);
+      if (tid == 0) {  // the coefficient cache as the serial loop leaves it: set for the chunk's last frame
+        PgLfo l; l.phase = ph[T - 1]; l.phase_inc = 0.0f; l.waveform = wf;
+        const float cutoff = clampf(cutoff_base * powf(2.0f, lfo_value(l) * filter_depth * 2.0f), 20.0f, nyq);
+        svf_set(d.coef, delay_to_svf(d.filter_type), fx.sample_rate, cutoff, 0.302f);
+      }
+    } else rev_biquad_scan(*lco, d.flt, buf, T, xchg);
     __syncthreads();
     for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); buf[bi] = delay_saturate(buf[bi], drive); }
     __syncthreads();

@@ -706,9 +706,9 @@ def test_stop_all_voices_and_pending_events():
 
 @pytest.mark.parametrize("shape", [0, 1, 2, 3, 4])
 def test_delay_with_lfo_on_time_and_feedback_takes_the_time_parallel_path(shape):
-    """DelayEffect with its LFO modulating delay time and / or feedback (delay.rs:343-372; LFO -> filter stays on the serial path):
-    per-frame tap positions and feedback from the exact f32 phase sequence, chunk length from the shortest delay of the sweep.
-    Every deterministic LFO shape, stereo and ping-pong, a fast LFO; nothing is handed to the serial kernel in steady state."""
+    """DelayEffect with its LFO modulating delay time and / or feedback (delay.rs:343-372):
+    per-frame tap positions, feedback and filter coefficients from the exact f32 phase sequence, chunk length from the shortest delay of
+    the sweep. Every deterministic LFO shape, stereo and ping-pong, a fast LFO; nothing is handed to the serial kernel in steady state."""
     def build(g):
         m1 = g.add_mixer()
         g.add_effect(m1, _capi.FX_DELAY, params={"dlay": 120.0, "fdbk": 0.6, "lfor": 7.3, "lfos": shape, "lfdt": 0.6, "ldfb": -0.5})
@@ -720,6 +720,13 @@ def test_delay_with_lfo_on_time_and_feedback_takes_the_time_parallel_path(shape)
         m3 = g.add_mixer()
         g.add_effect(m3, _capi.FX_DELAY, params={"dlay": 250.0, "fdbk": 0.7, "lfor": 2.0, "lfos": shape, "ldfb": 0.9})
         g.add_voice(m3, workloads.tone_buffer(19, 44100, 0.3), 2, 44100, volume=0.7, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        # LFO -> filter cutoff: per-frame SVF coefficients (time-varying blocked scan), each filter type, alone and with the other two
+        for i, (ftyp, extra) in enumerate(((0, {}), (1, {"lfdt": 0.3}), (2, {"ldfb": 0.4, "lfdt": -0.5}))):
+            m = g.add_mixer()
+            p = {"dlay": 90.0 + 40.0 * i, "fdbk": 0.65, "ftyp": ftyp, "cuto": 1500.0 + 900.0 * i, "lfor": 3.1 + i, "lfos": shape, "lfdf": 0.8 - 0.7 * i, "driv": 0.2 * i}
+            p.update(extra)
+            g.add_effect(m, _capi.FX_DELAY, params=p)
+            g.add_voice(m, workloads.tone_buffer(23 + i, 44100, 0.3), 2, 44100, volume=0.7, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
         return {}
 
     for blk, n in ((1024, 30), (700, 12)):
