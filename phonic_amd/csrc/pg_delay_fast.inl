@@ -67,10 +67,11 @@ DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] 
 //   s_{n+1} = A_n s_n + B_n x_n   — still linear in the state, so the blocked scan of rev_biquad_scan_t carries over with one change:
 // a segment's transition is the product of its eight A_n (accumulated in pass 1) instead of a power of one matrix, and the
 // Kogge-Stone scan combines (matrix, offset) pairs:  (Mc, zc) after (Mp, zp)  =  (Mc Mp,  zc + Mc zp).
-// `coef(n, a1, a2, a3, k)` recomputes frame n's coefficients (the same expressions as svf_apply, so the same values as the serial
-// loop's per-frame svf_set); type = SvfFilterType of the output tap.
-template <typename CoefFn>
-DEVO void svf_scan_time_varying(CoefFn coef, int type, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
+// `coef(n, a1, a2, a3, m0, m1, m2)` recomputes frame n's coefficients (the same expressions as svf_apply / biquad_apply, so the same
+// values as the serial loop's per-frame set); output = m0 v0 + m1 v1 + m2 v2 (for the SVF taps: (0,0,1), (0,1,0), (1,-k,-1)),
+// rounded through f32 when the reference stores the filtered sample as f32 (FilterEffect).
+template <bool ROUND_F32, typename CoefFn>
+DEVO void svf_scan_time_varying(CoefFn coef, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
@@ -82,8 +83,8 @@ DEVO void svf_scan_time_varying(CoefFn coef, int type, PgState2* st, double* buf
   if (seg == 0) { s1 = st[ch].ic1eq; s2 = st[ch].ic2eq; }
   Mat2 M{1.0, 0.0, 0.0, 1.0};
   for (int k = 0; k < len; ++k) {
-    double a1, a2, a3, kk;
-    coef(n0 + k, a1, a2, a3, kk);
+    double a1, a2, a3, m0, m1, m2;
+    coef(n0 + k, a1, a2, a3, m0, m1, m2);
     const double v0 = buf[REV_IDX(n0 + k, ch)];
     const double v3 = v0 - s2;
     const double v1 = a1 * s1 + a2 * v3;
@@ -124,15 +125,16 @@ DEVO void svf_scan_time_varying(CoefFn coef, int type, PgState2* st, double* buf
   }
   // pass 2: every segment again from its true start state, writing the outputs (svf_tick, svf.rs:211-222)
   for (int k = 0; k < len; ++k) {
-    double a1, a2, a3, kk;
-    coef(n0 + k, a1, a2, a3, kk);
+    double a1, a2, a3, m0, m1, m2;
+    coef(n0 + k, a1, a2, a3, m0, m1, m2);
     const double v0 = buf[REV_IDX(n0 + k, ch)];
     const double v3 = v0 - b2;
     const double v1 = a1 * b1 + a2 * v3;
     const double v2 = b2 + a2 * b1 + a3 * v3;
     b1 = 2.0 * v1 - b1;
     b2 = 2.0 * v2 - b2;
-    buf[REV_IDX(n0 + k, ch)] = type == 0 ? v2 : (type == 2 ? v1 : v0 - kk * v1 - v2);
+    const double y = m0 * v0 + m1 * v1 + m2 * v2;
+    buf[REV_IDX(n0 + k, ch)] = ROUND_F32 ? (double)(float)y : y;
   }
   __syncthreads();
   if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
@@ -236,17 +238,18 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const double srd = (double)fx.sample_rate;
       const double kq = fmax(2.0 * (1.0 - (double)0.302f * 0.97), 0.03);
       const int wf = d.lfo.waveform;
-      auto coef = [&](int n, double& a1, double& a2, double& a3, double& kk) {
+      const int svf_type = delay_to_svf(d.filter_type);
+      auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
         PgLfo l; l.phase = ph[n]; l.phase_inc = 0.0f; l.waveform = wf;
         const float filter_mod = powf(2.0f, lfo_value(l) * filter_depth * 2.0f);
         const float cutoff = clampf(cutoff_base * filter_mod, 20.0f, nyq);
         const double g = tan(F64_PI * (double)cutoff / srd);
-        kk = kq;
+        if (svf_type == 0) { m0 = 0.0; m1 = 0.0; m2 = 1.0; } else if (svf_type == 2) { m0 = 0.0; m1 = 1.0; m2 = 0.0; } else { m0 = 1.0; m1 = -kq; m2 = -1.0; }
         a1 = 1.0 / (1.0 + g * (g + kq));
         a2 = g * a1;
         a3 = g * a2;
       };
-      svf_scan_time_varying(coef, delay_to_svf(d.filter_type), d.flt, buf, T, xchg);
+      svf_scan_time_varying<false>(coef, d.flt, buf, T, xchg);
       if (tid == 0) {  // the coefficient cache as the serial loop leaves it: set for the chunk's last frame
         PgLfo l; l.phase = ph[T - 1]; l.phase_inc = 0.0f; l.waveform = wf;
         const float cutoff = clampf(cutoff_base * powf(2.0f, lfo_value(l) * filter_depth * 2.0f), 20.0f, nyq);

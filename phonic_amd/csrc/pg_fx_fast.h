@@ -52,6 +52,45 @@ DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs
   }
   __syncthreads();
 }
+// FilterEffect while cutoff and / or Q ramp (filter.rs:166-192): the two smoothers' f32 value sequences are laid out by one lane (the
+// same sm_next calls as the serial loop: exact, including the frame at which a ramp ends), every frame's coefficients are
+// recomputed from them as biquad_apply does, and the recurrence runs as the time-varying blocked scan.
+DEVO void filter_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  PgFilter& f = fx.u.filter;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* buf = (double*)fc.scratch;
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  float* cut = fc.tmp;            // [T] cutoff per frame (already clamped), then [T] q per frame
+  const int frames = n_samples / 2;
+  const int piece = fc.tmp_floats / 2 < 1024 ? fc.tmp_floats / 2 : 1024;
+  const float nyq = (float)fx.sample_rate / 2.0f;
+  const int btype = filter_to_biquad(f.type);
+  const uint32_t sr = fx.sample_rate;
+  for (int done = 0; done < frames; done += piece) {
+    const int T = frames - done < piece ? frames - done : piece;
+    float* qv = cut + T;
+    __syncthreads();
+    if (tid == 0) {
+      PgSmooth sc = f.cutoff, sq = f.q;
+      for (int k = 0; k < T; ++k) { cut[k] = clampf(sm_next(sc), 20.0f, nyq); qv[k] = sm_next(sq); }
+      f.cutoff = sc; f.q = sq;
+    }
+    for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
+    __syncthreads();
+    auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
+      PgBiquadCoef c;
+      c.type = btype; c.sample_rate = sr; c.cutoff = cut[n]; c.q = qv[n]; c.gain = 0.0f;
+      c.a1 = 0.0; c.a2 = 0.0; c.a3 = 0.0; c.m0 = 0.0; c.m1 = 0.0; c.m2 = 0.0;
+      (void)biquad_apply(c);
+      a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
+    };
+    svf_scan_time_varying<true>(coef, f.st, buf, T, xchg);
+    __syncthreads();
+    if (tid == 0) (void)biquad_set(f.coef, btype, sr, cut[T - 1], qv[T - 1], 0.0f);  // the coefficient set the serial loop ends the block with
+    for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)];
+  }
+  __syncthreads();
+}
 DEVO bool eq5_steady(const PgEq5& e) {
   bool ramp = false;
   for (int i = 0; i < 5; ++i) ramp = ramp || sm_need_ramp(e.freqs[i]) || sm_need_ramp(e.bws[i]) || sm_need_ramp(e.gains[i]);
@@ -63,7 +102,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx) {
   switch (fx.kind) {
     case 0: return !sm_need_ramp(fx.u.gain.gain);
     case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
-    case 2: return !sm_need_ramp(fx.u.filter.cutoff) && !sm_need_ramp(fx.u.filter.q);
+    case 2: return true;  // ramping cutoff / Q: time-varying scan
     case 3: return eq5_steady(fx.u.eq5);
     case 4: return delay_fast_eligible(fx);
     case 5: return reverb_fast_eligible(fx);
@@ -134,7 +173,11 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     }
     case 2: if constexpr ((KMASK >> 2) & 1) {  // FilterEffect, no ramp (filter.rs:193-200)
       PgFilter& f = fx.u.filter;
-      if (sm_need_ramp(f.cutoff) || sm_need_ramp(f.q)) return false;
+      if (sm_need_ramp(f.cutoff) || sm_need_ramp(f.q)) {
+        if (fc.tmp_floats < 16) return false;
+        filter_ramp_fast(fx, sig, n, fc);
+        return true;
+      }
       biquad_chain_fast(sig, n, &f.coef, f.st, 1, 1, fc);
       return true;
     } else return false;

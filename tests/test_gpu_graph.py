@@ -741,3 +741,49 @@ def test_delay_with_lfo_on_time_and_feedback_takes_the_time_parallel_path(shape)
     for i in range(5):
         g.write(out, i * 1024)
     assert g.deferred_units() == 0
+
+
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3])
+def test_filter_cutoff_and_q_ramps_take_the_time_parallel_path(ftype):
+    """FilterEffect while cutoff and Q ramp (filter.rs:166-192: coefficients recomputed every frame): smoother value sequences laid out
+    exactly, per-frame coefficients, time-varying blocked scan. Every filter type, ramps that start mid-block, overlap and end
+    mid-block; also in front of a Reverb (wide staged kernel). After the block that holds the parameter event the unit is back on
+    the time-parallel kernels although the ramp is still running."""
+    def build(g):
+        m1 = g.add_mixer()
+        f1 = g.add_effect(m1, _capi.FX_FILTER, params={"type": ftype, "cuto": 4000.0, "fltq": 0.9})
+        g.add_voice(m1, workloads.tone_buffer(6, 44100, 0.3), 2, 44100, volume=0.8, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_voice(m1, workloads.tone_buffer(30, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m2 = g.add_mixer()
+        f2 = g.add_effect(m2, _capi.FX_FILTER, params={"type": ftype, "cuto": 800.0})
+        g.add_effect(m2, _capi.FX_REVERB, params={"room": 0.3}, reverb_seeds=workloads.reverb_seeds(61))
+        g.add_voice(m2, workloads.tone_buffer(11, 44100, 0.3), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return dict(f1=f1, f2=f2)
+
+    def act2(g, ids, pos):
+        g.schedule_param(ids["f1"], "cuto", 300.0, pos + 333)
+        g.schedule_param(ids["f2"], "cuto", 6000.0, pos + 900)
+    def act4(g, ids, pos):
+        g.schedule_param(ids["f1"], "fltq", 3.0, pos + 10)
+    def act9(g, ids, pos):
+        g.schedule_param(ids["f1"], "cuto", 9000.0, pos + 512)
+        g.schedule_param(ids["f1"], "fltq", 0.3, pos + 700)
+
+    for blk, n in ((1024, 40), (600, 30)):
+        a, b = both(build, n, blk, actions={2: act2, 4: act4, 9: act9}, max_frames=1024)
+        compare(a, b)
+        assert np.abs(a).max() > 1e-2
+    from phonic_amd.graph import Graph
+
+    g = Graph(SR, 2, 1024, 0)
+    ids = build(g)
+    out = np.zeros(2048, np.float32)
+    for i in range(3):
+        g.write(out, i * 1024)
+    g.schedule_param(ids["f1"], "fltq", 3.5, 3 * 1024 + 5)   # Q: linear steps of 0.01 per frame at 44.1 kHz -> some hundred frames
+    g.schedule_param(ids["f1"], "cuto", 200.0, 3 * 1024 + 5)
+    g.write(out, 3 * 1024)
+    assert g.deferred_units() >= 1
+    g.write(out, 4 * 1024)
+    g.write(out, 5 * 1024)
+    assert g.deferred_units() == 0
