@@ -462,7 +462,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
 
   if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
     int ramping = 0;
-    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]]) ? 0 : 1;
+    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]], unit.staged != 0) ? 0 : 1;
     for (int vi = 0; vi < unit.n_voices; ++vi) {  // a pitch glide in progress is rendered here as well
       const PgVoice& vv = L.voices[L.voice_index[unit.voice_off + vi]];
       ramping |= (vv.current_speed != vv.target_speed) ? 1 : 0;
@@ -499,7 +499,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
 // Fast-kernel variants by the effect kinds compiled in: the lean one (Gain, Panning, Reverb = the headline per-voice chain)
 // keeps the hot loop free of spills; the wide one adds Filter, Eq5 and Distortion. The host picks by the kinds present.
 #define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
-#define PG_KMASK_ALL 0x3ff
+#define PG_KMASK_ALL 0x7ff  // bits 0..9: effect kinds; bit 10: the ramp paths (FilterEffect cutoff / Q)
 #define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
 // leading effects of the wide staged kernel: every kind with a time-parallel path whose LDS needs fit stage 1's arena (no Chorus)
 #define PG_KMASK_LEADING ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 9))
