@@ -143,7 +143,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from phonic_amd.graph import Graph
-    from phonic_amd.parallel import reduce_master_bus
+    from phonic_amd.parallel import MasterBusRing, reduce_master_bus
 
     name = args.workload
     v_per_gpu = args.voices or DEFAULT_VOICES[name]
@@ -169,51 +169,32 @@ def main():
     # workgroup resident on some CU leaves one render workgroup waiting for a second round, so fewer, larger reduces also mean fewer
     # disturbed blocks.
     M = 1 if (world == 1 or bus_on_root) else max(1, args.reduce_every)
-    N_BUS = 4
-    buses = [torch.zeros(M * n_samples, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(N_BUS)]
-    pending = [None] * N_BUS
     # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
     # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
     render_stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.synchronize()
     torch.cuda.set_stream(render_stream)
     stream = render_stream.cuda_stream
+    ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0)
+    if bus_on_root:
+        ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
     pos = 0
-    step_no = 0
 
     def step():
-        nonlocal pos, step_no
-        k = (step_no // M) % N_BUS
-        j = step_no % M
-        if j == 0 and pending[k] is not None:  # buffer reuse: the reduce issued N_BUS super-blocks ago must have finished
-            pending[k].wait()
-            pending[k] = None
-        bus = buses[k]
-        w = g.write_device(bus.data_ptr() + j * n_samples * 4, n_samples, pos, stream)
+        nonlocal pos
+        bus = ring.slot()
+        w = g.write_device(bus.data_ptr(), n_samples, pos, stream)
         if w != n_samples:
             raise RuntimeError("graph write failed: " + str(w))
-        if world > 1:
-            if bus_on_root:
-                reduce_master_bus(bus, root=0)
-                if rank == 0:
-                    g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
-            elif j == M - 1:
-                pending[k] = dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        if world > 1 and bus_on_root:
+            reduce_master_bus(bus, root=0)
+            if rank == 0:
+                g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
+        ring.submit()
         pos += block
-        step_no += 1
 
-    def drain():
-        nonlocal step_no
-        # a super-block the loop left partly filled still owes its reduce (every rank has rendered the same number of blocks)
-        j = step_no % M
-        if world > 1 and not bus_on_root and j != 0:
-            k = (step_no // M) % N_BUS
-            pending[k] = dist.reduce(buses[k][: j * n_samples], dst=0, op=dist.ReduceOp.SUM, async_op=True)
-            step_no += M - j  # the next block opens a fresh super-block
-        for k in range(N_BUS):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+    drain = ring.drain
+    buses = ring.buffers
 
     for _ in range(args.warmup):
         step()

@@ -3,6 +3,7 @@ ranks — the reference's own parallel axis is independent sub-mixers (src/sourc
 and the partial master buses meet in ONE sum-reduce per block (the caller-side sum of worker outputs,
 src/source/mixed.rs:522-536). On ROCm torch.distributed's "nccl" backend is RCCL over xGMI; the same code runs on
 gloo for the CPU tests. The per-block message is 8 bytes x frames (8 KiB at 1024 frames): latency bound."""
+import torch
 import torch.distributed as dist
 
 
@@ -19,3 +20,50 @@ def reduce_master_bus(bus, root=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(bus, dst=root, op=dist.ReduceOp.SUM, group=group)
     return bus
+
+
+class MasterBusRing:
+    """Master-bus buffers of the sharded render: a ring of `n_buffers` super-blocks of `blocks_per_reduce` blocks each. A rank renders
+    block `step` into `slot(step)`; `submit(step)` issues ONE asynchronous sum-reduce to `root` when that block completes its
+    super-block (SURVEY §8e "per super-block": offline rendering has no deadline per block; 1 = per block, the real-time setting);
+    `slot` waits for the reduce issued `n_buffers` super-blocks ago before its buffer is written again; `drain()` reduces a partly
+    filled super-block, waits for everything in flight and lets the next block open a fresh super-block. With RCCL the reduce
+    runs on RCCL's own stream, ordered behind the render stream by an event, under the renders of the following super-blocks;
+    `Work.wait()` only makes the current stream wait. Without a process group the ring is plain double buffering (world size 1)."""
+
+    def __init__(self, n_samples, blocks_per_reduce, device, n_buffers=4, root=0, group=None):
+        self.n_samples, self.m, self.n_buffers, self.root, self.group = int(n_samples), max(1, int(blocks_per_reduce)), int(n_buffers), root, group
+        self.buffers = [torch.zeros(self.m * self.n_samples, dtype=torch.float32, device=device) for _ in range(self.n_buffers)]
+        self.pending = [None] * self.n_buffers
+        self.step = 0  # next block (super-block aligned after drain())
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def _where(self):
+        return (self.step // self.m) % self.n_buffers, self.step % self.m
+
+    def slot(self):
+        """The [n_samples] view the next block is rendered into (on the root it later holds the sum over ranks)."""
+        k, j = self._where()
+        if j == 0 and self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        return self.buffers[k][j * self.n_samples : (j + 1) * self.n_samples]
+
+    def submit(self):
+        """The block rendered into `slot()` is complete (enqueued on the current stream): advance, reduce a finished super-block."""
+        k, j = self._where()
+        self.step += 1
+        if self.distributed and j == self.m - 1:
+            self.pending[k] = dist.reduce(self.buffers[k], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return k, j
+
+    def drain(self):
+        k, j = self._where()
+        if j != 0:  # every rank has rendered the same number of blocks: the partly filled super-block still owes its reduce
+            if self.distributed:
+                self.pending[k] = dist.reduce(self.buffers[k][: j * self.n_samples], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.step += self.m - j
+        for i in range(self.n_buffers):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None

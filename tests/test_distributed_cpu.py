@@ -83,3 +83,63 @@ def test_two_rank_voice_sharding_and_bus_reduce():
     # f32 sum order differs (shard sums are reduced instead of one serial sum): reassociation error only
     np.testing.assert_allclose(got, ref, atol=2e-7)
     assert np.abs(ref).max() > 1e-3
+
+
+def _ring_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phonic_amd.parallel import MasterBusRing
+
+    n, m = 8, 3
+    ring = MasterBusRing(n, m, "cpu", n_buffers=2, root=0)
+    val = lambda step, r: float((step + 1) * (1 if r == 0 else 100))   # the rank's partial bus of block `step`: a constant
+
+    def run(first, count):
+        for step in range(first, first + count):
+            ring.slot().fill_(val(step, rank))
+            ring.submit()
+
+    snaps = []
+    run(0, 5)            # super-block 0 complete (one reduce), super-block 1 holds two blocks
+    ring.drain()         # ... reduced as a partial super-block; the next block opens a fresh super-block
+    snaps.append([b.clone().numpy() for b in ring.buffers])
+    run(5, 7)            # three more super-blocks through the ring of two: buffers are written again behind their reduces
+    ring.drain()
+    snaps.append([b.clone().numpy() for b in ring.buffers])
+    ring.drain()         # nothing in flight: a no-op
+    if rank == 0:
+        q.put(snaps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_master_bus_ring_super_block_reduce_two_ranks():
+    """phonic_amd.parallel.MasterBusRing — the buffer ring bench.py renders into at N > 1 — over gloo with two ranks: one reduce per
+    complete super-block, the partly filled one at drain(), buffer reuse behind the reduce issued a ring round earlier. The root
+    ends up with the sum over ranks of every block, in the slot the block was rendered into."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    snaps = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, m = 8, 3
+    total = lambda step: float((step + 1) * 101)
+    first, second = snaps
+    # after 5 blocks + drain: buffer 0 = blocks 0, 1, 2; buffer 1 = blocks 3, 4 (third slot never written)
+    for j, step in enumerate((0, 1, 2)):
+        assert np.all(first[0][j * n : (j + 1) * n] == total(step))
+    for j, step in enumerate((3, 4)):
+        assert np.all(first[1][j * n : (j + 1) * n] == total(step))
+    assert np.all(first[1][2 * n :] == 0.0)
+    # blocks 5 .. 11 start at a super-block boundary (ring position 2 -> buffer 0): 5-7 in buffer 0, 8-10 in buffer 1, 11 in buffer 0 again
+    assert np.all(second[1][: n] == total(8)) and np.all(second[1][n : 2 * n] == total(9)) and np.all(second[1][2 * n :] == total(10))
+    assert np.all(second[0][: n] == total(11))                       # reduced alone by drain()
+    assert np.all(second[0][n : 2 * n] == total(6)) and np.all(second[0][2 * n :] == total(7))   # left from the reduce of blocks 5-7
