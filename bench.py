@@ -7,11 +7,17 @@ workload = the configuration BASELINE.json's target is quoted on: "headline" = 1
 -> cubic resampler -> gain/pan -> per-voice Reverb -> mixer sum (SURVEY.md §8d "H"), per GPU.
 
   python bench.py --gpus 1 --steps 50 --warmup 10
+  python bench.py --gpus N ...                     (spawns one child process per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N --workload c5 --scaling strong --total-voices 8192     (BASELINE config 5)
 
-Multi-GPU: voices are sharded over ranks (weak scaling: --voices per GPU), each rank renders its partial master
-bus on its GPU, and the partial buses meet in one RCCL sum-reduce to rank 0 per block (the reference's caller-side
-sum of worker outputs, src/source/mixed.rs:522-536).
+Multi-GPU: voices are sharded over ranks (weak scaling: --voices per GPU; strong scaling: --total-voices split over the
+ranks), each rank renders its partial master bus on its GPU, and the partial buses meet in one RCCL sum-reduce to rank 0 per
+super-block (the reference's caller-side sum of worker outputs, src/source/mixed.rs:522-536).
+
+The timed leg renders `--repeats` (default 5) legs of exactly `--steps` blocks, each bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `ms_per_step` / `value` come from the MEDIAN leg and
+the spread is printed under `repeats`.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel launch(es) of the graph, named in `roofline.kernel`, hipEvent-timed
 on the launching stream) and `cpu_baseline` (the CPU oracle — a C++ port of the reference path, NOT the Rust binary — on this
@@ -20,23 +26,28 @@ box's host cores, bounded sample of about 12 s).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np  # noqa: E402
 
 # algorithmic bytes per voice-frame (derivation in DESIGN.md)
 B_ALG = {"headline": 423.4, "c2": 14.6, "c3": 36.0, "c4": 7.5, "c5": 456.0}
 DEFAULT_VOICES = {"headline": 1024, "c2": 64, "c3": 1024, "c4": 256, "c5": 1024}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WORKLOAD_TEXT = {
+    "headline": "H: 1024 stereo 44.1k voices -> cubic resampler -> gain/pan -> per-voice Reverb -> mixer sum",
+    "c2": "C2: 64 stereo 48k voices, Eq5+Reverb on the bus",
+    "c3": "C3: 1024 mono voices, per-voice Filter+Chorus",
+    "c4": "C4: 256 stereo 44.1k voices -> cubic -> bus limiter",
+    "c5": "C5: per-voice Filter->Eq5->Delay->Reverb",
+}
 
 
 def build_workload(g, name, n_voices, first_voice, total_voices, seconds):
-    import workloads
+    from phonic_amd import workloads
 
     if name == "headline":
         workloads.build_headline(g, n_voices, first_voice, total_voices, seconds)
@@ -53,37 +64,48 @@ def build_workload(g, name, n_voices, first_voice, total_voices, seconds):
 
 
 def pmc_traffic(name, v_per_gpu, block):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 FETCH correction applied), if one matches this configuration.
-    bench.py cannot run the profiler on itself; the file names the command that produced it."""
+    """HBM bytes per 1024-frame block of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 FETCH correction applied). Only a file recorded with THIS build of the
+    kernels counts: the file carries the hash of the library sources it was measured with (phonic_amd._capi.source_hash);
+    bench.py cannot run the profiler on itself. Returns (bytes or None, note)."""
     import glob
 
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+    from phonic_amd import _capi
+
+    have = _capi.source_hash()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") == name and d.get("voices_per_gpu") == v_per_gpu and d.get("block_frames") == block:
-            best = d
-    return best["traffic_bytes_per_launch"] if best else None
+            if d.get("source_hash") == have:
+                return d["traffic_bytes_per_block"] if "traffic_bytes_per_block" in d else d["traffic_bytes_per_launch"], os.path.basename(f)
+            stale = stale or os.path.basename(f)
+    return None, (f"no PMC pass recorded for source hash {have}" + (f" (latest: {stale}, other build)" if stale else ""))
 
 
 def cpu_baseline(name, block, seconds_budget=12.0):
     """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core). A short parallel
-    run calibrates the block count so that the timed sample takes about `seconds_budget` seconds on this host."""
+    run calibrates the block count so that the timed sample takes about `seconds_budget` seconds on this host. The library timed
+    here is oracle/_build/libphonic_oracle_native.so (-O3 -march=native, built on this host when g++ is there), else
+    the portable -O2 build the parity tests use; the flags are reported."""
     import ctypes as C
 
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
 
     cores = os.cpu_count() or 1
     threads = cores
-    lib = oracle.lib()
+    lib, flags = oracle.lib_native()
     per_graph = {"headline": 4, "c2": 16, "c3": 8, "c4": 32, "c5": 2}[name]
     n_graphs = threads
 
     def run(n_blocks):
-        graphs = [oracle.OracleGraph(48000, 2, block) for _ in range(n_graphs)]
+        graphs = [oracle.OracleGraph(48000, 2, block, library=lib) for _ in range(n_graphs)]
         for i, g in enumerate(graphs):
             build_workload(g, name, per_graph, i * per_graph, per_graph * n_graphs, 0.5)
         handles = (C.c_void_p * n_graphs)(*[g._h for g in graphs])
@@ -102,8 +124,41 @@ def cpu_baseline(name, block, seconds_budget=12.0):
         "unit": "voice-frames/s",
         "cores": threads,
         "kind": "port",
+        "flags": flags,
         "sample": f"{n_graphs} oracle graphs x {per_graph} voices x {n_blocks} blocks of {block} frames, {threads} threads, {dt:.1f} s",
     }
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, exactly what torch.distributed.run sets) BEFORE this process imports torch or touches HIP — a process that has
+    initialised the GPU must never be replaced or forked — forward rank 0's JSON line and fail if any rank fails."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 600
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if any(rc != 0 for rc in rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
 
 
 def main():
@@ -111,16 +166,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed legs of --steps blocks each; the median leg is reported")
     ap.add_argument("--workload", default="headline", choices=sorted(B_ALG))
-    ap.add_argument("--voices", type=int, default=0, help="voices PER GPU (default: the config's count)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --voices per GPU; strong: --total-voices split over the GPUs")
+    ap.add_argument("--voices", type=int, default=0, help="weak scaling: voices PER GPU (default: the config's count)")
+    ap.add_argument("--total-voices", type=int, default=0, help="strong scaling: voices of the whole job (default: c5 8192, else the config's count)")
     ap.add_argument("--block", type=int, default=1024)
+    ap.add_argument("--superblock", type=int, default=16, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
-    ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th step (the event pair costs ~8 us per step)")
-    ap.add_argument("--reduce-every", type=int, default=16, help="multi-GPU: blocks per RCCL master-bus reduce (offline super-block; 1 = per block, the real-time setting)")
+    ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th launch round (the event pair costs ~8 us of stream time)")
+    ap.add_argument("--reduce-every", type=int, default=0, help="multi-GPU: blocks per RCCL master-bus reduce (default: the super-block; 1 = per block, the real-time setting)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -128,47 +191,56 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # PHONIC_BENCH_SHARED_GPU=1 (test hook, 1-GPU boxes): every rank renders on GPU 0 and the ranks meet over gloo — exercises the
     # multi-rank control flow (sharding, buffer ring, async reduce, timing) where RCCL cannot run (it refuses two ranks on one GPU)
     shared_gpu = os.environ.get("PHONIC_BENCH_SHARED_GPU", "") == "1"
     if shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if shared_gpu else "nccl"
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from phonic_amd.graph import Graph
-    from phonic_amd.parallel import MasterBusRing, reduce_master_bus
+    from phonic_amd.parallel import MasterBusRing, reduce_master_bus, shard_range
 
     name = args.workload
-    v_per_gpu = args.voices or DEFAULT_VOICES[name]
-    total_voices = v_per_gpu * world
+    if args.scaling == "strong":
+        total_voices = args.total_voices or (8192 if name == "c5" else DEFAULT_VOICES[name])
+        first_voice, v_per_gpu = shard_range(total_voices, rank, world)
+    else:
+        v_per_gpu = args.voices or DEFAULT_VOICES[name]
+        total_voices = v_per_gpu * world
+        first_voice = rank * v_per_gpu
     block = args.block
+    bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
+    sb = max(1, args.superblock)
+    if bus_on_root:
+        sb = 1  # the bus chain (one serial workgroup) runs per block behind the per-block reduce
     g = Graph(48000, 2, block, local_rank)
     if args.exact:
         g.set_fast_math(0)
     g.set_staged(args.staged)
     g.set_timing_period(args.time_every)
-    bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
     if world > 1 and bus_on_root:
         g.set_defer_bus(True)
-    build_workload(g, name, v_per_gpu, rank * v_per_gpu, total_voices, 2.0)
+    build_workload(g, name, v_per_gpu, first_voice, total_voices, 2.0)
 
     n_samples = block * 2
     # Master-bus buffers: a ring of N_BUS super-blocks of M blocks each. Offline rendering (the reference's WavOutput pull loop,
-    # src/output/wav.rs:210-250) has no deadline per block, so the partial buses of M consecutive blocks travel in ONE RCCL reduce
-    # (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own stream, ordered after the renders by an
-    # event) overlaps the renders of the following ones, and the render stream only waits when a buffer comes round again.
-    # --reduce-every 1 is the real-time setting (one reduce per block). Bus effects on the root (c2 / c4) run per block.
-    # The headline launch fills the chip exactly (1024 workgroups = 256 CUs x 4 resident): a block whose dispatch finds an RCCL
-    # workgroup resident on some CU leaves one render workgroup waiting for a second round, so fewer, larger reduces also mean fewer
-    # disturbed blocks.
-    M = 1 if (world == 1 or bus_on_root) else max(1, args.reduce_every)
+    # src/output/wav.rs:210-250) has no deadline per block, so M consecutive blocks are rendered by ONE pg_graph_write_device call
+    # (the reference's MixedSource::write loops over its <= 4096-frame chunks the same way, src/source/mixed.rs:679-712) and their
+    # partial buses travel in ONE RCCL reduce (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own
+    # stream, ordered after the renders by an event) overlaps the renders of the following ones, and the render stream only waits
+    # when a buffer comes round again. --superblock 1 is the real-time setting (one call and one reduce per block).
+    M = 1 if bus_on_root else max(sb, args.reduce_every or sb)
+    M = (M + sb - 1) // sb * sb  # a reduce covers whole super-blocks
     # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
     # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
     render_stream = torch.cuda.Stream(device=local_rank)
@@ -180,51 +252,70 @@ def main():
         ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
     pos = 0
 
-    def step():
+    def render(n_blocks):
+        """n_blocks consecutive blocks: super-blocks of `sb` (one ABI call each), the remainder in one smaller call."""
         nonlocal pos
-        bus = ring.slot()
-        w = g.write_device(bus.data_ptr(), n_samples, pos, stream)
-        if w != n_samples:
-            raise RuntimeError("graph write failed: " + str(w))
-        if world > 1 and bus_on_root:
-            reduce_master_bus(bus, root=0)
-            if rank == 0:
-                g.process_bus_device(bus.data_ptr(), n_samples, pos, stream)
-        ring.submit()
-        pos += block
+        done = 0
+        while done < n_blocks:
+            k = min(sb, n_blocks - done, ring.room())
+            bus = ring.slots(k)
+            w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
+            if w != k * n_samples:
+                raise RuntimeError("graph write failed: " + str(w))
+            if world > 1 and bus_on_root:
+                reduce_master_bus(bus, root=0)
+                if rank == 0:
+                    g.process_bus_device(bus.data_ptr(), k * n_samples, pos, stream)
+            ring.submit(k)
+            pos += k * block
+            done += k
 
-    drain = ring.drain
-    buses = ring.buffers
+    def leg(n_blocks):
+        torch.cuda.synchronize()
+        g.kernel_ms(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        render(n_blocks)
+        ring.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches, blocks = g.kernel_stats(reset=True)
+        return dt, ms, launches, blocks
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    g.kernel_ms(reset=True)
+    render(args.warmup)
+    ring.drain()
+    legs = [leg(args.steps) for _ in range(max(1, args.repeats))]
+    dts = [l[0] for l in legs]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = g.kernel_ms(reset=True)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    peak = float(max(b.abs().max().item() for b in buses))
+        dts = [float(x) for x in t.tolist()]
+    torch.cuda.synchronize()
+    last = ring.last_block()
+    peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
 
     if rank == 0:
-        vf_total = total_voices * block * args.steps
-        value = vf_total / dt
-        vf_per_launch = v_per_gpu * block
-        achieved = B_ALG[name] * vf_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        med = int(np.argsort(dts)[len(dts) // 2])
+        dt = dts[med]
+        value = total_voices * block * args.steps / dt
+        # roofline of the dominant kernel: algorithmic bytes of one launch / its average duration. A launch renders `blocks_per_launch`
+        # blocks of this rank's voices (super-block launches loop over the blocks inside the kernel).
+        per_leg = []
+        for (_, ms, launches, blocks) in legs:
+            if launches and ms > 0:
+                bpl = blocks / launches
+                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * block * bpl / (ms * 1e-3) / 1e9, launches))
+        if per_leg:
+            ach = sorted(p[2] for p in per_leg)
+            ms_l, bpl_l, achieved, launches_l = sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
+        else:
+            ach, ms_l, bpl_l, achieved, launches_l = [0.0], 0.0, 0.0, 0.0, 0
+        traffic, traffic_note = pmc_traffic(name, v_per_gpu, block)
         out = {
             "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample",
             "value": value,
@@ -234,21 +325,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "repeats": {"n": len(dts), "reported": "median", "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_median": dt / args.steps * 1e3,
+                        "ms_per_step_max": max(dts) / args.steps * 1e3},
             "config": {
-                "workload": {"headline": "H: 1024 stereo 44.1k voices -> cubic resampler -> gain/pan -> per-voice Reverb -> mixer sum",
-                             "c2": "C2: 64 stereo 48k voices, Eq5+Reverb on the bus", "c3": "C3: 1024 mono voices, per-voice Filter+Chorus",
-                             "c4": "C4: 256 stereo 44.1k voices -> cubic -> bus limiter", "c5": "C5: per-voice Filter->Eq5->Delay->Reverb"}[name],
+                "workload": WORKLOAD_TEXT[name],
                 "voices_per_gpu": v_per_gpu,
                 "total_voices": total_voices,
                 "block_frames": block,
+                "blocks_per_call": sb,
                 "sample_rate": 48000,
                 "master_frames_per_s": value / total_voices,
                 "x_realtime": value / total_voices / 48000.0,
-                "sharding": f"voices/{world}" + (f" + RCCL reduce(sum) of the master bus per {M} block(s)" if world > 1 else ""),
+                "sharding": f"voices/{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} reduce(sum) of the master bus per {M} block(s)" if world > 1 else ""),
+                "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else (0 if world > 1 else 1),
+                "backend": backend,
                 "exact_mode": bool(args.exact),
                 "bus_peak": peak,
             },
@@ -258,12 +352,18 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(name, v_per_gpu, block),
+                "frac_min": ach[0] / HBM_PEAK_GBS,
+                "frac_max": ach[-1] / HBM_PEAK_GBS,
+                "traffic": traffic * bpl_l if traffic else None,
+                "traffic_note": traffic_note,
                 "kernel": g.dominant_kernel(),
-                "kernel_ms": kernel_ms,
-                "launches": launches,
+                "kernel_ms": ms_l,
+                "blocks_per_launch": bpl_l,
+                "kernel_ms_per_block": ms_l / bpl_l if bpl_l else 0.0,
+                "launches": launches_l,
                 "timed_every": args.time_every,
                 "bytes_per_voice_frame": B_ALG[name],
+                "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * block * bpl_l,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -312,6 +312,11 @@ int po_graphs_render_parallel(po_graph** graphs, int n_graphs, int threads, floa
   return PG_OK;
 }
 
+#ifndef PO_BUILD_FLAGS
+#define PO_BUILD_FLAGS "unknown"
+#endif
+const char* po_build_flags(void) { return PO_BUILD_FLAGS; }  // compiler flags of this build (reported by bench.py's cpu_baseline)
+
 // ---- primitive probes for the KAT tests ------------------------------------------------------
 void po_clear_buffer(float* d, size_t n) { clear_buffer(d, n); }
 void po_scale_buffer(float* d, size_t n, float v) { scale_buffer(d, n, v); }

@@ -160,6 +160,23 @@ def _preload_hip_runtime():
         pass
 
 
+def source_hash():
+    """16 hex digits over the sources libphonic_gpu.so is built from (csrc/*.hip|.h|.inl, the Makefile, include/phonic_gpu.h). Profiles that
+    bench.py quotes (profiles/*_pmc_traffic.json) carry the hash of the build they were measured with."""
+    import glob
+    import hashlib
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) + glob.glob(os.path.join(here, "csrc", "*.inl")))
+    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(os.path.dirname(here), "include", "phonic_gpu.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libphonic_gpu.so")
 
@@ -214,6 +231,8 @@ def load():
     lib.pg_graph_is_voice_playing.argtypes = [vp, C.c_int]
     lib.pg_graph_kernel_ms.restype = C.c_double
     lib.pg_graph_kernel_ms.argtypes = [vp, C.c_int, P(C.c_uint64)]
+    lib.pg_graph_kernel_stats.restype = C.c_int
+    lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
     lib.pg_graph_set_fast_math.restype = C.c_int
     lib.pg_graph_set_fast_math.argtypes = [vp, C.c_int]
     lib.pg_graph_set_timing_period.restype = C.c_int

@@ -465,6 +465,7 @@ struct pg_graph {
   unsigned long long* d_diag = nullptr;  // diagnostic builds
   // timing of the dominant kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<uint32_t> ev_blocks;  // max_frames blocks the timed launch rendered (super-block launches: several)
   size_t ev_used = 0;
 };
 
@@ -1038,18 +1039,31 @@ int pg_graph_deferred_units(pg_graph* g) {
   const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
   return fb == ~0ull ? 0 : (int)(uint32_t)fb;
 }
-double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
+// Timing of the dominant kernel: every timed launch holds a hipEvent pair (riding the dispatch or bracketing the launches). The
+// pairs are waited for one by one (hipEventSynchronize on the stop event: the launches may sit on a caller's stream), pairs that
+// cannot be read are left out of the sum AND of the count.
+int pg_graph_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* launches, uint64_t* blocks) {
   (void)hipSetDevice(g->device);
-  (void)hipStreamSynchronize(g->stream);
   double total = 0.0;
+  uint64_t n_ok = 0, n_blocks = 0;
   for (size_t i = 0; i < g->ev_used; ++i) {
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, g->ev_pool[i].first, g->ev_pool[i].second) == hipSuccess) total += ms;
+    if (hipEventSynchronize(g->ev_pool[i].second) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, g->ev_pool[i].first, g->ev_pool[i].second) != hipSuccess) continue;
+    total += ms; n_ok += 1; n_blocks += g->ev_blocks[i];
   }
-  if (launches) *launches = g->ev_used;
-  double avg = g->ev_used ? total / (double)g->ev_used : 0.0;
+  if (total_ms) *total_ms = total;
+  if (launches) *launches = n_ok;
+  if (blocks) *blocks = n_blocks;
   if (reset) g->ev_used = 0;
-  return avg;
+  return PG_OK;
+}
+double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
+  double total = 0.0;
+  uint64_t n = 0;
+  (void)pg_graph_kernel_stats(g, reset, &total, &n, nullptr);
+  if (launches) *launches = n;
+  return n ? total / (double)n : 0.0;
 }
 
 // One launch round: all graph units for frames [t0, t0+n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
@@ -1090,6 +1104,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     g->ev_pool.emplace_back(a, b);
+    g->ev_blocks.push_back(1);
   }
   size_t timed_level = 0;  // the level holding most units carries the timing events
   for (size_t li = 1; li < g->levels.size(); ++li) if (g->levels[li].cnt > g->levels[timed_level].cnt) timed_level = li;
@@ -1135,7 +1150,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
       HIP_TRY(pg_launch_units(L, stream, e0, e1));
     }
   }
-  if (timed) g->ev_used++;
+  if (timed) { g->ev_blocks[g->ev_used] = 1; g->ev_used++; }
   L.mode = 0;
   // the main mixer sums the rows of its own sub-mixers and sources: the last level
   const Level& top = g->levels.back();

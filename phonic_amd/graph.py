@@ -46,6 +46,13 @@ class Graph(GraphHandle):
         ms = self._lib.pg_graph_kernel_ms(self._h, 1 if reset else 0, C.byref(n))
         return ms, n.value
 
+    def kernel_stats(self, reset=True):
+        """(average ms per timed launch of the dominant kernel, timed launches, blocks those launches rendered): a super-block launch
+        renders several max_frames blocks per unit."""
+        ms, n, b = C.c_double(0.0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.pg_graph_kernel_stats(self._h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(b)))
+        return (ms.value / n.value if n.value else 0.0), n.value, b.value
+
     def set_timing_period(self, every_n_rounds):
         """Time every n-th round with a hipEvent pair (the pair costs ~8 us of stream time); 0 = never."""
         self._check(self._lib.pg_graph_set_timing_period(self._h, int(every_n_rounds)))

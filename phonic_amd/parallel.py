@@ -36,26 +36,44 @@ class MasterBusRing:
         self.buffers = [torch.zeros(self.m * self.n_samples, dtype=torch.float32, device=device) for _ in range(self.n_buffers)]
         self.pending = [None] * self.n_buffers
         self.step = 0  # next block (super-block aligned after drain())
+        self._last = None
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
     def _where(self):
         return (self.step // self.m) % self.n_buffers, self.step % self.m
 
-    def slot(self):
-        """The [n_samples] view the next block is rendered into (on the root it later holds the sum over ranks)."""
+    def room(self):
+        """Blocks left in the super-block being filled."""
+        return self.m - self.step % self.m
+
+    def slots(self, n_blocks=1):
+        """The [n_blocks * n_samples] view the next `n_blocks` consecutive blocks are rendered into (n_blocks <= room()); on the root
+        it later holds the sum over ranks."""
         k, j = self._where()
+        assert 1 <= n_blocks <= self.m - j, (n_blocks, j, self.m)
         if j == 0 and self.pending[k] is not None:
             self.pending[k].wait()
             self.pending[k] = None
-        return self.buffers[k][j * self.n_samples : (j + 1) * self.n_samples]
+        return self.buffers[k][j * self.n_samples : (j + n_blocks) * self.n_samples]
 
-    def submit(self):
-        """The block rendered into `slot()` is complete (enqueued on the current stream): advance, reduce a finished super-block."""
+    def slot(self):
+        return self.slots(1)
+
+    def submit(self, n_blocks=1):
+        """The blocks rendered into `slots(n_blocks)` are complete (enqueued on the current stream): advance, reduce a finished super-block."""
         k, j = self._where()
-        self.step += 1
-        if self.distributed and j == self.m - 1:
+        self.step += n_blocks
+        self._last = (k, j + n_blocks - 1)
+        if self.distributed and j + n_blocks == self.m:
             self.pending[k] = dist.reduce(self.buffers[k], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return k, j
+
+    def last_block(self):
+        """View of the block submitted last (call after drain(): on the root it then holds the reduced sum)."""
+        if getattr(self, "_last", None) is None:
+            return None
+        k, j = self._last
+        return self.buffers[k][j * self.n_samples : (j + 1) * self.n_samples]
 
     def drain(self):
         k, j = self._where()

@@ -58,6 +58,27 @@ def lib():
     return _LIB
 
 
+_NATIVE = None
+
+
+def lib_native():
+    """(library, flags) for the cpu_baseline leg of bench.py: oracle/_build/libphonic_oracle_native.so (-O3 -march=native, `make native`,
+    built on the host it is timed on — it must not travel between hosts), else the portable build."""
+    global _NATIVE
+    if _NATIVE is None:
+        portable_flags = "-O2 -ffp-contract=off -fno-fast-math (portable build)"
+        try:
+            subprocess.run(["make", "-s", "-C", ORACLE_DIR, "native"], check=True, capture_output=True, timeout=300)
+            l = C.CDLL(os.path.join(ORACLE_DIR, "_build", "libphonic_oracle_native.so"))
+            _capi.declare(l, "po_")
+            l.po_graphs_render_parallel.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_uint64]
+            l.po_build_flags.restype = C.c_char_p
+            _NATIVE = (l, l.po_build_flags().decode())
+        except Exception:
+            _NATIVE = (lib(), portable_flags)
+    return _NATIVE
+
+
 def fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -74,5 +95,5 @@ class OracleEffect(EffectHandle):
 
 
 class OracleGraph(GraphHandle):
-    def __init__(self, sample_rate=48000, channels=2, max_frames=4096):
-        super().__init__(lib(), "po_", sample_rate, channels, max_frames, 0)
+    def __init__(self, sample_rate=48000, channels=2, max_frames=4096, library=None):
+        super().__init__(library or lib(), "po_", sample_rate, channels, max_frames, 0)

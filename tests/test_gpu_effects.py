@@ -182,11 +182,38 @@ def test_delay_time_parallel_path_short_delays_and_lfo_phase(mode, ftyp, dlay):
     """The time-parallel DelayEffect path (LFO depths 0, nothing ramping): delays of a few ms force many chunks per block
     (chunk <= floor(delay_samples) - 1), both routing modes and the three feedback-filter types. The LFO only advances its phase
     there (closed-form f32 accumulation); switching the LFO depths on afterwards hands over to the serial path, which must
-    continue from exactly the phase the reference would have — any drift shows up in the modulated blocks."""
+    continue from exactly the phase the reference would have — any drift shows up in the modulated blocks. The 375 ms case
+    (18 000 frames, the default) runs 45 blocks so that two echoes pass through the wet path before the hand-over."""
     params = {"mode": mode, "dlay": dlay, "fdbk": 0.6, "ftyp": ftyp, "driv": 0.3, "lfor": 3.7}
-    updates = {4: [("lfdt", 0.02, False), ("lfdf", 0.3, False)]}
-    a, b, _, _ = run_pair(_capi.FX_DELAY, params, None, blocks=7, frames=1024, signal="noise", updates=updates)
+    long_run = dlay > 100.0
+    blocks = 45 if long_run else 7
+    updates = {(40 if long_run else 4): [("lfdt", 0.02, False), ("lfdf", 0.3, False)]}
+    a, b, _, _ = run_pair(_capi.FX_DELAY, params, None, blocks=blocks, frames=1024, signal="noise", updates=updates)
     check(a, b)
+    if long_run:
+        assert_wet_path_audible(a, params, blocks, 1024, "noise")
+
+
+def assert_wet_path_audible(out, params, blocks, frames, signal, first_echo_frame=18000):
+    """Against the same Delay with wet = 0 (oracle) the output must differ by > 1e-3 after the first echo: the delay-line read,
+    feedback filter, saturation and DC filter at the config's own delay time are really compared, not zeros."""
+    dry_params = dict(params or {}, **{"wet_": 0.0})
+    e = oracle.OracleEffect(_capi.FX_DELAY, dry_params, None)
+    e.initialize(SR, 2, 4096)
+    x = workloads.test_signal(blocks * frames, seed=_capi.FX_DELAY + 11, kind=signal)
+    for blk in range(blocks):
+        e.process(x[blk * frames * 2:(blk + 1) * frames * 2])
+    late = slice(2 * first_echo_frame, None)
+    assert float(np.abs(out[late].astype(np.float64) - x[late].astype(np.float64)).max()) > 1e-3, "the delay's wet path is inaudible in this run"
+
+
+@pytest.mark.parametrize("signal", ["noise", "burst"])
+def test_delay_default_two_echoes(signal):
+    """DelayEffect::new() — 375 ms = 18 000 frames at 48 kHz, feedback 0.5 (src/effect/delay.rs:124-177) — over 45 blocks of 1024
+    frames: the first echo returns in block 17, its feedback copy in block 35."""
+    a, b, _, _ = run_pair(_capi.FX_DELAY, None, None, blocks=45, frames=1024, signal=signal)
+    check(a, b)
+    assert_wet_path_audible(a, None, 45, 1024, signal)
 
 
 @pytest.mark.parametrize("params", [

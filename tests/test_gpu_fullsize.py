@@ -82,6 +82,147 @@ def test_long_run_stays_on_the_oracle():
     assert np.abs(a[-2048:]).max() > 1e-3
 
 
+def _f32_sum_in_mixer_order(rows):
+    """The mixer sum's fixed f32 order (pg_mix_kernel / pg_mix_kernel_1+2): partial sums over groups of 16 units in unit order,
+    then the groups in order, every add rounded to f32."""
+    n = rows.shape[0]
+    total = np.zeros(rows.shape[1], np.float32)
+    for g0 in range(0, n, 16):
+        acc = np.zeros(rows.shape[1], np.float32)
+        for u in range(g0, min(g0 + 16, n)):
+            acc = (acc + rows[u]).astype(np.float32)
+        total = (total + acc).astype(np.float32)
+    return total
+
+
+@pytest.mark.parametrize("n_units", [4096, 4097, 8192])
+def test_mixer_sum_large_unit_counts_bit_exact(n_units):
+    """The mixer-graph sum over more than 4096 units takes the two-launch path (pg_mix_kernel_1 / pg_mix_kernel_2, partials through
+    HBM), up to 4096 the one-launch kernel; both must produce the documented f32 sum order bit for bit. Units = main-mixer sources
+    that play a constant (48 kHz stereo, unit gain, centre pan: resampler bypass, gain and pan skipped — the row IS the PCM value),
+    so the expected bus is a pure function of the sum order. Equal start times are inserted BEFORE existing sources
+    (mixed.rs:324-329): unit order = reverse order of addition."""
+    rng = np.random.default_rng(n_units)
+    vals = (rng.standard_normal((n_units, 2)) * 1e-3).astype(np.float32)
+    frames = 600
+    g = gpu_graph(512)
+    for i in range(n_units):
+        pcm = np.tile(vals[i], frames).astype(np.float32)
+        g.add_voice(0, np.concatenate([pcm, np.zeros(2, np.float32)]), 2, SR, volume=1.0, panning=0.0, fade_out_seconds=-1.0)
+    out = np.zeros(1024, np.float32)
+    assert g.write(out, 0) == 1024
+    expect = _f32_sum_in_mixer_order(vals[::-1])
+    assert np.array_equal(out.reshape(-1, 2), np.tile(expect, (512, 1)))
+    ref = vals.astype(np.float64).sum(axis=0)
+    assert np.abs(out.reshape(-1, 2)[0] - ref).max() < 1e-6
+
+
+def test_c5_8192_voices_full_size():
+    """BASELINE config 5 at its stated size on ONE GPU (8192 voices x Filter -> Eq5 -> Delay -> Reverb, ~43 GB of delay-line state;
+    the N = 1 anchor of the strong-scaling claim): determinism (two builds, bit-identical), linearity of the mixer over
+    the 8 shards of 1024 voices the 8-GPU run uses, and oracle spot checks of single voices. 24 blocks = 24 576 frames: the Delay's
+    first echo (18 000 frames) is inside the run. Also the first exercise of the > 4096-unit mixer path on sub-mixer units."""
+    V5, blocks = 8192, 24
+    g = gpu_graph()
+    workloads.build_c5(g, V5, 0, V5, seconds=0.25)
+    full = g.render(blocks, 1024)
+    assert np.isfinite(full).all() and np.abs(full).max() > 1e-2
+    g.close()
+    g2 = gpu_graph()
+    workloads.build_c5(g2, V5, 0, V5, seconds=0.25)
+    again = g2.render(blocks, 1024)
+    g2.close()
+    assert np.array_equal(again, full)
+    acc = np.zeros_like(full, dtype=np.float64)
+    for s in range(8):
+        gs = gpu_graph()
+        workloads.build_c5(gs, 1024, s * 1024, V5, seconds=0.25)
+        acc += gs.render(blocks, 1024)
+        gs.close()
+    assert rms(acc - full) <= 2e-6 and np.abs(acc - full).max() <= 2e-5
+    level = workloads.voice_level(V5)
+    for i in (0, 4095, 8191):
+        gg, gc = gpu_graph(), oracle.OracleGraph(SR, 2, 1024)
+        for h in (gg, gc):
+            workloads.build_c5(h, 1, i, V5, seconds=0.25)
+        a, b = gg.render(blocks, 1024), gc.render(blocks, 1024)
+        assert rms(a - b) <= 1e-5 * level * 4, (i, rms(a - b))  # a single voice sits at `level` of the bus scale
+        assert np.abs(a[2 * 18000:] - a[:2 * 6576]).max() > 0  # (sanity: not a constant)
+
+
+@pytest.mark.parametrize("name,voices,blocks", [("c2", 64, 45), ("c3", 1024, 24), ("c4", 256, 24)])
+def test_baseline_configs_full_size_against_oracle(name, voices, blocks):
+    """BASELINE configs 2, 3 and 4 at their stated sizes. Their oracle renders in seconds (no per-voice reverb), so the full graph is
+    compared directly — <= 1e-5 RMS, <= 1e-4 max — plus determinism and, for C3 (independent per-voice chains), shard linearity."""
+    def build(h, n=voices, first=0):
+        if name == "c2":
+            workloads.build_c2(h, n, seconds=0.25)
+        elif name == "c3":
+            workloads.build_c3(h, n, first, voices, seconds=0.25)
+        else:
+            workloads.build_c4(h, n, seconds=0.25)
+    g, gc = gpu_graph(), oracle.OracleGraph(SR, 2, 1024)
+    build(g)
+    build(gc)
+    a, b = g.render(blocks, 1024), gc.render(blocks, 1024)
+    d = a.astype(np.float64) - b.astype(np.float64)
+    assert rms(d) <= 1e-5 and np.abs(d).max() <= 1e-4, (rms(d), np.abs(d).max())
+    assert np.abs(a).max() > 1e-2
+    g2 = gpu_graph()
+    build(g2)
+    assert np.array_equal(g2.render(blocks, 1024), a)
+    if name == "c3":
+        acc = np.zeros_like(a, dtype=np.float64)
+        for s in range(4):
+            gs = gpu_graph()
+            build(gs, voices // 4, s * (voices // 4))
+            acc += gs.render(blocks, 1024)
+        assert rms(acc - a) <= 1e-6 and np.abs(acc - a).max() <= 1e-5
+
+
+def _run_bench(args, env_extra, launcher=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_plain_invocation_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts one child per rank before it touches the GPU and forwards rank
+    0's JSON line (PHONIC_BENCH_SHARED_GPU=1: both ranks on GPU 0 over gloo, RCCL refuses two ranks on one device). Weak scaling by
+    default; `--scaling strong --total-voices` splits a fixed voice count over the ranks."""
+    d = _run_bench(["--gpus", "2", "--steps", "8", "--warmup", "2", "--repeats", "2", "--voices", "48"], {"PHONIC_BENCH_SHARED_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_voices"] == 96 and d["config"]["voices_per_gpu"] == 48
+    assert d["config"]["backend"] == "gloo" and d["value"] > 0 and d["config"]["bus_peak"] > 0.01 and d["repeats"]["n"] == 2
+    d = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "2", "--workload", "c5", "--scaling", "strong", "--total-voices", "25"],
+                   {"PHONIC_BENCH_SHARED_GPU": "1"})
+    assert d["scaling"] == "strong" and d["config"]["total_voices"] == 25 and d["config"]["voices_per_gpu"] == 13 and d["value"] > 0
+    assert abs(d["value"] - 25 * 1024 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
+
+
+def test_bench_single_gpu_line_shape():
+    """The default invocation's JSON contract at a reduced size: roofline (kernel-timed), cpu_baseline with its flags, repeats."""
+    d = _run_bench(["--steps", "20", "--warmup", "4", "--repeats", "3", "--voices", "64"], {})
+    assert d["n_gpus"] == 1 and d["unit"] == "voice-frames/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["launches"] > 0 and r["kernel_ms"] > 0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and "-O" in c["flags"] and c["value"] > 0
+    assert d["repeats"]["ms_per_step_min"] <= d["ms_per_step"] <= d["repeats"]["ms_per_step_max"]
+
+
 @pytest.mark.parametrize("steps,warmup,reduce_every", [(6, 2, 8), (13, 3, 4), (6, 2, 1)])
 def test_bench_two_ranks_on_one_gpu_control_flow(steps, warmup, reduce_every):
     """bench.py's multi-rank path (voice sharding, ring of super-block bus buffers, asynchronous reduce per `reduce_every` blocks incl.
@@ -100,7 +241,8 @@ def test_bench_two_ranks_on_one_gpu_control_flow(steps, warmup, reduce_every):
         port = s.getsockname()[1]
     env = dict(os.environ, PHONIC_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--voices", "64", "--reduce-every", str(reduce_every)]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--voices", "64", "--reduce-every", str(reduce_every),
+           "--superblock", str(min(reduce_every, 4)), "--repeats", "2"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -153,7 +153,9 @@ def test_auto_bypass_and_submixer_silence_gate():
 
 @pytest.mark.parametrize("name", ["headline", "c2", "c3", "c4", "c5"])
 def test_benchmark_workloads_reduced(name):
-    """The BASELINE.json configs at reduced voice counts (oracle finishes in seconds), 1024-frame blocks."""
+    """The BASELINE.json configs at reduced voice counts (oracle finishes in seconds), 1024-frame blocks. C5 renders 45 blocks =
+    46 080 frames: its Delay sits at the config's own default of 375 ms = 18 000 frames (src/effect/delay.rs:124-177), so two echoes
+    come back through the wet / feedback path (SVF, saturation, DC filter) inside the run."""
     builders = {
         "headline": lambda g: workloads.build_headline(g, 6, seconds=0.2),
         "c2": lambda g: workloads.build_c2(g, 8, seconds=0.2),
@@ -161,9 +163,36 @@ def test_benchmark_workloads_reduced(name):
         "c4": lambda g: workloads.build_c4(g, 8, seconds=0.2),
         "c5": lambda g: workloads.build_c5(g, 4, seconds=0.2),
     }
-    a, b = both(lambda g: builders[name](g) or {}, 6, 1024, max_frames=1024)
+    n_blocks = 45 if name == "c5" else 6
+    a, b = both(lambda g: builders[name](g) or {}, n_blocks, 1024, max_frames=1024)
     compare(a, b)
     assert np.abs(a).max() > 1e-3
+    if name == "c5":
+        assert_delay_audible(a, lambda g: _build_c5_variant(g, 4, delay_wet=0.0), n_blocks, 1024)
+
+
+def _build_c5_variant(g, n_voices, delay_wet):
+    """C5 with the Delay's wet amount overridden (0 = the delay line's output never reaches the signal)."""
+    vol = workloads.voice_level(n_voices)
+    for i in range(n_voices):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_FILTER, params={"type": 0, "cuto": 8000.0, "fltq": 0.707})
+        g.add_effect(m, _capi.FX_EQ5, params={"gan1": 3.0, "gan3": -4.0, "gan5": 2.0})
+        g.add_effect(m, _capi.FX_DELAY, params={"wet_": delay_wet})
+        g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+        g.add_voice(m, workloads.tone_buffer(i, 48000, 0.2), 2, 48000, volume=vol, panning=float(np.float32(workloads.voice_pan(i))), has_repeat=1,
+                    repeat=_capi.PG_REPEAT_FOREVER)
+    return {}
+
+
+def assert_delay_audible(out, build_dry_only, n_blocks, block, first_echo_frame=18000):
+    """The delay line's read must matter: against the same graph with the Delay fully dry (oracle), the output differs by more than
+    1e-3 once the first echo is back — a delay read stubbed to zero (or a run shorter than the delay time) fails here."""
+    gc = oracle.OracleGraph(SR, 2, block)
+    build_dry_only(gc)
+    dry = gc.render(n_blocks, block)
+    late = slice(2 * first_echo_frame, None)
+    assert float(np.abs(out[late].astype(np.float64) - dry[late].astype(np.float64)).max()) > 1e-3, "the delay's wet path is inaudible in this run"
 
 
 def test_exact_mode_matches_fast_mode():
@@ -330,7 +359,8 @@ def test_resampler_schedule_bit_exact_over_many_blocks(rate, block, n_blocks):
 def test_wide_staged_kernel_filter_eq5_delay_reverb_chain():
     """Reverb-terminated sub-mixers whose leading effects go beyond Gain / Panning (C5's Filter -> Eq5 -> Delay -> Reverb, plus a
     Distortion -> Reverb one) are rendered by pg_stage_fused_wide_kernel; pg_graph_set_staged(0) keeps them in the fused wide
-    kernel. Same stage functions and effect paths: the two agree to f64 rounding, and both match the oracle."""
+    kernel. Same stage functions and effect paths: the two agree to f64 rounding, and both match the oracle. 45 blocks: the Delay
+    (default 375 ms = 18 000 frames) returns two echoes inside the run."""
     def build(g):
         workloads.build_c5(g, 3, 0, 3, seconds=0.2)
         m = g.add_mixer()
@@ -339,11 +369,21 @@ def test_wide_staged_kernel_filter_eq5_delay_reverb_chain():
         g.add_effect(m, _capi.FX_REVERB, params={"room": 0.35}, reverb_seeds=workloads.reverb_seeds(42))
         g.add_voice(m, workloads.tone_buffer(7, 44100, 0.2), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
         return {}
-    staged, _per_stage, fused, ref = _render_modes(build, 8, 1024)
+    n_blocks = 45
+    staged, _per_stage, fused, ref = _render_modes(build, n_blocks, 1024)
     assert float(np.abs(staged - fused).max()) <= 2e-6
     compare(staged, ref)
     compare(fused, ref)
     assert np.abs(staged).max() > 1e-3
+
+    def build_dry(g):
+        _build_c5_variant(g, 3, delay_wet=0.0)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_DISTORTION, params={"type": 0, "driv": 2.0})
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.5})
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.35}, reverb_seeds=workloads.reverb_seeds(42))
+        g.add_voice(m, workloads.tone_buffer(7, 44100, 0.2), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    assert_delay_audible(staged, build_dry, n_blocks, 1024)
 
 
 def test_staged_kernel_ragged_block_sizes():
