@@ -228,6 +228,7 @@ def main():
         g.set_fast_math(0)
     g.set_staged(args.staged)
     g.set_timing_period(args.time_every)
+    g.set_max_blocks_per_launch(sb)
     if world > 1 and bus_on_root:
         g.set_defer_bus(True)
     build_workload(g, name, v_per_gpu, first_voice, total_voices, 2.0)
@@ -299,6 +300,9 @@ def main():
     last = ring.last_block()
     peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
 
+    dev_err = g.device_errors()
+    if dev_err:
+        raise RuntimeError(f"kernel consistency flags raised: {dev_err}")
     if rank == 0:
         med = int(np.argsort(dts)[len(dts) // 2])
         dt = dts[med]

@@ -213,6 +213,15 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
  * on `hip_stream` (a hipStream_t, NULL = the graph's own stream); asynchronous when a stream is
  * given. Used for the multi-GPU master-bus reduce and by bench.py. */
 size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos_in_frames, void* hip_stream);
+/* Offline rendering (the reference's WavOutput pull loop, src/output/wav.rs:210-250, has no deadline per block): a write*() call that
+ * spans several blocks of max_frames may render up to `n_blocks` of them in ONE launch sequence when nothing is scheduled inside them and
+ * every unit is in steady state (MixedSource::write walks its chunks inside one call the same way, src/source/mixed.rs:679-712). All
+ * per-block semantics (bypass counters, tails, silence gates) stay per block. Default 1; sizes the per-unit output table
+ * (n_blocks x units x max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph. */
+int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks);
+/* Sticky consistency flags raised by the kernels (0 = none; see PG_DEVERR_* in phonic_amd/csrc/pg_dev.h): conditions the host-side
+ * routing of units to kernel variants must make impossible. Synchronises the graph's own stream. Negative pg_status on failure. */
+int pg_graph_device_errors(pg_graph* g);
 /* Multi-GPU: when set, bus effects are skipped in write*(): the caller reduces the partial bus of
  * all ranks (RCCL) and then runs them once on the root with pg_graph_process_bus_device(). */
 int pg_graph_set_defer_bus(pg_graph* g, int defer);

@@ -233,6 +233,10 @@ def load():
     lib.pg_graph_kernel_ms.argtypes = [vp, C.c_int, P(C.c_uint64)]
     lib.pg_graph_kernel_stats.restype = C.c_int
     lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
+    lib.pg_graph_set_max_blocks_per_launch.restype = C.c_int
+    lib.pg_graph_set_max_blocks_per_launch.argtypes = [vp, C.c_int]
+    lib.pg_graph_device_errors.restype = C.c_int
+    lib.pg_graph_device_errors.argtypes = [vp]
     lib.pg_graph_set_fast_math.restype = C.c_int
     lib.pg_graph_set_fast_math.argtypes = [vp, C.c_int]
     lib.pg_graph_set_timing_period.restype = C.c_int

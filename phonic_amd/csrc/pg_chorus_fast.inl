@@ -57,7 +57,7 @@ DEVO bool chorus_fast_eligible(const PgFx& fx) {
 DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (!chorus_fast_eligible(fx)) return false;
   PgChorus& c = fx.u.chorus;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int frames = n_samples / 2;
   if (frames == 0) return true;
   double* buf = (double*)fc.scratch;                       // [T][2] f64, skewed (REV_IDX)

@@ -33,7 +33,7 @@ DEVO bool comp_fast_eligible(const PgFx& fx) {
 DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (!comp_fast_eligible(fx)) return false;
   PgComp& c = fx.u.comp;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   float* a0 = (float*)fc.scratch;              // [COMP_FAST_CAP] frame peaks: history (W - 1 frames) then the block
   float* a1 = a0 + COMP_FAST_CAP;              // ping-pong partner of the doubling; later the copy of the block's input
   float* env = a1 + COMP_FAST_CAP;             // [1024] input dB, then envelope

@@ -14,7 +14,7 @@
 // DcFilter::process_sample (src/utils/dsp/filters/dc.rs:84-88) over the chunk, both channels, in place on the skewed LDS buffer:
 //   y_n = (x_n - x_{n-1}) + r * y_{n-1}.  Blocked like the biquad scan: 128 segments of 8 frames per channel.
 DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] */) {
-  const int tid = threadIdx.x;
+  const int tid = pg_tid();
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
   const int seg = half * 64 + lane;
@@ -72,7 +72,7 @@ DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] 
 // rounded through f32 when the reference stores the filtered sample as f32 (FilterEffect).
 template <bool ROUND_F32, typename CoefFn>
 DEVO void svf_scan_time_varying(CoefFn coef, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
-  const int tid = threadIdx.x;
+  const int tid = pg_tid();
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
   const int seg = half * 64 + lane;
@@ -156,7 +156,7 @@ DEVO bool delay_fast_eligible(const PgFx& fx) {
 DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (!delay_fast_eligible(fx)) return false;
   PgDelay& d = fx.u.delay;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int frames = n_samples / 2;
   if (frames == 0) return true;
   double* buf = (double*)fc.scratch;                       // [T][2] f64, skewed (REV_IDX)

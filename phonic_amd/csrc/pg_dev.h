@@ -278,5 +278,16 @@ struct PgLaunch {
   int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
   const float* rows_base; // nested sub-mixers: row 0 of the per-unit output table (unit_out points at this launch's level) ...
   const int2* child_rows; // ... and {row, unit slot} of every nested sub-mixer, indexed by PgUnit::child_off
+  // Super-block launch (steady state, no command inside): every workgroup of the fast / staged kernels renders n_chunks consecutive
+  // blocks of n_frames for its unit — block c covers frames [pos + c * n_frames, +n_frames) and goes to unit_out + c * chunk_stride —
+  // with all per-block decisions (bypass counters, silence gates, tails) taken per block exactly as in n_chunks single launches.
+  // Workgroups are independent until the mixer sum, so they drift out of lock-step across the blocks. 0 / 1: one block.
+  int32_t n_chunks;
+  int32_t pad_chunks;
+  uint64_t chunk_stride;  // floats between the per-unit output tables of consecutive blocks
+  int32_t* error_word;    // device word of sticky consistency flags (PG_DEVERR_*), nullptr: not collected
 };
+// PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
+enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take
+       PG_DEVERR_SUPER_DEFERRED = 2 };  // a unit wanted the generic kernel inside a super-block launch
 constexpr int PG_STAGE_BUF_DOUBLES = 2 * 1024 + 128 + 8;

@@ -15,6 +15,7 @@ struct FastCtx {
   int* ctl;          // LDS: 32 ints for uniform decisions
   float* red;        // LDS: 16 floats for reductions
   unsigned long long* diag;
+  int32_t* err;      // device word of sticky consistency flags (PgLaunch::error_word), may be nullptr
 };
 
 constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
@@ -30,7 +31,7 @@ constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 
 // scratch buffer; `as f32` between stages is reproduced by rounding every stage's output through f32.
 DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs, PgState2* st /*[ch][n_stages]*/, int n_stages, int st_stride,
                             FastCtx& fc) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   double* buf = (double*)fc.scratch;
   double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
   PgState2* lst = (PgState2*)(xchg + 4);  // [2] per-stage state view for the scan
@@ -57,7 +58,7 @@ DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs
 // recomputed from them as biquad_apply does, and the recurrence runs as the time-varying blocked scan.
 DEVO void filter_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgFilter& f = fx.u.filter;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   double* buf = (double*)fc.scratch;
   double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
   float* cut = fc.tmp;            // [T] cutoff per frame (already clamped), then [T] q per frame
@@ -118,7 +119,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
 // KMASK: bit k set = the code of effect kind k is compiled into this kernel variant (register budget of the hot variants).
 template <int KMASK>
 DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   if (!((KMASK >> fx.kind) & 1)) return false;
   switch (fx.kind) {
     case 0: {  // GainEffect without ramp: optional DC filter per channel (gain.rs:147-153), then scale_buffer (gain.rs:162-165)

@@ -4,7 +4,7 @@
 // values held in LDS.
 DEVO bool gate_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgGate& g = fx.u.gate;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   float* db = (float*)fc.scratch;  // [1024] input level, then the smoothed gate gain in dB
   const int total = n_samples / 2;
   const float threshold = g.threshold, range_db = g.range;

@@ -28,7 +28,7 @@ size_t pg_unit_lds_bytes(uint32_t n_frames);
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
-                         const int32_t* order, int* audible_out, hipStream_t stream);
+                         const int32_t* order, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0);
 
 // ---- errors ---------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -430,6 +430,9 @@ struct pg_graph {
   size_t defer_rows = 0;
   size_t stage_rows = 0;
   bool defer_bus = false;
+  size_t max_blocks = 1;        // blocks of max_frames one launch sequence may render (pg_graph_set_max_blocks_per_launch); sizes d_unit_out
+  size_t unit_out_blocks = 0;   // ... as allocated
+  int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
   // host mirrors
   std::vector<HostMixer> mixers;        // [0] = main
   std::vector<HostVoice> voices;
@@ -609,11 +612,13 @@ static int rebuild_topology(pg_graph* g) {
   tmp.release();
   // per-unit output rows
   size_t rows = std::max<size_t>(g->n_graph_units, 1);
-  if (rows > g->unit_out_rows) {
+  if (rows > g->unit_out_rows || g->max_blocks != g->unit_out_blocks) {
     if (g->d_unit_out) (void)hipFree(g->d_unit_out);
-    size_t nr = std::max(rows, g->unit_out_rows * 2);
-    HIP_TRY(hipMalloc((void**)&g->d_unit_out, (nr * g->stride + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
+    size_t nr = rows > g->unit_out_rows ? std::max(rows, g->unit_out_rows * 2) : g->unit_out_rows;
+    // one table of rows per block of a super-block launch; +4: the mixer sum reads whole float4s (odd max_frames)
+    HIP_TRY(hipMalloc((void**)&g->d_unit_out, (nr * g->stride * g->max_blocks + 4) * sizeof(float)));
     g->unit_out_rows = nr;
+    g->unit_out_blocks = g->max_blocks;
   }
   if (rows > g->defer_rows) {
     if (g->d_defer) (void)hipFree(g->d_defer);
@@ -677,6 +682,7 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     return nullptr;
   }
   (void)hipMemset(g->d_audible, 0, 16);
+  if (hipMalloc((void**)&g->d_error, 16) == hipSuccess) (void)hipMemset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (hipHostMalloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     *g->h_feedback = ~0ull;  // nothing reported yet
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
@@ -702,6 +708,7 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->d_defer) (void)hipFree(g->d_defer);
   if (g->d_bus) (void)hipFree(g->d_bus);
   if (g->d_audible) (void)hipFree(g->d_audible);
+  if (g->d_error) (void)hipFree(g->d_error);
   if (g->h_pinned) (void)hipHostFree(g->h_pinned);
   if (g->h_feedback) (void)hipHostFree(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -999,6 +1006,28 @@ int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic 
   HIP_TRY(hipMemcpy(out, g->d_diag, (size_t)(n > cap ? cap : n) * 8, hipMemcpyDeviceToHost));
   return PG_OK;
 }
+int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
+  if (n_blocks < 1 || n_blocks > 64) return set_error(PG_ERR_PARAMETER, "blocks per launch must be in 1..=64");
+  (void)hipSetDevice(g->device);
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  // staging of pg_graph_write (host buffers): one super-block + the status words
+  float* nb = nullptr; float* np = nullptr;
+  const size_t words = (size_t)g->stride * (size_t)n_blocks + 4;
+  HIP_TRY(hipMalloc((void**)&nb, words * sizeof(float)));
+  if (hipHostMalloc((void**)&np, words * sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)hipFree(nb); return set_error(PG_ERR_DEVICE, "pinned allocation failed"); }
+  (void)hipFree(g->d_bus); (void)hipHostFree(g->h_pinned);
+  g->d_bus = nb; g->h_pinned = np;
+  g->max_blocks = (size_t)n_blocks;
+  g->topo_dirty = true;  // the per-unit output table is sized at the next topology build (never inside a steady-state write)
+  return PG_OK;
+}
+int pg_graph_device_errors(pg_graph* g) {
+  (void)hipSetDevice(g->device);
+  if (!g->d_error) return 0;
+  int32_t e = 0;
+  if (hipStreamSynchronize(g->stream) != hipSuccess || hipMemcpy(&e, g->d_error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -PG_ERR_DEVICE;
+  return (int)e;
+}
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
 int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; g->last_change_round = g->launch_counter; return PG_OK; }
 const char* pg_graph_dominant_kernel(pg_graph* g) {
@@ -1066,8 +1095,23 @@ double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
   return n ? total / (double)n : 0.0;
 }
 
-// One launch round: all graph units for frames [t0, t0+n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
-static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds) {
+// Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
+// nothing deferred, and units leave the steady state only through those host-visible events.
+static bool graph_steady(const pg_graph* g) {
+  if (!(g->fast && g->levels.size() == 1 && g->n_static_defer == 0 && g->d_feedback)) return false;
+  const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
+  return fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
+}
+// A super-block launch sequence renders several blocks of max_frames per workgroup: only in steady state (nobody would render the
+// later blocks of a unit that defers itself), in the single-launch kernels, and with no bus chain behind the sum (it needs the
+// `audible` result of every block).
+static bool graph_super_ok(const pg_graph* g) {
+  return g->max_blocks > 1 && g->staged_mode != 2 && (g->defer_bus || g->mixers[0].fx.empty()) && graph_steady(g);
+}
+
+// One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
+// n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok().
+static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1) {
   int rc;
   if (!cmds.empty()) {  // rare (parameter automation): drain the stream so the previous round no longer reads the command table
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1082,6 +1126,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.out_stride = g->stride;
   L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
   L.diag = g->d_diag;
+  L.n_chunks = n_chunks; L.chunk_stride = (uint64_t)g->unit_out_rows * g->stride; L.error_word = g->d_error;
   const uint64_t round = g->launch_counter;
   if (!cmds.empty()) g->last_change_round = round;
   L.round = (uint32_t)round; L.host_feedback = g->d_feedback;
@@ -1089,12 +1134,10 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
   // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.
   // (Graphs with nested sub-mixers always launch it: the parents are rendered there.)
-  bool generic_idle = false;
-  if (g->fast && !nested && g->n_static_defer == 0 && cmds.empty() && g->d_feedback) {
-    const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
-    generic_idle = fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
-  }
-  L.sched = g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
+  const bool generic_idle = !nested && cmds.empty() && graph_steady(g);
+  // (a super-block runs without the resampler schedule cache: its banks alternate per launch, not per block; voices of a cached
+  // class replay their schedule serially, and the cache re-validates itself by key when single-block rounds resume)
+  L.sched = n_chunks > 1 ? nullptr : g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
   g->launch_counter++;
   // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
   // average can time every n-th round (pg_graph_set_timing_period)
@@ -1150,11 +1193,12 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
       HIP_TRY(pg_launch_units(L, stream, e0, e1));
     }
   }
-  if (timed) { g->ev_blocks[g->ev_used] = 1; g->ev_used++; }
+  if (timed) { g->ev_blocks[g->ev_used] = (uint32_t)n_chunks; g->ev_used++; }
   L.mode = 0;
   // the main mixer sums the rows of its own sub-mixers and sources: the last level
   const Level& top = g->levels.back();
-  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d + top.off, g->d_audible, stream));
+  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d + top.off, g->d_audible, stream,
+                        n_chunks, (size_t)L.chunk_stride));
   if (run_bus && !g->mixers[0].fx.empty()) {
     PgLaunch B = L;
     B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
@@ -1257,8 +1301,19 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
     }
     // bus commands run in the bus launch; everything is sorted by (unit, frame), stable
     std::stable_sort(cmds.begin(), cmds.end(), [](const PgCmd& a, const PgCmd& b) { return a.unit != b.unit ? a.unit < b.unit : a.frame < b.frame; });
-    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds)) { g->failed = true; return 0; }
-    done += n;
+    // Super-block: when the call still spans several whole blocks of max_frames, nothing is scheduled inside them and the graph is in
+    // steady state, ONE launch sequence renders them all (the reference's MixedSource::write walks its <= 4096-frame chunks in one call
+    // the same way, mixed.rs:679-712); every per-block decision is still taken per block, on the device.
+    uint64_t k = 1;
+    if (cmds.empty() && n == g->max_frames && graph_super_ok(g)) {
+      k = std::min<uint64_t>((frames - done) / g->max_frames, g->max_blocks);
+      uint64_t t_next = UINT64_MAX;
+      for (const HostMixer& mx : g->mixers) if (!mx.events.empty()) t_next = std::min(t_next, mx.events.front().sample_time);
+      if (t_next != UINT64_MAX && t_next < now + k * n) k = (t_next - now) / n;  // (t_next >= now + n: no command fell into this block)
+      if (k < 1) k = 1;
+    }
+    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds, (int)k)) { g->failed = true; return 0; }
+    done += n * k;
   }
   return n_samples;
 }
@@ -1274,27 +1329,27 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
   if (g->failed) return 0;
   (void)hipSetDevice(g->device);
   size_t total = 0;
-  // the staging bus holds one chunk of max_frames; larger writes are split exactly like the reference's mix_buffer loop
-  size_t chunk_samples = g->stride;
+  // the staging bus holds max_blocks chunks of max_frames (one super-block); larger writes are split like the reference's mix_buffer loop
+  const size_t cap = (size_t)g->stride * g->max_blocks;
   size_t off = 0;
   uint64_t pos = pos_in_frames;
   while (off < n_samples) {
-    size_t n = std::min(chunk_samples, n_samples - off);
+    size_t n = std::min(cap, n_samples - off);
     size_t w = graph_write_impl(g, g->d_bus, n, pos, g->stream);
     if (w == 0) { if (g->failed) return 0; if (off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
     // device feedback: how many main-mixer sources are still alive (transient sources are dropped when exhausted, :715)
     int n_main = (int)g->mixers[0].voices.size();  // the main-mixer voices are the last n_main entries of the voice index table
     hipLaunchKernelGGL(pg_status_kernel, dim3(1), dim3(64), 0, g->stream, g->d_voices.d, g->d_voice_index.d + (g->d_voice_index.n - (size_t)n_main), n_main,
-                       g->d_bus + g->stride);
+                       g->d_bus + cap);
     if (hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-        hipMemcpyAsync(g->h_pinned + g->stride, g->d_bus + g->stride, 4 * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipMemcpyAsync(g->h_pinned + cap, g->d_bus + cap, 4 * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         hipStreamSynchronize(g->stream) != hipSuccess) {
       g->failed = true;
       set_error(PG_ERR_DEVICE, "device failure in write: %s", hipGetErrorString(hipGetLastError()));
       return 0;
     }
     memcpy(out + off, g->h_pinned, n * sizeof(float));
-    g->main_active_voices = ((int*)(g->h_pinned + g->stride))[0];
+    g->main_active_voices = ((int*)(g->h_pinned + cap))[0];
     off += n; pos += n / 2; total += n;
   }
   return total;

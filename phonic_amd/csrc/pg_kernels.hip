@@ -147,7 +147,7 @@ __device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value) {
 }
 
 __device__ void wg_fill_zero(double* p, size_t n) {
-  for (size_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
+  for (size_t i = pg_tid(); i < n; i += blockDim.x) p[i] = 0.0;
 }
 
 // Reset messages (DelayEffectMessage::Reset, ReverbEffectMessage::Reset, ChorusEffectMessage::Reset) and the
@@ -159,7 +159,7 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
       PgDelay& d = fx.u.delay;
       wg_fill_zero(d.line[0], (size_t)d.mask + 1);
       wg_fill_zero(d.line[1], (size_t)d.mask + 1);
-      if (threadIdx.x == 0) {
+      if (pg_tid() == 0) {
         d.write_pos[0] = d.write_pos[1] = 0;
         d.flt[0].ic1eq = d.flt[0].ic2eq = d.flt[1].ic1eq = d.flt[1].ic2eq = 0.0;
         d.dc[0].x1 = d.dc[0].y1 = d.dc[1].x1 = d.dc[1].y1 = 0.0;
@@ -172,13 +172,13 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
       for (int i = 0; i < 8; ++i) wg_fill_zero(r.line[i].buf, (size_t)r.line[i].frames * 2);
       for (int i = 0; i < 4; ++i) wg_fill_zero(r.ap[i].buf, (size_t)r.ap[i].frames * 2);
       wg_fill_zero(r.pre, ((size_t)r.pre_mask + 1) * 2);
-      if (threadIdx.x == 0) { for (int i = 0; i < 4; ++i) r.ap[i].write_pos = 0; r.pre_write_pos = 0; }
+      if (pg_tid() == 0) { for (int i = 0; i < 4; ++i) r.ap[i].write_pos = 0; r.pre_write_pos = 0; }
     } break;
     case 6: {  // ChorusEffect::reset  chorus.rs:201-210
       PgChorus& c = fx.u.chorus;
       wg_fill_zero(c.line[0], (size_t)c.mask + 1);
       wg_fill_zero(c.line[1], (size_t)c.mask + 1);
-      if (threadIdx.x == 0) {
+      if (pg_tid() == 0) {
         c.write_pos[0] = c.write_pos[1] = 0;
         c.flt[0].ic1eq = c.flt[0].ic2eq = c.flt[1].ic1eq = c.flt[1].ic2eq = 0.0;
         sm_init(c.rate, c.rate.target);
@@ -200,12 +200,14 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
 template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
   if (FAST_ONLY) {
-    (void)fx_fast_process<KMASK>(fx, sig, n, fc);
+    // no serial code in this kernel: the host's routing (lean / wide / staged) and the eligibility check of the previous block must
+    // agree with what the time-parallel path accepts. A decline here leaves the effect unapplied for this block: make it visible.
+    if (!fx_fast_process<KMASK>(fx, sig, n, fc) && fc.err && pg_tid() == 0) atomicOr(fc.err, PG_DEVERR_FAST_DECLINED);
     return;
   } else {
     if (fast && fx_fast_process<KMASK>(fx, sig, n, fc)) return;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (pg_tid() == 0) {
       switch (fx.kind) {
         case 0: gain_serial(fx, sig, n); break;
         case 1: pan_serial(fx, sig, n); break;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
 // pre-part: bypass decision (:88-101). Returns true when the effect is bypassed for this block. All lanes call.
 __device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, int* ctl) {
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (pg_tid() == 0) {
     bool should_bypass = input_bypassed && fx.tail_counter == 0 && fx.silence_counter == PG_USIZE_MAX;  // :88-91
     if (should_bypass && !fx.bypassed) fx.bypassed = 1;                                                // process_stopped: no-op for stock effects
     else if (!should_bypass && fx.bypassed) { fx.bypassed = 0; fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0; }
@@ -240,7 +242,7 @@ __device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, 
 // post-part: update_tail_counters / reset_tail_counters (:111-152) after the effect rendered `n` samples into `sig`
 __device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, int n, bool input_bypassed, uint32_t sample_rate, int* ctl, float* red) {
   if (input_bypassed) {  // update_tail_counters :111-145
-    if (threadIdx.x == 0) {
+    if (pg_tid() == 0) {
       uint64_t tail_frames;
       if (fx_process_tail(fx, tail_frames)) {
         if (tail_frames == PG_USIZE_MAX) fx.tail_counter = tail_frames;
@@ -253,7 +255,7 @@ __device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, in
     __syncthreads();
     if (ctl[1]) {  // unknown tail: detect silence
       float max_sample = wg_max_abs(sig, n, red);
-      if (threadIdx.x == 0) {
+      if (pg_tid() == 0) {
         if (max_sample < 0.001f) {
           uint64_t fp = (uint64_t)(n / 2);
           fx.silence_counter = (fx.silence_counter > PG_USIZE_MAX - fp) ? PG_USIZE_MAX : fx.silence_counter + fp;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, in
         } else fx.silence_counter = 0;
       }
     }
-  } else if (threadIdx.x == 0) {
+  } else if (pg_tid() == 0) {
     fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0;  // reset_tail_counters :148-152
   }
   __syncthreads();
@@ -284,7 +286,7 @@ extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 // sub-mixer: silence gate on the call's peak, then the call's samples (or silence) go to the unit's output row. Returns whether the
 // call produced output. (A sub-mixer without sources, effects or events returns 0 samples: max over an empty slice = 0 -> silent.)
 __device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* sig, float* out, int a, int b, uint32_t sample_rate, int* ctl, float* red) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const float max_sample = wg_max_abs(sig + 2 * a, 2 * (b - a), red);
   if (tid == 0) {
     int audible;
@@ -303,11 +305,11 @@ __device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* 
 }
 
 template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) {
+__device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, const int chunk = 0) {
   if (slot >= L.n_units) return;
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   PgUnit& unit = L.units[u];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
   float* sig = (float*)pg_smem;
   float* tmp = sig + 2 * N;
@@ -322,7 +324,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
   S.diag = L.diag;
   S.sched_rd = nullptr;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
   if (L.mode != 2) PG_STAMP(L.diag, 0);
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
@@ -334,7 +336,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
       int ok = !(unit.static_defer || unit.maybe_ramping);
       for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
       unit.deferred = ok ? 0 : 1;
-      if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
+      if (!ok && L.n_chunks > 1) { if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED); }  // nobody renders the later blocks of this unit
+      else if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
       ctl[5] = ok;
     }
     __syncthreads();
@@ -367,7 +370,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
   bool any_audible = false;
   // nested sub-mixers: an ancestor that splits its block at events calls this unit once per segment (CMD_CALL_SPLIT marks the
   // boundaries); the silence gate and the `audible` result are per call. Only the generic kernel sees more than one call.
-  float* const out = external ? nullptr : L.unit_out + (size_t)slot * L.out_stride;
+  float* const out = external ? nullptr : L.unit_out + (size_t)chunk * L.chunk_stride + (size_t)slot * L.out_stride;
   int call_start = 0, call_idx = 0, seg_idx = 0;
   unsigned long long call_mask = 0;
   while (frame0 < N) {
@@ -405,7 +408,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
     if (ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame < N) frame1 = (int)L.cmds[ci].frame;
     const int seg = frame1 - frame0;
     float* sseg = sig + 2 * frame0;
-    const uint64_t pos = L.pos + (uint64_t)frame0;
+    const uint64_t pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)frame0;
     bool audible_input;
     if (external) {
       audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (*L.bus_audible != 0) : true);
@@ -503,14 +506,22 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot) 
 #define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
 // leading effects of the wide staged kernel: every kind with a time-parallel path whose LDS needs fit stage 1's arena (no Chorus)
 #define PG_KMASK_LEADING ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 9))
-__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) { pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x); }
-__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) { pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x); }
+// Super-block launches (L.n_chunks > 1): the workgroup renders its unit's consecutive blocks one after the other; everything a block
+// leaves behind (effect / voice / unit state) went to global memory and is read back by the same workgroup after a barrier.
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) {
+  pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, 0);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, c); }
+}
+__global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) {
+  pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, 0);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, c); }
+}
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
 // walks its share of the units, so the launch that finds nothing deferred costs 256 workgroup starts instead of n_units.
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
     const int n = *L.defer_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && pg_tid() == 0) {
       *L.defer_reset = 0;
       // tell the host how many units this round deferred: after a round with none (and no change since) it skips this launch
       if (L.host_feedback) { *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n; __threadfence_system(); }
@@ -543,11 +554,11 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
 __device__ __forceinline__ int stage_image_doubles(int T) { return 2 * T + (T >> 3) + 2; }
 __device__ __forceinline__ void stage_store_image(double* g, const double* lds, int T) {
   const int n2 = (stage_image_doubles(T) + 1) >> 1;
-  for (int i = threadIdx.x; i < n2; i += blockDim.x) ((double2*)g)[i] = ((const double2*)lds)[i];
+  for (int i = pg_tid(); i < n2; i += blockDim.x) ((double2*)g)[i] = ((const double2*)lds)[i];
 }
 __device__ __forceinline__ void stage_load_image(double* lds, const double* g, int T) {
   const int n2 = (stage_image_doubles(T) + 1) >> 1;
-  for (int i = threadIdx.x; i < n2; i += blockDim.x) ((double2*)lds)[i] = ((const double2*)g)[i];
+  for (int i = pg_tid(); i < n2; i += blockDim.x) ((double2*)lds)[i] = ((const double2*)g)[i];
 }
 constexpr size_t STAGE_ARENA_PREFIX = (size_t)REV_BUF_DOUBLES * 8 + 16 * sizeof(RevRec) + 16 * 8 + 13 * sizeof(RevDesc) + 4 * 8;  // bufA .. xchg
 constexpr size_t STAGE_FIXED = ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
@@ -572,21 +583,22 @@ __device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& u
 // Returns the unit's stage flags (PG_STAGE_*, also left in the unit record for the per-stage launches), or -1 when the unit was
 // deferred to the generic kernel.
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int4 si) {
+__device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int4 si, const int chunk = 0, char* smem = pg_smem) {
   // `si` = L.slot_info[slot], loaded by the kernel: one load names the unit, its first voice and its reverb (and the unit's staged
   // level): their state blocks are then fetched side by side
   const int u = si.x;
   PgUnit& unit = L.units[u];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
-  float* out = L.unit_out + (size_t)slot * L.out_stride;
+  float* out = L.unit_out + (size_t)chunk * L.chunk_stride + (size_t)slot * L.out_stride;
+  const uint64_t pos0 = L.pos + (uint64_t)chunk * (uint64_t)N;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   PgFx& gfx = L.fx[si.z];
   uint32_t voice_word = 0;
   if ((si.w & 0xffffff) > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
   unsigned long long fxr_word = 0;  // the reverb's state block (one qword per lane), used after the source stage
   if (tid < n_fx_words / 2) fxr_word = ((const unsigned long long*)&gfx)[tid];
-  const StageLds m0 = stage_lds();
+  const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
   float* sig = (float*)(m0.arena + STAGE1_UNION);
   float* tmp = sig + 2 * N;
@@ -596,14 +608,15 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   S.diag = L.diag;
   S.sched_rd = nullptr;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = m0.arena; fc.ctl = ctl; fc.red = red; fc.diag = L.diag;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = m0.arena; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
   PG_STAMP(L.diag, 0);
   // deferral decision: identical to the fused fast kernel
   if (tid == 0) {
     int ok = !(unit.static_defer || unit.maybe_ramping);
     for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;
     unit.deferred = ok ? 0 : 1;
-    if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
+    if (!ok && L.n_chunks > 1) { if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED); }
+    else if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
     ctl[5] = ok;
   }
   __syncthreads();
@@ -615,7 +628,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   bool audible_input = false;
   for (int vi = 0; vi < n_voices; ++vi) {
     PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[voice_off + vi]];
-    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, L.pos, S, L.sched, L.sched_bank, vi == 0, voice_word);
+    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word);
   }
   PG_STAMP(L.diag, 1);
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
@@ -669,14 +682,14 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
 }
 
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flags) {
+__device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flags, char* smem = pg_smem) {
   if (!(flags & PG_STAGE_ACTIVE)) return;
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   PgUnit& unit = L.units[u];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
-  const StageLds m0 = stage_lds();
+  const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx;
   const RevLds m = rev_lds(m0.arena);
   if (!RESIDENT) {
@@ -698,15 +711,15 @@ __device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flag
 }
 
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags, char* smem = pg_smem) {
+__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags, char* smem = pg_smem, const int chunk = 0) {
   // one load names the unit and its reverb (as in stage 1); it is issued ahead of the dry-signal transfer below so that waiting
   // for it does not wait for the transfer (loads return in order)
   const int4 si = L.slot_info[slot];
   PgUnit& unit = L.units[si.x];
   PgFx& gfx = L.fx[si.z];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
-  float* out = L.unit_out + (size_t)slot * L.out_stride;
+  float* out = L.unit_out + (size_t)chunk * L.chunk_stride + (size_t)slot * L.out_stride;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
@@ -798,29 +811,23 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch
   bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
   if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags);
 }
-// One launch; the launch structure lives in LDS so that out-of-line stage functions can take it by pointer.
-// PG_STAGE_OUTLINE: bit k set = stage k+1 is an out-of-line call (own register allocation, but the callee saves the
-// callee-saved VGPRs it uses to scratch: ~12 KB per wave and call, real HBM traffic); clear = inlined into the kernel function.
+// One launch per round; the workgroup runs the three stages of its unit's block back to back (chunk buffer and effect state stay in
+// LDS). PG_STAGE_OUTLINE: bit k set = stage k+1 is an out-of-line call (own register allocation, but a callee that needs more than the
+// 80 caller-saved VGPRs saves the callee-saved ones it uses to scratch — ~12 KB per wave and call, real HBM traffic; -enable-ipra
+// does not remove those saves for a `tail call`ed function) ; clear = inlined into the kernel function.
 // Measured on one box (ms per headline block): 7 (all calls) 0.166, 2 0.157, 5 0.155, 0 (all inline) 0.152, 4 (tail only) 0.149.
+// (The tail stage fits the caller-saved registers: its call costs nothing.)
+// The launch structure lives in LDS (written by one lane from the scalar registers the arguments arrive in) so that the
+// out-of-line stage can take it by pointer. (The kernarg segment is not addressable from a callee: llvm.amdgcn.kernarg.segment.ptr
+// lowers to NULL outside kernels.)
 #ifndef PG_STAGE_OUTLINE
 #define PG_STAGE_OUTLINE 4
 #endif
-#if PG_STAGE_OUTLINE & 1
-static __device__ __noinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot, stage_slot_info(*L, slot)); }
-#else
-__device__ __forceinline__ int stage1_call(const PgLaunch* L, int slot) { return stage1_run<2, true>(*L, slot, stage_slot_info(*L, slot)); }
-#endif
-#if PG_STAGE_OUTLINE & 2
-static __device__ __noinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
-#else
-__device__ __forceinline__ void stage2_call(const PgLaunch* L, int slot, int flags) { stage2_run<2, true>(*L, slot, flags); }
-#endif
+typedef __attribute__((address_space(3))) char* PgLdsPtr;
 #if PG_STAGE_OUTLINE & 4
-typedef __attribute__((address_space(3))) char* PgLdsPtr;
-static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem) { stage3_run<2, true>(*L, slot, flags, (char*)smem); }
+static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk); }
 #else
-typedef __attribute__((address_space(3))) char* PgLdsPtr;
-__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem) { stage3_run<2, true>(*L, slot, flags, (char*)smem); }
+__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk); }
 #endif
 // The kernel's dynamic LDS as an opaque value: handed to the out-of-line stage as is, constant propagation would put the name
 // pg_smem (and with it the offset-table lookup) back into the callee.
@@ -829,49 +836,44 @@ __device__ __forceinline__ PgLdsPtr stage_smem_arg() {
   asm volatile("" : "+s"(a));
   return (PgLdsPtr)(uintptr_t)a;
 }
-__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) {
-  if ((int)blockIdx.x >= L.n_units) return;
-  const int slot = blockIdx.x;
-  const int4 si = stage_slot_info(L, slot);
-  if ((si.w >> 24) != 1) return;
-  // the launch structure for the out-of-line stage: written by one lane from the scalar registers the arguments arrive in (no
-  // trip to memory); the barriers in front of that stage make it visible
-  __shared__ PgLaunch sL;
-  if (threadIdx.x == 0) sL = L;
 #ifdef PG_DIAG
 #define PG_SLOT_STAMP(i) do { if (L.diag && threadIdx.x == 0 && slot < 4096) L.diag[64 + 4 * slot + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PG_SLOT_STAMP(i) do { } while (0)
 #endif
-  PG_SLOT_STAMP(0);
-  // inlined stages read the launch structure from the kernel arguments (scalar registers), out-of-line ones from the LDS copy
-  const int flags = stage1_run<2, true>(L, slot, si);
-  if (flags < 0) return;  // deferred to the generic kernel
-  __syncthreads();
-  PG_SLOT_STAMP(1);
-  if ((PG_STAGE_OUTLINE >> 1) & 1) stage2_call(&sL, slot, flags); else stage2_run<2, true>(L, slot, flags);
-  __syncthreads();
-  PG_SLOT_STAMP(2);
-  if ((PG_STAGE_OUTLINE >> 2) & 1) stage3_call(&sL, slot, flags, stage_smem_arg()); else stage3_run<2, true>(L, slot, flags);
-  PG_SLOT_STAMP(3);
-}
-
-// The same single launch for reverb units whose leading effects go beyond Gain / Panning (Filter, Eq5, Delay, Distortion:
-// C5's per-voice Filter -> Eq5 -> Delay -> Reverb). A kernel of its own so that the lean one keeps its register allocation.
-__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kernel(PgLaunch L) {
+// Super-block launches (L.n_chunks > 1): the workgroup renders the consecutive blocks of ITS unit one after the other. Units are
+// independent until the mixer sum, so nothing synchronises the workgroups of a launch: they drift apart across the blocks, and the
+// latency-bound source / front / tail stages of some run under the bandwidth-bound mid stage of others (with one block per launch
+// all resident workgroups pass the stages in lock-step and HBM idles during the first and the last fifth of the kernel).
+// A block leaves all of its state in global memory; the barrier between two blocks orders it before the next block's loads.
+// (Per-lane values derive from pg_tid(), which keeps the stages' address arithmetic from being hoisted out of this loop.)
+template <int LEVEL, int TAG>
+__device__ __forceinline__ void stage_fused_body(const PgLaunch& L) {
   if ((int)blockIdx.x >= L.n_units) return;
   const int slot = blockIdx.x;
   const int4 si = stage_slot_info(L, slot);
-  if ((si.w >> 24) != 2) return;
-  __shared__ PgLaunch sL;
+  if ((si.w >> 24) != LEVEL) return;
+  __shared__ PgLaunch sL;  // for the out-of-line stage; the barriers in front of that stage make it visible
   if (threadIdx.x == 0) sL = L;
-  const int flags = stage1_run<3, true>(L, slot, si);
-  if (flags < 0) return;
-  __syncthreads();
-  stage2_run<3, true>(L, slot, flags);
-  __syncthreads();
-  stage3_call(&sL, slot, flags, stage_smem_arg());
+  const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    PG_SLOT_STAMP(0);
+    const int flags = stage1_run<TAG, true>(L, slot, si, chunk);
+    if (flags < 0) return;  // deferred to the generic kernel (never inside a super-block: the host launches those in steady state only)
+    __syncthreads();
+    PG_SLOT_STAMP(1);
+    stage2_run<TAG, true>(L, slot, flags);
+    __syncthreads();
+    PG_SLOT_STAMP(2);
+    stage3_call(&sL, slot, flags, stage_smem_arg(), chunk);
+    PG_SLOT_STAMP(3);
+    __syncthreads();
+  }
 }
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_kernel(PgLaunch L) { stage_fused_body<1, 2>(L); }
+// The same single launch for reverb units whose leading effects go beyond Gain / Panning (Filter, Eq5, Delay, Distortion:
+// C5's per-voice Filter -> Eq5 -> Delay -> Reverb). A kernel of its own so that the lean one keeps its register allocation.
+__global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage_fused_wide_kernel(PgLaunch L) { stage_fused_body<2, 3>(L); }
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
 // last float4 of a block with an odd frame count: only the samples that exist (the caller's buffer ends there)
@@ -885,7 +887,7 @@ __device__ __forceinline__ void mix_store(float* bus, int s4, int n_samples, con
 // Lanes run over the sample index s (coalesced float4); the f32 sum order is fixed (deterministic).
 __global__ void __launch_bounds__(64) pg_mix_kernel_1(const float* __restrict__ unit_out, uint32_t stride, int n_units, int group, float* __restrict__ partial,
                                                       int n_vec4) {
-  int s4 = blockIdx.x * blockDim.x + threadIdx.x;
+  int s4 = blockIdx.x * blockDim.x + pg_tid();
   int g = blockIdx.y;
   if (s4 >= n_vec4) return;
   int u0 = g * group, u1 = u0 + group;
@@ -901,12 +903,12 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_1(const float* __restrict__ 
 __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_samples,
                                                       const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
                                                       int* __restrict__ audible_out) {
-  int s4 = blockIdx.x * blockDim.x + threadIdx.x;
+  int s4 = blockIdx.x * blockDim.x + pg_tid();
   if (blockIdx.x == gridDim.x - 1 && audible_out) {  // the extra last block: OR of the units' audible flags (wave reduction)
     int a = 0;
-    for (int u = threadIdx.x; u < n_units; u += 64) a |= units[order[u]].audible;
+    for (int u = pg_tid(); u < n_units; u += 64) a |= units[order[u]].audible;
     for (int off = 32; off > 0; off >>= 1) a |= __shfl_xor(a, off, 64);
-    if (threadIdx.x == 0) *audible_out = a;
+    if (pg_tid() == 0) *audible_out = a;
     return;
   }
   const int n_vec4 = (n_samples + 3) / 4;
@@ -927,12 +929,16 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
 #define PG_MIX_MAX_GROUPS 256
 #define PG_MIX_COLS 4
 __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ unit_out, uint32_t stride, int n_units, int n_groups, float* __restrict__ bus,
-                                                      int n_samples, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out) {
+                                                      int n_samples, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out,
+                                                      size_t chunk_stride) {
+  // super-block launches: blockIdx.y = block of the super-block (its unit rows chunk_stride floats further, its bus n_samples further)
+  unit_out += (size_t)blockIdx.y * chunk_stride;
+  bus += (size_t)blockIdx.y * (size_t)n_samples;
   const int n_vec4 = (n_samples + 3) / 4;
   __shared__ float4 part[PG_MIX_MAX_GROUPS][PG_MIX_COLS];
-  const int t = threadIdx.x;
+  const int t = pg_tid();
   if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags (two dependent loads per unit: all 256
-    if (!audible_out) return;         // lanes take part so that few of those trips follow one another)
+    if (!audible_out || blockIdx.y + 1 != gridDim.y) return;  // lanes take part so that few of those trips follow one another)
     int a = 0;
 #pragma unroll 4
     for (int u = t; u < n_units; u += 256) a |= units[order[u]].audible;
@@ -1026,17 +1032,21 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0
   return hipGetLastError();
 }
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
-                         const int32_t* order, int* audible_out, hipStream_t stream) {
+                         const int32_t* order, int* audible_out, hipStream_t stream, int n_chunks, size_t chunk_stride) {
   int n_vec4 = (int)((n_samples + 3) / 4);
   int group = 16;
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
+  if (n_chunks < 1) n_chunks = 1;
   if (n_groups <= PG_MIX_MAX_GROUPS) {
-    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, units, order, audible_out);
+    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, units, order,
+                       audible_out, chunk_stride);
     return hipGetLastError();
   }
   dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
-  hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out, stride, n_units, group, partial, n_vec4);
-  hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus, (int)n_samples, units, order, n_units, audible_out);
+  for (int c = 0; c < n_chunks; ++c) {  // (the partials buffer holds one block: the launches of consecutive blocks follow each other in stream order)
+    hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out + (size_t)c * chunk_stride, stride, n_units, group, partial, n_vec4);
+    hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus + (size_t)c * n_samples, (int)n_samples, units, order, n_units, c + 1 == n_chunks ? audible_out : nullptr);
+  }
   return hipGetLastError();
 }

@@ -152,7 +152,7 @@ DEVO Mat2 mat2_mul(const Mat2& x, const Mat2& y) { return Mat2{x.a * y.a + x.b *
 // Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative).
 template <bool ROUND_F32>
 DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
-  const int tid = threadIdx.x;
+  const int tid = pg_tid();
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
   const int seg = half * 64 + lane;
@@ -267,7 +267,7 @@ struct RevBlock {  // per-block uniform parameters
 
 // vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store (caller syncs)
 DEVO void rev_load_vtab(const PgReverb& r, const RevLds& m) {
-  const int tid = threadIdx.x;
+  const int tid = pg_tid();
   const gdouble* tg = (const gdouble*)r.vib_tab;
   double t0[5], t1[5];
 #pragma unroll
@@ -280,7 +280,7 @@ DEVO void rev_load_vtab(const PgReverb& r, const RevLds& m) {
 // state while room size and wet stay put. All lanes call; returns false for a degenerate geometry (serial path).
 DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
   PgReverb& r = fx.u.reverb;
-  const int tid = threadIdx.x;
+  const int tid = pg_tid();
   __syncthreads();
   if (tid == 0) {
     if (!(r.cache_valid && r.cache_room == r.room.target && r.cache_wet == r.wet.target)) {
@@ -307,7 +307,7 @@ DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
 
 // ---- front: predelay (DelayLine<2>::process, delay.rs:47-66) in chunks of <= predelay frames, then biquad A ----
 DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   double* bufA = m.bufA;
   const int ch0 = tid & 1;  // nt is even: a lane keeps its channel across trips
   const uint32_t fpd = ch0 ? r.fpd_r : r.fpd_l;
@@ -347,7 +347,7 @@ DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const 
 
 // ---- mid: allpasses + vibrato lines ----
 DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   RevRec* rec = m.rec; double* gl = m.gl; RevDesc* desc = m.desc; double* anch = m.anch; double* vtab = m.vtab;
   const double blend = b.blend, regen = b.regen, wet = b.wet;
 #ifdef PG_DIAG
@@ -536,7 +536,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
 // the wait sits behind the two scans, in front of the barrier that precedes the first read.
 template <bool DRY_DMA>
 DEVO void rev_tail_impl(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   double* bufA = m.bufA;
   const double wet = b.wet;
   PG_STAMP(diag, 56);

@@ -86,7 +86,7 @@ DEVO SchedTab schedtab_step(int u0) {
 
 // All lanes of the workgroup (256). `scr`: >= 32 ints of LDS. Returns false when it gave up (caller replays serially).
 DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = pg_tid(), lane = tid & 63, wave = tid >> 6;
   const int TWO24 = 1 << 24;
   const int R = (int)(ratio * 16777216.0f);  // exact: ratio in [0.5, 1)
   int* s_viol = scr;          // first element whose wrap decision differs from the closed form
@@ -170,7 +170,7 @@ DEVO uint64_t div_channels(uint64_t x, int C) { return C == 2 ? (x >> 1) : (C ==
 // src/source/mixed.rs:606-608) instead of going through the temporary mix buffer.
 DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScratch& S, const SrcPost& P, float* acc) {
   const int C = (int)v->channels;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   // loop range in samples (:273-280)
   uint64_t lr_start = 0, lr_end = v->n_samples;
   if (v->repeat > 0 && v->has_loop) { lr_start = v->loop_start * C; lr_end = v->loop_end * C; }
@@ -469,7 +469,7 @@ DEVO void voice_seek(PgVoice* v, double seconds) {
 template <bool GLIDE>
 DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
   *added = 0;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
   // process_messages: Stop (preloaded.rs:195-208)
   if (tid == 0 && pending_stop && !v->finished) {
@@ -593,7 +593,7 @@ template <bool GLIDE>
 DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
                         const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0) {
   SrcScratch S = S0;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = pg_tid(), nt = blockDim.x;
   static_assert(sizeof(PgVoice) / 4 <= 256, "one dword per lane");
   __syncthreads();
   {  // stage the voice state into LDS (uniform reads, lane-0 writes); `word` = this lane's dword when the caller prefetched it

@@ -21,6 +21,14 @@ class Graph(GraphHandle):
         returns when the block is complete."""
         return self._lib.pg_graph_write_device(self._h, C.c_void_p(d_out_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0))
 
+    def set_max_blocks_per_launch(self, n_blocks):
+        """Offline rendering: let one write call render up to `n_blocks` blocks of max_frames per launch sequence (steady state only)."""
+        self._check(self._lib.pg_graph_set_max_blocks_per_launch(self._h, int(n_blocks)))
+
+    def device_errors(self):
+        """Sticky consistency flags raised by the kernels (0 = none)."""
+        return self._id(self._lib.pg_graph_device_errors(self._h))
+
     def set_defer_bus(self, defer):
         self._check(self._lib.pg_graph_set_defer_bus(self._h, 1 if defer else 0))
 

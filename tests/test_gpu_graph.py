@@ -827,3 +827,70 @@ def test_filter_cutoff_and_q_ramps_take_the_time_parallel_path(ftype):
     g.write(out, 4 * 1024)
     g.write(out, 5 * 1024)
     assert g.deferred_units() == 0
+
+
+def test_superblock_launch_is_bit_identical_to_single_blocks():
+    """pg_graph_set_max_blocks_per_launch: a write call spanning several blocks of max_frames is rendered by ONE launch sequence whose
+    workgroups loop over the blocks of their unit (steady state, nothing scheduled inside). Every per-block decision stays per block,
+    so the result must equal the block-by-block render BIT FOR BIT: staged lean units (headline), staged wide units (C5 chain), fused
+    units (Filter -> Chorus), plain main-mixer sources incl. two voices of one resampler-schedule-cache class (ratio < 0.5), a one-shot
+    voice whose reverb tail runs out, auto-bypasses and closes the sub-mixer's 2 s silence gate inside super-blocks, and parameter /
+    voice events that split super-blocks at their sample times. Also checked against the oracle, and that super-block launches really
+    happened (blocks per timed launch > 1) without any consistency flag from the kernels."""
+    from phonic_amd.graph import Graph
+
+    N, per_call, calls = 1024, 8, 15
+
+    def build(g):
+        workloads.build_headline(g, 3, seconds=0.2)
+        workloads.build_c5(g, 2, 0, 2, seconds=0.2)
+        workloads.build_c3(g, 2, 0, 2, seconds=0.2)
+        for i in range(2):
+            g.add_voice(0, workloads.tone_buffer(3 + i, 16000, 0.2), 2, 16000, volume=0.2, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m = g.add_mixer()
+        rv = g.add_effect(m, _capi.FX_REVERB, params={"room": 0.2}, reverb_seeds=workloads.reverb_seeds(61))
+        g.add_voice(m, workloads.tone_buffer(8, 48000, 0.05), 2, 48000, volume=0.5)
+        m2 = g.add_mixer()
+        rv2 = g.add_effect(m2, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(62))
+        v2 = g.add_voice(m2, workloads.tone_buffer(12, 44100, 0.3), 2, 44100, volume=0.4, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return {"rv2": rv2, "v2": v2}
+
+    def events(g, ids, call, pos):
+        if call == 3:
+            g.schedule_param(ids["rv2"], "room", 0.8, pos + 3 * N + 100)     # inside the 4th block of the call
+            g.set_voice_volume(ids["v2"], 0.2, pos + 6 * N)                  # exactly on a block boundary
+        if call == 9:
+            g.schedule_param(ids["rv2"], "wet ", 0.6, pos + 17)
+
+    outs, stats = [], []
+    for mode in ("single", "super", "oracle"):
+        g = oracle.OracleGraph(SR, 2, N) if mode == "oracle" else Graph(SR, 2, N, 0)
+        if mode == "super":
+            g.set_max_blocks_per_launch(per_call)
+        if mode != "oracle":
+            g.set_timing_period(1)
+        ids = build(g)
+        chunks, pos = [], 0
+        warm = np.zeros(2 * 2 * N, np.float32)   # two blocks: every unit reaches the steady state
+        assert g.write(warm, pos) == warm.size
+        chunks.append(warm)
+        pos += 2 * N
+        if mode != "oracle":
+            g.kernel_stats(reset=True)
+        for c in range(calls):
+            events(g, ids, c, pos)
+            o = np.zeros(per_call * 2 * N, np.float32)
+            assert g.write(o, pos) == o.size
+            chunks.append(o)
+            pos += per_call * N
+        outs.append(np.concatenate(chunks))
+        if mode != "oracle":
+            _, launches, blocks = g.kernel_stats(reset=True)
+            stats.append((launches, blocks))
+            assert g.device_errors() == 0
+    single, sup, ref = outs
+    assert np.array_equal(single, sup)
+    compare(sup, ref)
+    assert stats[0][1] == stats[0][0]                 # one block per launch
+    assert stats[1][1] > 2 * stats[1][0]              # super-block launches carried most blocks
+    assert np.abs(sup[-2 * N:]).max() > 1e-3
