@@ -8,12 +8,19 @@
  * Conventions
  *   - audio buffers are interleaved f32; all stock effects and the graph are stereo
  *     (reference: `enforce_stereo_playback`, src/player.rs:134,179).
- *   - handles are NOT thread safe; exactly one thread may call process/write on a handle at
- *     a time (the reference passes `&mut self`, src/effect.rs:155, src/source.rs:95).
+ *   - threading (reference: src/source/mixed.rs:113-194,233-234,294-499): exactly one thread at a time may be inside
+ *     process/write of a handle (the reference passes `&mut self`, src/effect.rs:155, src/source.rs:95), and the calls that CHANGE a graph
+ *     (pg_graph_add_* / remove_* / move_effect / set_*) belong to that owner too. The CONTROL calls — pg_graph_schedule_param,
+ *     pg_graph_schedule_reset, pg_graph_set_voice_volume / _panning / _speed, pg_graph_seek_voice, pg_graph_stop_voice,
+ *     pg_graph_stop_all_voices — may be called from ANY thread at ANY time, concurrently with write and with each other: like the
+ *     reference's handles they only push a record into a lock-free queue (PG_ERR_QUEUE_FULL when 65536 records wait), which write drains
+ *     at its top exactly like MixedSource::process_messages.
  *   - all functions returning `int` return a pg_status; the message of the last failure
  *     on the calling thread is available from pg_last_error_message().
- *   - host/device allocations happen in create/initialize/add_* only; process/write
- *     allocate nothing (reference: assert_no_alloc, src/output/cpal.rs:712-715).
+ *   - host/device allocations happen in create/initialize/add_* / set_* only (grow-by-doubling); process/write allocate nothing,
+ *     free nothing and — on a caller's stream — never wait for the device (reference: assert_no_alloc, src/output/cpal.rs:712-715;
+ *     checked with pg_debug_hip_calls). The graph-changing calls first wait for the work of earlier writes (also on the caller's
+ *     stream the last write used): none of them may run between two asynchronous writes without that wait.
  */
 #ifndef PHONIC_GPU_H
 #define PHONIC_GPU_H
@@ -219,6 +226,11 @@ size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64
  * per-block semantics (bypass counters, tails, silence gates) stay per block. Default 1; sizes the per-unit output table
  * (n_blocks x units x max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph. */
 int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks);
+/* Process-wide counters of the library's own HIP calls: out[0] = allocations (hipMalloc / hipHostMalloc), out[1] = releases, out[2] = host
+ * waits for a stream (hipStreamSynchronize), out[3] = blocking copies / fills. The reference runs its audio callback under
+ * assert_no_alloc (src/output/cpal.rs:712-715); with these counters a test asserts the same of pg_graph_write*: on a built graph it
+ * allocates nothing and frees nothing, and on a caller's stream it never blocks the host. */
+void pg_debug_hip_calls(uint64_t out[4]);
 /* Sticky consistency flags raised by the kernels (0 = none; see PG_DEVERR_* in phonic_amd/csrc/pg_dev.h): conditions the host-side
  * routing of units to kernel variants must make impossible. Synchronises the graph's own stream. Negative pg_status on failure. */
 int pg_graph_device_errors(pg_graph* g);

@@ -235,6 +235,8 @@ def load():
     lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
     lib.pg_graph_set_max_blocks_per_launch.restype = C.c_int
     lib.pg_graph_set_max_blocks_per_launch.argtypes = [vp, C.c_int]
+    lib.pg_debug_hip_calls.restype = None
+    lib.pg_debug_hip_calls.argtypes = [P(C.c_uint64)]
     lib.pg_graph_device_errors.restype = C.c_int
     lib.pg_graph_device_errors.argtypes = [vp]
     lib.pg_graph_set_fast_math.restype = C.c_int

@@ -8,15 +8,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/phonic_gpu.h"
+#include "pg_ctrl.h"
 #include "pg_dev.h"
 #include "pg_dsp_dev.h"
 #include "pg_params.h"
@@ -41,6 +44,8 @@ static int set_error(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
+#define PG_CMD_RING 65536   // commands in flight between two points at which the host knows the stream drained (2 MB device + 2 MB pinned)
+#define PG_CTRL_RING 65536  // control messages waiting for the next write (the reference: 4096 per mixer; here one ring per graph)
 #define HIP_TRY(expr)                                                                                    \
   do {                                                                                                   \
     hipError_t _e = (expr);                                                                              \
@@ -48,36 +53,90 @@ static int set_error(int code, const char* fmt, ...) {
   } while (0)
 
 // ---- device memory helpers ------------------------------------------------------------------------------
+// Every allocation, release and host-blocking HIP call of the library goes through these wrappers and is counted
+// (pg_debug_hip_calls): the reference wraps its audio callback in assert_no_alloc (src/output/cpal.rs:712-715); the test-suite
+// checks the same property here — a write() on a built graph allocates nothing, frees nothing and (on a caller's stream) never blocks.
+static std::atomic<uint64_t> g_n_alloc{0}, g_n_free{0}, g_n_sync{0}, g_n_blocking_copy{0};
+static hipError_t pg_malloc(void** p, size_t bytes) { g_n_alloc++; return hipMalloc(p, bytes); }
+static hipError_t pg_host_malloc(void** p, size_t bytes, unsigned flags) { g_n_alloc++; return hipHostMalloc(p, bytes, flags); }
+static hipError_t pg_free(void* p) { g_n_free++; return hipFree(p); }
+static hipError_t pg_host_free(void* p) { g_n_free++; return hipHostFree(p); }
+static hipError_t pg_stream_sync(hipStream_t s) { g_n_sync++; return hipStreamSynchronize(s); }
+static hipError_t pg_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { g_n_blocking_copy++; return hipMemcpy(d, s, n, k); }
+static hipError_t pg_memset(void* d, int v, size_t n) { g_n_blocking_copy++; return hipMemset(d, v, n); }
+
+// Device array that grows by reallocation + device-to-device copy (device-evolved state survives). New elements are collected in a
+// small pinned staging block and travel in batches: a full block is flushed by the (non real-time) call that filled it, the rest by
+// flush_async() on the render stream at the next write — one copy per <= STAGE elements instead of one per element.
 template <class T>
-struct DeviceVec {  // grows by reallocation + device-to-device copy, so device-evolved state survives
+struct DeviceVec {
+  static constexpr size_t STAGE = 256;
   T* d = nullptr;
-  size_t n = 0, cap = 0;
-  int ensure(size_t want) {
+  size_t n = 0, cap = 0;      // n counts staged elements too
+  T* h_stage = nullptr;       // pinned, STAGE elements
+  size_t n_staged = 0;        // elements [n - n_staged, n) wait in h_stage
+  int reserve(size_t want) {  // allocates: graph construction only
     if (want <= cap) return PG_OK;
     size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 16);
     T* nd = nullptr;
-    HIP_TRY(hipMalloc((void**)&nd, ncap * sizeof(T)));
-    if (d && n) HIP_TRY(hipMemcpy(nd, d, n * sizeof(T), hipMemcpyDeviceToDevice));
-    if (d) (void)hipFree(d);
+    HIP_TRY(pg_malloc((void**)&nd, ncap * sizeof(T)));
+    const size_t on_device = n - n_staged;
+    if (d && on_device) HIP_TRY(pg_memcpy(nd, d, on_device * sizeof(T), hipMemcpyDeviceToDevice));
+    if (d) (void)pg_free(d);
     d = nd;
     cap = ncap;
     return PG_OK;
   }
+  int flush() {  // blocking (graph construction)
+    if (n_staged) HIP_TRY(pg_memcpy(d + (n - n_staged), h_stage, n_staged * sizeof(T), hipMemcpyHostToDevice));
+    n_staged = 0;
+    return PG_OK;
+  }
+  int flush_async(hipStream_t s) {  // from write(): pinned source, no allocation, no wait; the staging block is not touched again before the
+    if (n_staged) HIP_TRY(hipMemcpyAsync(d + (n - n_staged), h_stage, n_staged * sizeof(T), hipMemcpyHostToDevice, s));  // next mutation, which drains the stream first
+    n_staged = 0;
+    return PG_OK;
+  }
   int push(const T& v, int* index) {
-    int rc = ensure(n + 1);
+    int rc = reserve(n + 1);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(d + n, &v, sizeof(T), hipMemcpyHostToDevice));
+    if (!h_stage) HIP_TRY(pg_host_malloc((void**)&h_stage, STAGE * sizeof(T), hipHostMallocDefault));
+    if (n_staged == STAGE && (rc = flush())) return rc;
+    h_stage[n_staged++] = v;
     *index = (int)n++;
     return PG_OK;
   }
-  int upload(const std::vector<T>& h) {
-    int rc = ensure(h.size());
-    if (rc) return rc;
-    if (!h.empty()) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    n = h.size();
+  void release() { if (d) (void)pg_free(d); if (h_stage) (void)pg_host_free(h_stage); d = nullptr; h_stage = nullptr; n = cap = n_staged = 0; }
+};
+
+// Table rebuilt from the host mirror at every topology change: capacity is reserved by the mutating calls (reserve: may allocate),
+// the contents travel with ONE asynchronous copy from pinned staging inside write (upload_async: never allocates).
+template <class T>
+struct DeviceTable {
+  T* d = nullptr;
+  T* h = nullptr;  // pinned staging, same capacity
+  size_t n = 0, cap = 0;
+  int reserve(size_t want) {
+    if (want <= cap) return PG_OK;
+    size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 64);
+    if (d) (void)pg_free(d);
+    if (h) (void)pg_host_free(h);
+    d = nullptr; h = nullptr; cap = 0;
+    HIP_TRY(pg_malloc((void**)&d, ncap * sizeof(T)));
+    HIP_TRY(pg_host_malloc((void**)&h, ncap * sizeof(T), hipHostMallocDefault));
+    cap = ncap;
     return PG_OK;
   }
-  void release() { if (d) (void)hipFree(d); d = nullptr; n = cap = 0; }
+  int upload_async(const std::vector<T>& v, hipStream_t s) {
+    if (v.size() > cap) return set_error(PG_ERR_STATE, "device table capacity was not reserved by the mutating call");
+    if (!v.empty()) {
+      memcpy(h, v.data(), v.size() * sizeof(T));
+      HIP_TRY(hipMemcpyAsync(d, h, v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    n = v.size();
+    return PG_OK;
+  }
+  void release() { if (d) (void)pg_free(d); if (h) (void)pg_host_free(h); d = nullptr; h = nullptr; n = cap = 0; }
 };
 
 static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
@@ -136,8 +195,10 @@ static void build_dist_luts(float* luts /*[5][256]*/) {
 }
 // vibrato rotation table of the reverb fast path: cos/sin(j * depth_i * vib_speed), j = 0..128, for the eight lines
 // (depths: src/effect/reverb.rs:137-144; increment depth*speed: reverb.rs:601-603). Read-only, shared by all instances.
-static std::map<int, double*> g_vib_tabs;
+static std::mutex g_tables_mutex;  // the shared read-only tables are built once per device, from whichever thread gets there first;
+static std::map<int, double*> g_vib_tabs;  // they live until the process ends (a few KB per device)
 static int get_vib_tab(int device, const double** out) {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_vib_tabs.find(device);
   if (it == g_vib_tabs.end()) {
     static const double depths[8] = {0.003251, 0.002999, 0.002917, 0.002749, 0.002503, 0.002423, 0.002146, 0.002088};
@@ -147,8 +208,8 @@ static int get_vib_tab(int device, const double** out) {
       for (int j = 0; j <= 128; ++j) { h[(i * 129 + j) * 2] = std::cos((double)j * d); h[(i * 129 + j) * 2 + 1] = std::sin((double)j * d); }
     }
     double* dp = nullptr;
-    HIP_TRY(hipMalloc((void**)&dp, h.size() * 8));
-    HIP_TRY(hipMemcpy(dp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(pg_malloc((void**)&dp, h.size() * 8));
+    HIP_TRY(pg_memcpy(dp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     it = g_vib_tabs.emplace(device, dp).first;
   }
   *out = it->second;
@@ -156,13 +217,14 @@ static int get_vib_tab(int device, const double** out) {
 }
 static std::map<int, float*> g_dist_luts;  // per device
 static int get_dist_luts(int device, const float** out) {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_dist_luts.find(device);
   if (it == g_dist_luts.end()) {
     std::vector<float> h(5 * 256);
     build_dist_luts(h.data());
     float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, h.size() * 4));
-    HIP_TRY(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(pg_malloc((void**)&d, h.size() * 4));
+    HIP_TRY(pg_memcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     it = g_dist_luts.emplace(device, d).first;
   }
   *out = it->second;
@@ -226,8 +288,8 @@ static int build_fx_device_state(HostFx& h, uint32_t sr, int device, bool standa
   fx.standalone = standalone ? 1 : 0;
   auto alloc = [&](size_t bytes) -> int {
     h.d_mem_bytes = bytes;
-    HIP_TRY(hipMalloc(&h.d_mem, bytes));
-    HIP_TRY(hipMemset(h.d_mem, 0, bytes));
+    HIP_TRY(pg_malloc(&h.d_mem, bytes));
+    HIP_TRY(pg_memset(h.d_mem, 0, bytes));
     return PG_OK;
   };
   switch (h.kind) {
@@ -416,14 +478,15 @@ struct pg_graph {
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
-  int timing_period = 1;   // time every n-th round with a hipEvent pair (0: never)
+  int timing_period = 0;   // time every n-th round with a hipEvent pair (0: never, the default); pg_graph_set_timing_period creates the pairs
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
   int n_staged_wide = 0;   // ... of level 2 (leading effects beyond Gain / Panning)
   int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
-  DeviceVec<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
-  DeviceVec<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
+  DeviceTable<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
+  DeviceTable<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
+  DeviceTable<PgUnit> d_topo;     // topology fields of every unit, patched into d_units by pg_patch_units_kernel
   std::vector<Level> levels;    // deepest first
   uint64_t defer_phase = 0;     // one deferral hand-shake per level launch (two counters, alternating)
   int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
@@ -446,8 +509,19 @@ struct pg_graph {
   DeviceVec<PgUnit> d_units;
   DeviceVec<PgVoice> d_voices;
   DeviceVec<PgFx> d_fx;
-  DeviceVec<int32_t> d_voice_index, d_fx_index, d_order;
-  DeviceVec<PgCmd> d_cmds;
+  DeviceTable<int32_t> d_voice_index, d_fx_index, d_order;
+  // Command lists of the launch rounds: a device ring fed from a pinned host ring of the same size by asynchronous copies, one region
+  // per round. A region is reused only after PG_CMD_RING commands have gone through since the last point at which the host knew the
+  // stream to be drained (then it waits once): rounds with parameter automation neither allocate nor block.
+  PgCmd* d_cmd_ring = nullptr;
+  PgCmd* h_cmd_ring = nullptr;
+  PgCmd* d_cmd_overflow = nullptr;
+  size_t cmd_head = 0, cmds_since_sync = 0;
+  hipStream_t last_stream = nullptr;   // the stream of the last write: mutating calls drain it before they touch device tables
+  // control path (pg_ctrl.h): messages from any thread, drained at the top of write like MixedSource::process_messages
+  pgc::CtrlRing ctrl{PG_CTRL_RING};
+  pgc::ChunkTable<int8_t> fx_kind_tab;     // effect id -> kind, -1 once removed (readable from any thread)
+  pgc::ChunkTable<int8_t> voice_alive_tab; // voice id -> 1 while it can take messages
   DeviceVec<PgSchedEntry> d_sched;       // [classes][2 banks]
   std::map<uint32_t, int> sched_class_of_ratio;
   uint64_t launch_counter = 0;
@@ -473,6 +547,17 @@ struct pg_graph {
 };
 
 static int graph_fail(pg_graph* g, int code) { g->failed = true; return code; }
+
+// Calls that change the graph (add_* / remove_* / move_* / mode switches) are not real-time calls: they first wait for everything the
+// last write enqueued — on the graph's own stream and on the caller's stream the last write used — so that no launch in flight reads a
+// table that is about to be re-uploaded, re-allocated or patched.
+static int graph_quiesce(pg_graph* g) {
+  (void)hipSetDevice(g->device);
+  HIP_TRY(pg_stream_sync(g->stream));
+  if (g->last_stream && g->last_stream != g->stream) HIP_TRY(pg_stream_sync(g->last_stream));
+  g->cmds_since_sync = 0;
+  return PG_OK;
+}
 
 // topology tables: unit -> voices / effects. Unit slots are stable; PgUnit state fields live on the device and are
 // preserved: only (kind, n_voices, voice_off, n_fx, fx_off) are patched.
@@ -509,7 +594,7 @@ static int new_unit(pg_graph* g, int kind) {
   return idx;
 }
 
-static int rebuild_topology(pg_graph* g) {
+static int rebuild_topology(pg_graph* g, hipStream_t stream) {
   std::vector<int32_t> vidx, fidx;
   std::vector<PgUnit> topo = g->h_units;
   // sub-mixers and the bus
@@ -576,18 +661,15 @@ static int rebuild_topology(pg_graph* g) {
   }
   g->n_graph_units = (int)g->order.size();
   g->levels.back().cnt = g->n_graph_units - g->levels.back().off;  // the main mixer's sources belong to the last level
-  {
-    int rc0;
-    if ((rc0 = g->d_child_rows.upload(child_rows))) return rc0;
-  }
+  int rc;
+  if ((rc = g->d_child_rows.upload_async(child_rows, stream))) return rc;
   {
     std::vector<int4> info;
     for (int slot : g->order) {
       const PgUnit& u = topo[slot];
       info.push_back(make_int4(slot, u.voice0, u.n_fx > 0 ? fidx[u.fx_off + u.n_fx - 1] : 0, (u.n_voices & 0xffffff) | (u.staged << 24)));
     }
-    int rc0;
-    if ((rc0 = g->d_slot_info.upload(info))) return rc0;
+    if ((rc = g->d_slot_info.upload_async(info, stream))) return rc;
   }
   g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
   for (Level& lv : g->levels) {
@@ -599,47 +681,75 @@ static int rebuild_topology(pg_graph* g) {
     g->n_staged += lv.n_staged; g->n_staged_wide += lv.n_staged_wide; g->n_static_defer += lv.n_static_defer;
   }
   g->h_units = topo;
-  int rc;
-  if ((rc = g->d_voice_index.upload(vidx))) return rc;
-  if ((rc = g->d_fx_index.upload(fidx))) return rc;
-  if ((rc = g->d_order.upload(g->order))) return rc;
-  // patch topology fields
-  DeviceVec<PgUnit> tmp;
-  if ((rc = tmp.upload(topo))) return rc;
+  if ((rc = g->d_voice_index.upload_async(vidx, stream))) return rc;
+  if ((rc = g->d_fx_index.upload_async(fidx, stream))) return rc;
+  if ((rc = g->d_order.upload_async(g->order, stream))) return rc;
+  // elements appended since the last build (units, effects, voices, schedule-cache entries), then the topology fields of every unit
+  if ((rc = g->d_units.flush_async(stream)) || (rc = g->d_fx.flush_async(stream)) || (rc = g->d_voices.flush_async(stream)) || (rc = g->d_sched.flush_async(stream))) return rc;
+  if ((rc = g->d_topo.upload_async(topo, stream))) return rc;
   int n = (int)topo.size();
-  hipLaunchKernelGGL(pg_patch_units_kernel, dim3((n + 63) / 64), dim3(64), 0, g->stream, g->d_units.d, tmp.d, n);
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  tmp.release();
-  // per-unit output rows
-  size_t rows = std::max<size_t>(g->n_graph_units, 1);
+  hipLaunchKernelGGL(pg_patch_units_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, g->d_units.d, g->d_topo.d, n);
+  HIP_TRY(hipGetLastError());
+  if ((size_t)std::max(g->n_graph_units, 1) > g->unit_out_rows || g->max_blocks != g->unit_out_blocks)
+    return set_error(PG_ERR_STATE, "per-unit buffers were not reserved by the mutating call");
+  g->topo_dirty = false;
+  g->last_change_round = g->launch_counter;  // the patch kernel marked every unit: the generic kernel must look at them again
+  return PG_OK;
+}
+
+// Device capacity for the graph as the host mirror describes it now. Called at the end of every mutating call (after graph_quiesce):
+// this is where the library allocates — grow-by-doubling — so that rebuild_topology and everything else inside write never does.
+static int graph_reserve(pg_graph* g) {
+  int rc;
+  const size_t n_units = g->h_units.size(), n_voices = g->voices.size(), n_fx = g->fx.size(), n_mixers = g->mixers.size();
+  if ((rc = g->d_topo.reserve(n_units)) || (rc = g->d_order.reserve(n_units)) || (rc = g->d_slot_info.reserve(n_units)) ||
+      (rc = g->d_voice_index.reserve(n_voices)) || (rc = g->d_fx_index.reserve(n_fx)) || (rc = g->d_child_rows.reserve(n_mixers)))
+    return rc;
+  if (!g->d_cmd_ring) {
+    HIP_TRY(pg_malloc((void**)&g->d_cmd_ring, PG_CMD_RING * sizeof(PgCmd)));
+    HIP_TRY(pg_host_malloc((void**)&g->h_cmd_ring, PG_CMD_RING * sizeof(PgCmd), hipHostMallocDefault));
+  }
+  // per-unit output rows (one table of rows per block of a super-block launch), deferral list, stage hand-over, mixer partials
+  const size_t rows = std::max<size_t>(n_units, 1);
   if (rows > g->unit_out_rows || g->max_blocks != g->unit_out_blocks) {
-    if (g->d_unit_out) (void)hipFree(g->d_unit_out);
+    if (g->d_unit_out) (void)pg_free(g->d_unit_out);
+    g->d_unit_out = nullptr;
     size_t nr = rows > g->unit_out_rows ? std::max(rows, g->unit_out_rows * 2) : g->unit_out_rows;
-    // one table of rows per block of a super-block launch; +4: the mixer sum reads whole float4s (odd max_frames)
-    HIP_TRY(hipMalloc((void**)&g->d_unit_out, (nr * g->stride * g->max_blocks + 4) * sizeof(float)));
+    HIP_TRY(pg_malloc((void**)&g->d_unit_out, (nr * g->stride * g->max_blocks + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
     g->unit_out_rows = nr;
     g->unit_out_blocks = g->max_blocks;
   }
   if (rows > g->defer_rows) {
-    if (g->d_defer) (void)hipFree(g->d_defer);
-    HIP_TRY(hipMalloc((void**)&g->d_defer, (2 + rows) * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(g->d_defer, 0, (2 + rows) * sizeof(int32_t), g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    g->defer_rows = rows;
+    if (g->d_defer) (void)pg_free(g->d_defer);
+    g->d_defer = nullptr;
+    const size_t nr = std::max(rows, g->defer_rows * 2);
+    HIP_TRY(pg_malloc((void**)&g->d_defer, (2 + nr) * sizeof(int32_t)));
+    HIP_TRY(pg_memset(g->d_defer, 0, (2 + nr) * sizeof(int32_t)));
+    g->defer_rows = nr;
   }
-  if (g->n_staged > 0 && rows > g->stage_rows) {
-    if (g->d_stage) (void)hipFree(g->d_stage);
-    HIP_TRY(hipMalloc((void**)&g->d_stage, rows * (size_t)PG_STAGE_BUF_DOUBLES * sizeof(double)));
-    g->stage_rows = rows;
+  bool any_reverb = false;
+  for (const auto& f : g->fx) any_reverb |= f->kind == PG_FX_REVERB;
+  if (any_reverb && rows > g->stage_rows) {  // hand-over buffer of the one-launch-per-stage mode (pg_graph_set_staged(g, 2))
+    if (g->d_stage) (void)pg_free(g->d_stage);
+    g->d_stage = nullptr;
+    const size_t nr = std::max(rows, g->stage_rows * 2);
+    HIP_TRY(pg_malloc((void**)&g->d_stage, nr * (size_t)PG_STAGE_BUF_DOUBLES * sizeof(double)));
+    g->stage_rows = nr;
   }
-  size_t prow = (rows + 15) / 16;
+  const size_t prow = (rows + 15) / 16;
   if (prow > g->partial_rows) {
-    if (g->d_partial) (void)hipFree(g->d_partial);
-    HIP_TRY(hipMalloc((void**)&g->d_partial, (prow * 2 * g->stride + 4) * sizeof(float)));
-    g->partial_rows = prow * 2;
+    if (g->d_partial) (void)pg_free(g->d_partial);
+    g->d_partial = nullptr;
+    const size_t nr = std::max(prow, g->partial_rows * 2);
+    HIP_TRY(pg_malloc((void**)&g->d_partial, (nr * g->stride + 4) * sizeof(float)));
+    g->partial_rows = nr;
   }
-  g->topo_dirty = false;
-  g->last_change_round = g->launch_counter;  // the patch kernel marked every unit: the generic kernel must look at them again
+  return PG_OK;
+}
+// blocking upload of whatever still waits in the staging blocks (introspection calls that read device state)
+static int graph_flush_blocking(pg_graph* g) {
+  int rc;
+  if ((rc = g->d_units.flush()) || (rc = g->d_fx.flush()) || (rc = g->d_voices.flush()) || (rc = g->d_sched.flush())) return rc;
   return PG_OK;
 }
 
@@ -676,14 +786,14 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   g->device = device; g->sample_rate = sample_rate; g->channels = 2; g->max_frames = max_frames;
   g->stride = (uint32_t)(2 * max_frames);
   if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
-  if (hipMalloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || hipMalloc((void**)&g->d_audible, 16) != hipSuccess ||
-      hipHostMalloc((void**)&g->h_pinned, (g->stride + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+  if (pg_malloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || pg_malloc((void**)&g->d_audible, 16) != hipSuccess ||
+      pg_host_malloc((void**)&g->h_pinned, (g->stride + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
     return nullptr;
   }
-  (void)hipMemset(g->d_audible, 0, 16);
-  if (hipMalloc((void**)&g->d_error, 16) == hipSuccess) (void)hipMemset(g->d_error, 0, 16); else g->d_error = nullptr;
-  if (hipHostMalloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
+  (void)pg_memset(g->d_audible, 0, 16);
+  if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
+  if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     *g->h_feedback = ~0ull;  // nothing reported yet
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
@@ -691,34 +801,39 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   g->mixers[0].depth = 0;
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
   if (g->mixers[0].unit_slot < 0) return nullptr;
+  if (graph_reserve(g.get())) return nullptr;
   return g.release();
 }
 
 void pg_graph_destroy(pg_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
-  (void)hipStreamSynchronize(g->stream);
-  for (auto& v : g->voices) if (v.d_pcm) (void)hipFree(v.d_pcm);
-  for (auto& f : g->fx) if (f->d_mem) (void)hipFree(f->d_mem);
+  (void)pg_stream_sync(g->stream);
+  if (g->last_stream && g->last_stream != g->stream) (void)pg_stream_sync(g->last_stream);
+  for (auto& v : g->voices) if (v.d_pcm) (void)pg_free(v.d_pcm);
+  for (auto& f : g->fx) if (f->d_mem) (void)pg_free(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_cmds.release(); g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release();
-  if (g->d_unit_out) (void)hipFree(g->d_unit_out);
-  if (g->d_partial) (void)hipFree(g->d_partial);
-  if (g->d_stage) (void)hipFree(g->d_stage);
-  if (g->d_defer) (void)hipFree(g->d_defer);
-  if (g->d_bus) (void)hipFree(g->d_bus);
-  if (g->d_audible) (void)hipFree(g->d_audible);
-  if (g->d_error) (void)hipFree(g->d_error);
-  if (g->h_pinned) (void)hipHostFree(g->h_pinned);
-  if (g->h_feedback) (void)hipHostFree(g->h_feedback);
+  g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release(); g->d_topo.release();
+  if (g->d_cmd_ring) (void)pg_free(g->d_cmd_ring);
+  if (g->d_cmd_overflow) (void)pg_free(g->d_cmd_overflow);
+  if (g->h_cmd_ring) (void)pg_host_free(g->h_cmd_ring);
+  if (g->d_unit_out) (void)pg_free(g->d_unit_out);
+  if (g->d_partial) (void)pg_free(g->d_partial);
+  if (g->d_stage) (void)pg_free(g->d_stage);
+  if (g->d_defer) (void)pg_free(g->d_defer);
+  if (g->d_bus) (void)pg_free(g->d_bus);
+  if (g->d_audible) (void)pg_free(g->d_audible);
+  if (g->d_error) (void)pg_free(g->d_error);
+  if (g->h_pinned) (void)pg_host_free(g->h_pinned);
+  if (g->h_feedback) (void)pg_host_free(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(g->stream);
   delete g;
 }
 
 int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id) {
-  (void)hipSetDevice(g->device);
   if (parent_mixer_id < 0 || parent_mixer_id >= (int)g->mixers.size() || g->mixers[parent_mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", parent_mixer_id);
+  if (graph_quiesce(g)) return -graph_fail(g, PG_ERR_DEVICE);
   int slot = new_unit(g, UNIT_SUBMIXER);
   if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
   const int id = (int)g->mixers.size();
@@ -727,13 +842,15 @@ int pg_graph_add_mixer_to(pg_graph* g, int parent_mixer_id) {
   g->mixers.back().parent = parent_mixer_id;
   g->mixers.back().depth = g->mixers[parent_mixer_id].depth + 1;
   if (parent_mixer_id != 0) g->mixers[parent_mixer_id].children.push_back(id);
+  g->mixers.back().events.reserve(64);
+  if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
   return id;
 }
 int pg_graph_add_mixer(pg_graph* g) { return pg_graph_add_mixer_to(g, 0); }
 
 int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_init* init) {
-  (void)hipSetDevice(g->device);
   if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  if (graph_quiesce(g)) return -graph_fail(g, PG_ERR_DEVICE);
   std::unique_ptr<HostFx> h(new HostFx());
   int rc = host_fx_from_init(kind, init, *h);
   if (rc) return -rc;
@@ -746,14 +863,17 @@ int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_ini
   g->fx.push_back(std::move(h));
   g->fx_mixer.push_back(mixer_id);
   g->mixers[mixer_id].fx.push_back(idx);
+  if (!g->fx_kind_tab.append((int8_t)kind)) return -set_error(PG_ERR_STATE, "too many effects");
   g->topo_dirty = true;
+  if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
   return idx;
 }
 
 // Player::stop_all_sources (src/player.rs:1012-1045): every playing file source is told to stop (fades out from the next write on,
 // like pg_graph_stop_voice at "now"), and every mixer gets MixerMessage::RemoveAllPendingEvents (src/source/mixed.rs:298-305), which
 // at the start of the next write drops the sources that have not started yet and the events scheduled after that write's position.
-int pg_graph_stop_all_voices(pg_graph* g) {
+static void drain_control_messages(pg_graph* g);
+static void stop_all_voices_now(pg_graph* g) {
   for (size_t v = 0; v < g->voices.size(); ++v) {
     if (g->voices[v].mixer < 0) continue;
     PgCmd c;
@@ -762,7 +882,16 @@ int pg_graph_stop_all_voices(pg_graph* g) {
     g->mixers[g->voices[v].mixer].messages.push_back(c);
   }
   for (HostMixer& mx : g->mixers) if (!mx.removed) mx.remove_pending = true;
+}
+static int ctrl_push(pg_graph* g, const pgc::CtrlMsg& m) {
+  if (!g->ctrl.push(m)) return set_error(PG_ERR_QUEUE_FULL, "mixer's message queue is full");  // Error::SendError
   return PG_OK;
+}
+int pg_graph_stop_all_voices(pg_graph* g) {
+  pgc::CtrlMsg m;
+  memset(&m, 0, sizeof m);
+  m.type = pgc::CT_STOP_ALL;
+  return ctrl_push(g, m);
 }
 static void apply_remove_pending(pg_graph* g, uint64_t pos) {
   for (HostMixer& mx : g->mixers) {
@@ -773,6 +902,7 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
       if (g->voices[v].start_time > pos) {
         mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [v](const PgCmd& c) { return c.param == v; }), mx.messages.end());
         g->voices[v].mixer = -1;
+        g->voice_alive_tab.set((size_t)v, 0);
         mx.voices.erase(mx.voices.begin() + i);
         if (&mx == &g->mixers[0] && g->main_active_voices > 0) g->main_active_voices -= 1;
         g->topo_dirty = true;
@@ -789,14 +919,16 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
 int pg_graph_remove_mixer(pg_graph* g, int mixer_id) {
   if (mixer_id == 0) return set_error(PG_ERR_PARAMETER, "Cannot remove the main mixer");
   if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  if (graph_quiesce(g)) return graph_fail(g, PG_ERR_DEVICE);
+  drain_control_messages(g);  // messages sent before the removal still find their target
   std::vector<int>& siblings = g->mixers[g->mixers[mixer_id].parent].children;
   siblings.erase(std::remove(siblings.begin(), siblings.end(), mixer_id), siblings.end());
   std::vector<int> gone(1, mixer_id);
   for (size_t i = 0; i < gone.size(); ++i) {
     HostMixer& mx = g->mixers[gone[i]];
     for (int c : mx.children) gone.push_back(c);
-    for (int f : mx.fx) g->fx_mixer[f] = -1;
-    for (int v : mx.voices) g->voices[v].mixer = -1;
+    for (int f : mx.fx) { g->fx_mixer[f] = -1; g->fx_kind_tab.set((size_t)f, -1); }
+    for (int v : mx.voices) { g->voices[v].mixer = -1; g->voice_alive_tab.set((size_t)v, 0); }
     mx.children.clear(); mx.fx.clear(); mx.voices.clear(); mx.events.clear(); mx.messages.clear(); mx.bus_events.clear();
     mx.removed = true;
   }
@@ -810,12 +942,15 @@ int pg_graph_remove_mixer(pg_graph* g, int mixer_id) {
 // effect on the collector thread, never on the audio thread).
 int pg_graph_remove_effect(pg_graph* g, int effect_id) {
   if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  if (graph_quiesce(g)) return graph_fail(g, PG_ERR_DEVICE);
+  drain_control_messages(g);
   HostMixer& mx = g->mixers[g->fx_mixer[effect_id]];
   mx.fx.erase(std::remove(mx.fx.begin(), mx.fx.end(), effect_id), mx.fx.end());
   auto addressed = [effect_id](const Event& e) { return (e.cmd.type == CMD_FX_PARAM || e.cmd.type == CMD_FX_RESET) && e.cmd.target == effect_id; };
   mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), addressed), mx.events.end());
   mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), addressed), mx.bus_events.end());
   g->fx_mixer[effect_id] = -1;
+  g->fx_kind_tab.set((size_t)effect_id, -1);
   g->topo_dirty = true;
   return PG_OK;
 }
@@ -825,6 +960,7 @@ int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement,
   if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
   if (g->fx_mixer[effect_id] != mixer_id) return set_error(PG_ERR_PARAMETER, "Effect %d does not belong to mixer %d", effect_id, mixer_id);
   if (movement < PG_MOVE_DIRECTION || movement > PG_MOVE_END) return set_error(PG_ERR_PARAMETER, "unknown effect movement %d", movement);
+  if (graph_quiesce(g)) return graph_fail(g, PG_ERR_DEVICE);
   std::vector<int>& fx = g->mixers[mixer_id].fx;
   const auto it = std::find(fx.begin(), fx.end(), effect_id);
   if (it == fx.end()) return PG_OK;  // (logged and ignored in the reference)
@@ -840,7 +976,6 @@ int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement,
 
 int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
                        const pg_voice_options* opt) {
-  (void)hipSetDevice(g->device);
   if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
   // AudioFileBuffer::new validation (file/buffer.rs:22-60)
   if (src_rate == 0) return -set_error(PG_ERR_PARAMETER, "file buffer sample rate must be > 0");
@@ -850,12 +985,13 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   if (!opt) { pg_voice_options_default(&def); opt = &def; }
   if (!(opt->speed > 0.0)) return -set_error(PG_ERR_PARAMETER, "speed must be > 0");
   if (opt->volume < 0.0f || opt->panning < -1.0f || opt->panning > 1.0f) return -set_error(PG_ERR_PARAMETER, "invalid volume or panning");
+  if (graph_quiesce(g)) return -graph_fail(g, PG_ERR_DEVICE);
   PgVoice v;
   memset(&v, 0, sizeof v);
   size_t n_samples = n_frames * src_channels;
   void* d_pcm = nullptr;
-  if (hipMalloc(&d_pcm, n_samples * sizeof(float)) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "hipMalloc(pcm) failed"));
-  if (hipMemcpy(d_pcm, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pcm upload failed"));
+  if (pg_malloc(&d_pcm, n_samples * sizeof(float)) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pg_malloc(pcm) failed"));
+  if (pg_memcpy(d_pcm, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pcm upload failed"));
   v.pcm = (const float*)d_pcm;
   v.n_samples = n_samples; v.channels = src_channels; v.src_rate = src_rate; v.out_rate = g->sample_rate;
   // FileSourceImpl::new: resampler file_rate -> (out_rate / speed) as u32  (file/common.rs:78-86); ratio = (in/out as f64) as f32 (cubic.rs:164)
@@ -920,118 +1056,149 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
     g->main_active_voices += 1;
     g->ever_had_main_voice = true;
   }
+  if (!g->voice_alive_tab.append(1)) return -set_error(PG_ERR_STATE, "too many voices");
   g->topo_dirty = true;
+  if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
   return id;
 }
 
-static int push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
-  HostMixer& mx = g->mixers[mixer];
-  if (mx.events.size() >= 4096) return set_error(PG_ERR_QUEUE_FULL, "mixer's event queue is full");  // EVENTS_CAPACITY mixed.rs:236
-  Event e{sample_time, g->event_seq++, cmd, mixer};
-  size_t pos = 0;  // partition_point(|e| e.sample_time <= sample_time)  event.rs:31-38
-  while (pos < mx.events.size() && mx.events[pos].sample_time <= sample_time) ++pos;
-  mx.events.insert(mx.events.begin() + pos, e);
-  return PG_OK;
+// ---- control calls: any thread, concurrently with write() ------------------------------------------------------------------
+// Each call validates what it can from immutable descriptor tables and the append-only id tables (kind of the effect, whether the
+// voice still exists), resolves Raw / Normalized to a raw value, and pushes ONE record into the graph's lock-free ring — nothing
+// else is touched. The thread inside write() drains the ring at the top of the call (drain_control_messages == process_messages,
+// src/source/mixed.rs:294-499): sample-time-tagged messages become sorted events of their mixer, StopSource stays a message.
+static int fx_kind_of(pg_graph* g, int effect_id) {  // -1: unknown or removed
+  if (effect_id < 0 || (size_t)effect_id >= g->fx_kind_tab.size()) return -1;
+  return (int)g->fx_kind_tab.get((size_t)effect_id);
 }
+static bool voice_alive(pg_graph* g, int voice_id) { return voice_id >= 0 && (size_t)voice_id < g->voice_alive_tab.size() && g->voice_alive_tab.get((size_t)voice_id) != 0; }
 
 int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
-  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
-  HostFx& h = *g->fx[effect_id];
-  int pi = find_param(h.kind, fourcc);
-  if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[h.kind].name);
+  const int kind = fx_kind_of(g, effect_id);
+  if (kind < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  int pi = find_param(kind, fourcc);
+  if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[kind].name);
   float raw;
-  if (!resolve_update(KINDS[h.kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;  // logged + ignored in the reference
-  if (h.kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
+  if (!resolve_update(KINDS[kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;  // logged + ignored in the reference
+  if (kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
     return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
-  h.target[pi] = raw;
-  // a Gain whose DC filter gets switched on later needs the kernel variants that carry the DC scan: classify the chain again
-  if (h.kind == PG_FX_GAIN && pi != P_GAIN_GAIN && (int)raw != 0 && (int)h.init_raw[1] == 0) { h.init_raw[1] = raw; g->topo_dirty = true; }
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_FX_PARAM; c.target = effect_id; c.param = pi; c.value = raw;
-  return push_event(g, g->fx_mixer[effect_id], sample_time, c);
+  pgc::CtrlMsg m;
+  memset(&m, 0, sizeof m);
+  m.type = pgc::CT_FX_PARAM; m.id = effect_id; m.param = pi; m.value = raw; m.sample_time = sample_time;
+  return ctrl_push(g, m);
 }
 int pg_graph_schedule_reset(pg_graph* g, int effect_id, uint64_t sample_time) {
-  if (effect_id < 0 || effect_id >= (int)g->fx.size() || g->fx_mixer[effect_id] < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
-  int kind = g->fx[effect_id]->kind;
+  const int kind = fx_kind_of(g, effect_id);
+  if (kind < 0) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
   if (kind != PG_FX_DELAY && kind != PG_FX_REVERB && kind != PG_FX_CHORUS)
     return set_error(PG_ERR_PARAMETER, "%sEffect: Invalid/unknown message payload", KINDS[kind].name);
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_FX_RESET; c.target = effect_id;
-  return push_event(g, g->fx_mixer[effect_id], sample_time, c);
+  pgc::CtrlMsg m;
+  memset(&m, 0, sizeof m);
+  m.type = pgc::CT_FX_RESET; m.id = effect_id; m.sample_time = sample_time;
+  return ctrl_push(g, m);
 }
-static int voice_event(pg_graph* g, int voice_id, int type, float value, uint64_t sample_time) {
-  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = type; c.target = g->voices[voice_id].dev_index; c.value = value;
-  c.param = voice_id;
-  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+static int voice_message(pg_graph* g, int voice_id, int type, float value, double dvalue, uint64_t sample_time) {
+  if (!voice_alive(g, voice_id)) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  pgc::CtrlMsg m;
+  memset(&m, 0, sizeof m);
+  m.type = type; m.id = voice_id; m.value = value; m.dvalue = dvalue; m.sample_time = sample_time;
+  return ctrl_push(g, m);
 }
-int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_VOLUME, volume, sample_time); }
-int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_event(g, voice_id, CMD_VOICE_PAN, panning, sample_time); }
+int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t sample_time) { return voice_message(g, voice_id, pgc::CT_VOICE_VOLUME, volume, 0.0, sample_time); }
+int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_message(g, voice_id, pgc::CT_VOICE_PAN, panning, 0.0, sample_time); }
 int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glide, uint64_t sample_time) {
   if (!(speed > 0.0)) return set_error(PG_ERR_PARAMETER, "speed must be > 0");
-  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_VOICE_SPEED; c.target = g->voices[voice_id].dev_index; c.value = glide; c.param = voice_id;
-  memcpy(&c.value64, &speed, 8);
-  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+  return voice_message(g, voice_id, pgc::CT_VOICE_SPEED, glide, speed, sample_time);
 }
 int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint64_t sample_time) {
-  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
   if (!(position_seconds >= 0.0)) return set_error(PG_ERR_PARAMETER, "seek position must be >= 0");
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_VOICE_SEEK; c.target = g->voices[voice_id].dev_index; c.param = voice_id;
-  memcpy(&c.value64, &position_seconds, 8);
-  return push_event(g, g->voices[voice_id].mixer, sample_time, c);
+  return voice_message(g, voice_id, pgc::CT_VOICE_SEEK, 0.0f, position_seconds, sample_time);
 }
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // MixerMessage::StopSource (mixed.rs:389-400): not an event
-  if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_VOICE_STOP; c.target = g->voices[voice_id].dev_index; c.value64 = sample_time; c.param = voice_id;
-  g->mixers[g->voices[voice_id].mixer].messages.push_back(c);
-  return PG_OK;
+  return voice_message(g, voice_id, pgc::CT_VOICE_STOP, 0.0f, 0.0, sample_time);
+}
+
+// insert_event (src/utils/event.rs:31-38): sorted by sample time, after the events of the same time
+static void push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
+  HostMixer& mx = g->mixers[mixer];
+  Event e{sample_time, g->event_seq++, cmd, mixer};
+  size_t pos = mx.events.size();  // partition_point(|e| e.sample_time <= sample_time); automation usually arrives in time order: search from the back
+  while (pos > 0 && mx.events[pos - 1].sample_time > sample_time) --pos;
+  mx.events.insert(mx.events.begin() + pos, e);
+}
+// MixedSource::process_messages (src/source/mixed.rs:294-499) for the whole graph: the writing thread only.
+static void drain_control_messages(pg_graph* g) {
+  pgc::CtrlMsg m;
+  while (g->ctrl.pop(m)) {
+    PgCmd c;
+    memset(&c, 0, sizeof c);
+    switch (m.type) {
+      case pgc::CT_FX_PARAM: {
+        if (m.id < 0 || m.id >= (int)g->fx.size() || g->fx_mixer[m.id] < 0) break;  // removed in the meantime: dropped, as an event for a missing effect is (mixed.rs:880-924)
+        HostFx& h = *g->fx[m.id];
+        h.target[m.param] = m.value;
+        // a Gain whose DC filter gets switched on later needs the kernel variants that carry the DC scan: classify the chain again
+        if (h.kind == PG_FX_GAIN && m.param != P_GAIN_GAIN && (int)m.value != 0 && (int)h.init_raw[1] == 0) { h.init_raw[1] = m.value; g->topo_dirty = true; }
+        c.type = CMD_FX_PARAM; c.target = m.id; c.param = m.param; c.value = m.value;
+        push_event(g, g->fx_mixer[m.id], m.sample_time, c);
+      } break;
+      case pgc::CT_FX_RESET: {
+        if (m.id < 0 || m.id >= (int)g->fx.size() || g->fx_mixer[m.id] < 0) break;
+        c.type = CMD_FX_RESET; c.target = m.id;
+        push_event(g, g->fx_mixer[m.id], m.sample_time, c);
+      } break;
+      case pgc::CT_STOP_ALL: stop_all_voices_now(g); break;
+      default: {
+        if (m.id < 0 || m.id >= (int)g->voices.size() || g->voices[m.id].mixer < 0) break;
+        const HostVoice& hv = g->voices[m.id];
+        c.target = hv.dev_index; c.param = m.id;
+        if (m.type == pgc::CT_VOICE_STOP) { c.type = CMD_VOICE_STOP; c.value64 = m.sample_time; g->mixers[hv.mixer].messages.push_back(c); break; }
+        if (m.type == pgc::CT_VOICE_VOLUME) { c.type = CMD_VOICE_VOLUME; c.value = m.value; }
+        else if (m.type == pgc::CT_VOICE_PAN) { c.type = CMD_VOICE_PAN; c.value = m.value; }
+        else if (m.type == pgc::CT_VOICE_SPEED) { c.type = CMD_VOICE_SPEED; c.value = m.value; memcpy(&c.value64, &m.dvalue, 8); }
+        else { c.type = CMD_VOICE_SEEK; memcpy(&c.value64, &m.dvalue, 8); }
+        push_event(g, hv.mixer, m.sample_time, c);
+      } break;
+    }
+  }
 }
 
 int pg_graph_diag(pg_graph* g, unsigned long long* out, int n) {  // diagnostic builds: shader-clock stamps of workgroup 0
   (void)hipSetDevice(g->device);
   const int cap = 64 + 4 * 4096;  // 64 stamps of workgroup 0, then {start, stage-1 end, stage-2 end, end} (s_memrealtime, 100 MHz) per launch slot
-  if (!g->d_diag) { HIP_TRY(hipMalloc((void**)&g->d_diag, (size_t)cap * 8)); HIP_TRY(hipMemset(g->d_diag, 0, (size_t)cap * 8)); return PG_OK; }
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  HIP_TRY(hipMemcpy(out, g->d_diag, (size_t)(n > cap ? cap : n) * 8, hipMemcpyDeviceToHost));
+  if (!g->d_diag) { HIP_TRY(pg_malloc((void**)&g->d_diag, (size_t)cap * 8)); HIP_TRY(pg_memset(g->d_diag, 0, (size_t)cap * 8)); return PG_OK; }
+  HIP_TRY(pg_stream_sync(g->stream));
+  HIP_TRY(pg_memcpy(out, g->d_diag, (size_t)(n > cap ? cap : n) * 8, hipMemcpyDeviceToHost));
   return PG_OK;
 }
 int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
   if (n_blocks < 1 || n_blocks > 64) return set_error(PG_ERR_PARAMETER, "blocks per launch must be in 1..=64");
-  (void)hipSetDevice(g->device);
-  HIP_TRY(hipStreamSynchronize(g->stream));
+  { int rc = graph_quiesce(g); if (rc) return rc; }
   // staging of pg_graph_write (host buffers): one super-block + the status words
   float* nb = nullptr; float* np = nullptr;
   const size_t words = (size_t)g->stride * (size_t)n_blocks + 4;
-  HIP_TRY(hipMalloc((void**)&nb, words * sizeof(float)));
-  if (hipHostMalloc((void**)&np, words * sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)hipFree(nb); return set_error(PG_ERR_DEVICE, "pinned allocation failed"); }
-  (void)hipFree(g->d_bus); (void)hipHostFree(g->h_pinned);
+  HIP_TRY(pg_malloc((void**)&nb, words * sizeof(float)));
+  if (pg_host_malloc((void**)&np, words * sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)pg_free(nb); return set_error(PG_ERR_DEVICE, "pinned allocation failed"); }
+  (void)pg_free(g->d_bus); (void)pg_host_free(g->h_pinned);
   g->d_bus = nb; g->h_pinned = np;
   g->max_blocks = (size_t)n_blocks;
-  g->topo_dirty = true;  // the per-unit output table is sized at the next topology build (never inside a steady-state write)
-  return PG_OK;
+  g->topo_dirty = true;
+  return graph_reserve(g);  // the per-unit output table grows here, never inside write
+}
+void pg_debug_hip_calls(uint64_t out[4]) {
+  out[0] = g_n_alloc.load(); out[1] = g_n_free.load(); out[2] = g_n_sync.load(); out[3] = g_n_blocking_copy.load();
 }
 int pg_graph_device_errors(pg_graph* g) {
   (void)hipSetDevice(g->device);
   if (!g->d_error) return 0;
   int32_t e = 0;
-  if (hipStreamSynchronize(g->stream) != hipSuccess || hipMemcpy(&e, g->d_error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -PG_ERR_DEVICE;
+  if (pg_stream_sync(g->stream) != hipSuccess || pg_memcpy(&e, g->d_error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -PG_ERR_DEVICE;
   return (int)e;
 }
 int pg_graph_set_defer_bus(pg_graph* g, int defer) { g->defer_bus = defer != 0; return PG_OK; }
 int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; g->last_change_round = g->launch_counter; return PG_OK; }
 const char* pg_graph_dominant_kernel(pg_graph* g) {
-  if (g->topo_dirty) (void)rebuild_topology(g);
+  if (g->topo_dirty) { (void)graph_quiesce(g); (void)rebuild_topology(g, g->stream); (void)pg_stream_sync(g->stream); }
   if (!g->fast || g->n_static_defer * 2 > g->n_graph_units) return "pg_unit_kernel";
   const int n_lean = g->n_staged - g->n_staged_wide;
   const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
@@ -1043,25 +1210,37 @@ const char* pg_graph_dominant_kernel(pg_graph* g) {
   }
   return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
 }
-int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) { g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds; return PG_OK; }
+int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) {
+  g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds;
+  (void)hipSetDevice(g->device);
+  while (g->timing_period > 0 && g->ev_pool.size() < 512) {  // created here, never inside write: when all are in use the later rounds go untimed
+    hipEvent_t a, b;                                           // until pg_graph_kernel_ms / pg_graph_kernel_stats collects them
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g->ev_pool.emplace_back(a, b);
+    g->ev_blocks.push_back(1);
+  }
+  return PG_OK;
+}
 int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; g->last_change_round = g->launch_counter; return PG_OK; }
 int pg_graph_voice_count(pg_graph* g) { return (int)g->voices.size(); }
 int pg_graph_synchronize(pg_graph* g) {
   (void)hipSetDevice(g->device);
-  HIP_TRY(hipStreamSynchronize(g->stream));
+  HIP_TRY(pg_stream_sync(g->stream));
   return PG_OK;
 }
 int pg_graph_is_voice_playing(pg_graph* g, int voice_id) {
   if (voice_id < 0 || voice_id >= (int)g->voices.size() || g->voices[voice_id].mixer < 0) return 0;
   (void)hipSetDevice(g->device);
-  (void)hipStreamSynchronize(g->stream);
+  (void)pg_stream_sync(g->stream);
+  if (graph_flush_blocking(g)) return 0;
   PgVoice v;
-  if (hipMemcpy(&v, g->d_voices.d + g->voices[voice_id].dev_index, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (pg_memcpy(&v, g->d_voices.d + g->voices[voice_id].dev_index, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return v.active && !v.finished;
 }
 int pg_graph_deferred_units(pg_graph* g) {
   (void)hipSetDevice(g->device);
-  (void)hipStreamSynchronize(g->stream);
+  (void)pg_stream_sync(g->stream);
   if (!g->h_feedback) return 0;
   // (round << 32 | deferred units) as the generic kernel of the last round that launched it reported; rounds that skipped the launch
   // did so because this word said 0 and nothing had changed since
@@ -1109,19 +1288,44 @@ static bool graph_super_ok(const pg_graph* g) {
   return g->max_blocks > 1 && g->staged_mode != 2 && (g->defer_bus || g->mixers[0].fx.empty()) && graph_steady(g);
 }
 
+// The command list of one round -> a fresh region of the device ring (asynchronous copy from the pinned ring on the round's stream).
+static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream_t stream, const PgCmd** d_out) {
+  const size_t n = cmds.size();
+  if (n > PG_CMD_RING) {
+    // More commands in ONE launch round than the ring holds (tens of thousands of events between two samples): the degenerate case
+    // leaves the allocation-free path — a table of its own, released when the next oversized round or the graph's end comes.
+    HIP_TRY(pg_stream_sync(stream));
+    if (g->d_cmd_overflow) (void)pg_free(g->d_cmd_overflow);
+    g->d_cmd_overflow = nullptr;
+    HIP_TRY(pg_malloc((void**)&g->d_cmd_overflow, n * sizeof(PgCmd)));
+    HIP_TRY(pg_memcpy(g->d_cmd_overflow, cmds.data(), n * sizeof(PgCmd), hipMemcpyHostToDevice));
+    *d_out = g->d_cmd_overflow;
+    return PG_OK;
+  }
+  size_t skipped = 0;
+  if (g->cmd_head + n > PG_CMD_RING) { skipped = PG_CMD_RING - g->cmd_head; g->cmd_head = 0; }
+  if (g->cmds_since_sync + skipped + n > PG_CMD_RING) {  // the region may still be read by a round in flight: wait once per ring revolution
+    HIP_TRY(pg_stream_sync(stream));
+    g->cmds_since_sync = 0; skipped = 0;
+  }
+  memcpy(g->h_cmd_ring + g->cmd_head, cmds.data(), n * sizeof(PgCmd));
+  HIP_TRY(hipMemcpyAsync(g->d_cmd_ring + g->cmd_head, g->h_cmd_ring + g->cmd_head, n * sizeof(PgCmd), hipMemcpyHostToDevice, stream));
+  *d_out = g->d_cmd_ring + g->cmd_head;
+  g->cmd_head += n;
+  g->cmds_since_sync += skipped + n;
+  return PG_OK;
+}
+
 // One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
 // n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok().
 static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1) {
-  int rc;
-  if (!cmds.empty()) {  // rare (parameter automation): drain the stream so the previous round no longer reads the command table
-    HIP_TRY(hipStreamSynchronize(stream));
-    if ((rc = g->d_cmds.upload(cmds))) return rc;
-  }
+  const PgCmd* d_cmds = nullptr;
+  if (!cmds.empty()) { int rc = stage_commands(g, cmds, stream, &d_cmds); if (rc) return rc; }
   PgLaunch L;
   memset(&L, 0, sizeof L);
   L.units = g->d_units.d; L.voices = g->d_voices.d; L.fx = g->d_fx.d;
   L.voice_index = g->d_voice_index.d; L.fx_index = g->d_fx_index.d;
-  L.cmds = g->d_cmds.d; L.n_cmds = (int)cmds.size();
+  L.cmds = d_cmds; L.n_cmds = (int)cmds.size();
   L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
   L.out_stride = g->stride;
   L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
@@ -1141,14 +1345,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   g->launch_counter++;
   // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
   // average can time every n-th round (pg_graph_set_timing_period)
-  bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < 8192 && g->n_graph_units > 0;
-  if (timed && g->ev_used >= g->ev_pool.size()) {
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    g->ev_pool.emplace_back(a, b);
-    g->ev_blocks.push_back(1);
-  }
+  const bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < g->ev_pool.size() && g->n_graph_units > 0;
   size_t timed_level = 0;  // the level holding most units carries the timing events
   for (size_t li = 1; li < g->levels.size(); ++li) if (g->levels[li].cnt > g->levels[timed_level].cnt) timed_level = li;
   for (size_t li = 0; li < g->levels.size(); ++li) {
@@ -1213,8 +1410,12 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
   if (g->failed) return 0;
   if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   (void)hipSetDevice(g->device);
+  // a caller that moves from one stream to another without a graph mutation in between: the tables and rings are ordered per stream
+  if (g->last_stream && g->last_stream != stream) { if (pg_stream_sync(g->last_stream) != hipSuccess) { g->failed = true; return 0; } g->cmds_since_sync = 0; }
+  g->last_stream = stream;
+  drain_control_messages(g);  // process_messages (mixed.rs:294-499)
   apply_remove_pending(g, pos);
-  if (g->topo_dirty && rebuild_topology(g)) { g->failed = true; return 0; }
+  if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
   // "Return early and avoid touching the buffer if there's nothing to do" (:664-670)
   bool any_events = false;
   for (auto& m : g->mixers) any_events |= !m.events.empty();
@@ -1321,7 +1522,7 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
 size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
   size_t w = graph_write_impl(g, d_out, n_samples, pos_in_frames, s);
-  if (!hip_stream && w) { if (hipStreamSynchronize(g->stream) != hipSuccess) { g->failed = true; return 0; } }
+  if (!hip_stream && w) { if (pg_stream_sync(g->stream) != hipSuccess) { g->failed = true; return 0; } g->cmds_since_sync = 0; }
   return w;
 }
 
@@ -1343,11 +1544,12 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
                        g->d_bus + cap);
     if (hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         hipMemcpyAsync(g->h_pinned + cap, g->d_bus + cap, 4 * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-        hipStreamSynchronize(g->stream) != hipSuccess) {
+        pg_stream_sync(g->stream) != hipSuccess) {
       g->failed = true;
       set_error(PG_ERR_DEVICE, "device failure in write: %s", hipGetErrorString(hipGetLastError()));
       return 0;
     }
+    g->cmds_since_sync = 0;
     memcpy(out + off, g->h_pinned, n * sizeof(float));
     g->main_active_voices = ((int*)(g->h_pinned + cap))[0];
     off += n; pos += n / 2; total += n;
@@ -1360,7 +1562,9 @@ int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uin
   (void)hipSetDevice(g->device);
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
   if (g->mixers[0].fx.empty()) return PG_OK;
-  if (g->topo_dirty && rebuild_topology(g)) return graph_fail(g, PG_ERR_DEVICE);
+  if (g->last_stream && g->last_stream != s) { HIP_TRY(pg_stream_sync(g->last_stream)); g->cmds_since_sync = 0; }
+  g->last_stream = s;
+  if (g->topo_dirty && rebuild_topology(g, s)) return graph_fail(g, PG_ERR_DEVICE);
   size_t frames = n_samples / 2, done = 0;
   HostMixer& main = g->mixers[0];
   while (done < frames) {
@@ -1378,16 +1582,13 @@ int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uin
     if (!main.bus_events.empty()) n64 = std::min<uint64_t>(n64, main.bus_events.front().sample_time - now);
     if (n64 == 0) continue;
     const uint32_t n = (uint32_t)n64;
-    if (!cmds.empty()) {
-      HIP_TRY(hipStreamSynchronize(s));
-      int rc = g->d_cmds.upload(cmds);
-      if (rc) return rc;
-    }
+    const PgCmd* d_cmds = nullptr;
+    if (!cmds.empty()) { int rc = stage_commands(g, cmds, s, &d_cmds); if (rc) return rc; }
     PgLaunch B;
     memset(&B, 0, sizeof B);
     B.units = g->d_units.d; B.voices = g->d_voices.d; B.fx = g->d_fx.d;
     B.voice_index = g->d_voice_index.d; B.fx_index = g->d_fx_index.d;
-    B.cmds = g->d_cmds.d; B.n_cmds = (int)cmds.size();
+    B.cmds = d_cmds; B.n_cmds = (int)cmds.size(); B.error_word = g->d_error;
     B.n_frames = n; B.pos = now; B.sample_rate = g->sample_rate; B.fast = g->fast;
     B.n_units = 1; B.unit_base = main.unit_slot;
     B.bus = d_bus + done * 2; B.bus_audible = nullptr;
@@ -1423,9 +1624,9 @@ void pg_effect_destroy(pg_effect* e) {
   if (!e) return;
   if (e->initialized) {
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
-    (void)hipFree(e->d_unit); (void)hipFree(e->d_fx); (void)hipFree(e->d_fx_index); (void)hipFree(e->d_cmds); (void)hipFree(e->d_buf);
-    if (e->host.d_mem) (void)hipFree(e->host.d_mem);
+    (void)pg_stream_sync(e->stream);
+    (void)pg_free(e->d_unit); (void)pg_free(e->d_fx); (void)pg_free(e->d_fx_index); (void)pg_free(e->d_cmds); (void)pg_free(e->d_buf);
+    if (e->host.d_mem) (void)pg_free(e->host.d_mem);
     (void)hipStreamDestroy(e->stream);
   }
   delete e;
@@ -1443,14 +1644,14 @@ int pg_effect_initialize(pg_effect* e, uint32_t sample_rate, size_t channel_coun
   memset(&u, 0, sizeof u);
   u.kind = UNIT_EFFECT; u.n_fx = 1; u.fx_off = 0; u.effects_bypassed = 0;
   int32_t zero = 0;
-  HIP_TRY(hipMalloc((void**)&e->d_unit, sizeof u));
-  HIP_TRY(hipMalloc((void**)&e->d_fx, sizeof fx));
-  HIP_TRY(hipMalloc((void**)&e->d_fx_index, 4));
-  HIP_TRY(hipMalloc((void**)&e->d_cmds, sizeof(PgCmd) * 64));
-  HIP_TRY(hipMalloc((void**)&e->d_buf, max_frames * 2 * sizeof(float)));
-  HIP_TRY(hipMemcpy(e->d_unit, &u, sizeof u, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->d_fx, &fx, sizeof fx, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->d_fx_index, &zero, 4, hipMemcpyHostToDevice));
+  HIP_TRY(pg_malloc((void**)&e->d_unit, sizeof u));
+  HIP_TRY(pg_malloc((void**)&e->d_fx, sizeof fx));
+  HIP_TRY(pg_malloc((void**)&e->d_fx_index, 4));
+  HIP_TRY(pg_malloc((void**)&e->d_cmds, sizeof(PgCmd) * 64));
+  HIP_TRY(pg_malloc((void**)&e->d_buf, max_frames * 2 * sizeof(float)));
+  HIP_TRY(pg_memcpy(e->d_unit, &u, sizeof u, hipMemcpyHostToDevice));
+  HIP_TRY(pg_memcpy(e->d_fx, &fx, sizeof fx, hipMemcpyHostToDevice));
+  HIP_TRY(pg_memcpy(e->d_fx_index, &zero, 4, hipMemcpyHostToDevice));
   e->sample_rate = sample_rate; e->max_frames = max_frames; e->initialized = true;
   return PG_OK;
 }
@@ -1469,7 +1670,7 @@ static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t 
   L.bus = e->d_buf;
   HIP_TRY(pg_launch_units(L, e->stream));
   if (n_samples) HIP_TRY(hipMemcpyAsync(host_buf, e->d_buf, n_samples * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(pg_stream_sync(e->stream));
   e->pending.clear();
   return PG_OK;
 }

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <mutex>
+
 #include "pg_dev.h"
 #include "pg_dsp_dev.h"
 #include "pg_fx_serial.h"
@@ -989,18 +991,27 @@ size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
 }
 // The staged pipeline of one round (units flagged `staged`): single_launch = pg_stage_fused_kernel, else three launches
 // (L.stage_buf must then hold n_units rows).
+// The kernels' dynamic-LDS limits are a per-device function attribute: set once for every device the library launches on (graphs of
+// different devices, handles used from different threads).
+static hipError_t pg_ensure_func_attributes() {
+  static std::mutex mtx;
+  static bool done[64] = {false};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mtx);
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  const void* fns[] = {(const void*)pg_stage1_kernel, (const void*)pg_stage2_kernel, (const void*)pg_stage3_kernel, (const void*)pg_unit_kernel,
+                       (const void*)pg_unit_kernel_fast, (const void*)pg_unit_kernel_fast_wide};
+  for (const void* f : fns) if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
+  if (dev >= 0 && dev < 64) done[dev] = true;
+  return hipSuccess;
+}
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)pg_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)pg_stage2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)pg_stage3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
-    attr_set = true;
-  }
+  { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
   if (single_launch) {
     // ev0/ev1 (only passed when exactly one of the two launches happens): start / stop timestamps taken from the dispatch itself —
     // no marker packets in the stream, which cost ~7 us per round with hipEventRecord
@@ -1016,16 +1027,7 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   size_t lds = pg_unit_lds_bytes(L.n_frames);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pg_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)pg_unit_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)pg_unit_kernel_fast_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
   if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else if (L.mode == 1) hipExtLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);

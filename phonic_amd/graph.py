@@ -77,6 +77,13 @@ class Graph(GraphHandle):
         self._check(self._lib.pg_graph_set_staged(self._h, int(mode)))
 
 
+def hip_calls():
+    """Process-wide counters of the library's own HIP calls: dict(alloc, free, sync, blocking_copy) — see pg_debug_hip_calls."""
+    out = (C.c_uint64 * 4)()
+    _capi.load().pg_debug_hip_calls(out)
+    return dict(alloc=out[0], free=out[1], sync=out[2], blocking_copy=out[3])
+
+
 def effect_parameters(kind):
     """`Effect::parameters()` descriptors of an effect kind."""
     lib = _capi.load()

@@ -894,3 +894,169 @@ def test_superblock_launch_is_bit_identical_to_single_blocks():
     assert stats[0][1] == stats[0][0]                 # one block per launch
     assert stats[1][1] > 2 * stats[1][0]              # super-block launches carried most blocks
     assert np.abs(sup[-2 * N:]).max() > 1e-3
+
+
+def test_write_allocates_nothing_and_never_blocks_on_a_callers_stream():
+    """The reference runs its audio callback under assert_no_alloc (src/output/cpal.rs:712-715). Here: all device / pinned allocations
+    happen in the graph-changing calls (grow-by-doubling in add_*), the topology tables travel with asynchronous copies from pinned
+    staging inside the first write after a change, command lists go through a pre-allocated ring — so the library's own HIP call
+    counters (pg_debug_hip_calls) must not move across writes: no allocation, no release, and on a caller's stream no host wait and no
+    blocking copy either — including the FIRST write after add_voice / add_effect and writes that carry parameter automation."""
+    import torch
+    from phonic_amd.graph import Graph, hip_calls
+
+    g = Graph(SR, 2, 1024, 0)
+    ids = []
+    for i in range(5):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_FILTER, params={"cuto": 3000.0})
+        ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i)))
+        g.add_voice(m, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.4, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    stream = torch.cuda.Stream()
+    buf = torch.zeros(8 * 2048, dtype=torch.float32, device="cuda:0")
+    pos = 0
+
+    def write(n_blocks=1):
+        nonlocal pos
+        assert g.write_device(buf.data_ptr(), n_blocks * 2048, pos, stream.cuda_stream) == n_blocks * 2048
+        pos += n_blocks * 1024
+
+    before = hip_calls()
+    write()                                    # first write after construction: topology upload + patch kernel, all asynchronous
+    for _ in range(4):
+        write()
+    g.schedule_param(ids[0], "room", 0.9, pos + 100)      # automation: command ring, generic kernel
+    g.set_voice_volume(0, 0.2, pos + 700)
+    write()
+    write(4)
+    assert hip_calls() == before, (before, hip_calls())
+    # a graph change allocates (in add_voice, not in write) ...
+    m = g.add_mixer()
+    g.add_effect(m, _capi.FX_CHORUS)
+    g.add_voice(m, workloads.tone_buffer(9, 48000, 0.2), 2, 48000, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+    after_change = hip_calls()
+    assert after_change["alloc"] > before["alloc"]
+    # ... and the first write after it again moves no counter
+    write()
+    write()
+    assert hip_calls() == after_change
+    stream.synchronize()
+    assert g.device_errors() == 0
+    host = buf.cpu().numpy()
+    assert np.isfinite(host).all() and np.abs(host[:2048]).max() > 1e-3
+    # the host-buffer variant waits for its result (one stream wait per call) but allocates nothing
+    out = np.zeros(2048, np.float32)
+    c0 = hip_calls()
+    assert g.write(out, pos) == 2048
+    c1 = hip_calls()
+    assert c1["alloc"] == c0["alloc"] and c1["free"] == c0["free"] and c1["blocking_copy"] == c0["blocking_copy"]
+
+
+def test_control_calls_from_another_thread_while_rendering():
+    """EffectHandle::set_parameter / FilePlaybackHandle::set_volume ... push into the mixer's lock-free message queue from any thread
+    while the audio thread renders (src/player/handles/effect.rs:67-95, src/source/mixed.rs:113-194,294-499). Same contract here: a
+    producer thread schedules 100 000 sample-time-tagged events (parameter changes on 8 per-voice Gain / Filter effects, voice volume
+    and panning moves) while this thread pulls blocks; the producer only has to stay ahead of the render position (a watermark the
+    render loop waits for), so every event takes effect at its sample time and the result must equal the oracle fed the same events
+    from one thread. Also: a full queue reports PG_ERR_QUEUE_FULL and loses nothing that was accepted."""
+    import threading
+
+    import phonic_amd
+    from phonic_amd.graph import Graph
+
+    N, blocks, n_units, n_events = 1024, 100, 8, 100_000
+    rng = np.random.default_rng(7)
+    times = np.sort(rng.integers(N, blocks * N, n_events)).astype(np.uint64)
+    kinds = rng.integers(0, 4, n_events)
+    units = rng.integers(0, n_units, n_events)
+    vals = rng.random(n_events).astype(np.float32)
+
+    def build(g):
+        ids = []
+        for i in range(n_units):
+            m = g.add_mixer()
+            ga = g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.8})
+            fi = g.add_effect(m, _capi.FX_FILTER, params={"cuto": 4000.0})
+            v = g.add_voice(m, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.3, panning=workloads.voice_pan(i), has_repeat=1,
+                            repeat=_capi.PG_REPEAT_FOREVER)
+            ids.append((ga, fi, v))
+        return ids
+
+    def send(g, ids, k):
+        ga, fi, v = ids[units[k]]
+        t = int(times[k])
+        if kinds[k] == 0:
+            g.schedule_param(ga, "gain", 0.2 + 0.6 * float(vals[k]), t)
+        elif kinds[k] == 1:
+            g.schedule_param(fi, "cuto", float(vals[k]), t, normalized=True)
+        elif kinds[k] == 2:
+            g.set_voice_volume(v, 0.1 + 0.4 * float(vals[k]), t)
+        else:
+            g.set_voice_panning(v, 2.0 * float(vals[k]) - 1.0, t)
+
+    # oracle: one thread, every block's events sent right before the block
+    gc = oracle.OracleGraph(SR, 2, N)
+    ids_c = build(gc)
+    ref = np.zeros((blocks, 2 * N), np.float32)
+    k = 0
+    for b in range(blocks):
+        while k < n_events and times[k] < (b + 1) * N:
+            send(gc, ids_c, k)
+            k += 1
+        assert gc.write(ref[b], b * N) == 2 * N
+    # GPU: producer thread runs ahead of the render loop
+    g = Graph(SR, 2, N, 0)
+    ids_g = build(g)
+    sent_until = [0]          # every event with sample time < sent_until[0] has been pushed
+    cond = threading.Condition()
+    errors = []
+
+    def producer():
+        try:
+            k = 0
+            for b in range(blocks):
+                while k < n_events and times[k] < (b + 1) * N:
+                    while True:
+                        try:
+                            send(g, ids_g, k)
+                            break
+                        except phonic_amd.PhonicError as e:   # queue full: the renderer has to drain first
+                            if e.code != _capi.PG_ERR_QUEUE_FULL:
+                                raise
+                    k += 1
+                with cond:
+                    sent_until[0] = (b + 1) * N
+                    cond.notify_all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            with cond:
+                sent_until[0] = blocks * N
+                cond.notify_all()
+
+    th = threading.Thread(target=producer)
+    out = np.zeros((blocks, 2 * N), np.float32)
+    th.start()
+    for b in range(blocks):
+        with cond:
+            cond.wait_for(lambda: sent_until[0] >= (b + 1) * N, timeout=120)
+        assert g.write(out[b], b * N) == 2 * N
+    th.join(timeout=120)
+    assert not errors, errors
+    assert g.device_errors() == 0
+    compare(out.reshape(-1), ref.reshape(-1))
+    assert np.abs(out).max() > 1e-3
+    # queue capacity: 65536 records; the 65537th push without a write in between is refused, the next write takes all accepted ones
+    accepted = 0
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        for _ in range(70000):
+            g.set_voice_volume(ids_g[0][2], 0.3, blocks * N + 10)
+            accepted += 1
+    assert ei.value.code == _capi.PG_ERR_QUEUE_FULL and accepted == 65536
+    tail = np.zeros(2 * N, np.float32)
+    assert g.write(tail, blocks * N) == 2 * N                 # 65536 commands on one sample of one unit: still rendered
+    g.set_voice_volume(ids_g[0][2], 0.3, blocks * N + 2000)   # accepted again after the drain
+    for k in range(70000):                                     # more than the command ring holds in one round: the degenerate path
+        if k == 65000:
+            assert g.write(tail, (blocks + 1) * N) == 2 * N
+        g.set_voice_panning(ids_g[1][2], 0.1, (blocks + 2) * N + 5)
+    assert g.write(tail, (blocks + 2) * N) == 2 * N and np.isfinite(tail).all()
