@@ -241,6 +241,42 @@ int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uin
 /* Block until all work of the graph's stream has finished. */
 int pg_graph_synchronize(pg_graph* g);
 
+/* ---- voice-sharded graph: the same main MixedSource spread over several GPUs of one node (SURVEY.md §8b `n_gpus`, §8e) ----------
+ *
+ * The reference's parallel axis is independent sub-mixers rendered by worker threads into private buffers which the caller sums
+ * (SubMixerThreadPool, src/source/mixed/submixer/thread_pool.rs:92-121,350-412; src/source/mixed.rs:522-536). Here the workers are
+ * devices: one handle owns one pg_graph per entry of `devices` (the first is the root). Every sub-mixer of the main mixer — with its
+ * effects, sources and nested sub-mixers — and every main-mixer source is placed on the least loaded shard when it is added (the greedy
+ * placement of WorkerTaskBatcher) and never moves; effects added to mixer 0 form the bus chain on the root. write = one asynchronous
+ * render per shard on its own device and stream, the partial buses copied to the root device (peer copies), summed there in shard order,
+ * then the bus chain. Ids returned here are global (valid for the pg_sharded_* calls only). Threading as for pg_graph: add_* / write from
+ * the owner thread, the control calls from any thread. A device may be listed more than once (several shards on one GPU: how the
+ * single-GPU test-suite exercises this path). bench.py's measured multi-GPU path is one process per GPU with an RCCL reduce instead
+ * (phonic_amd/parallel.py); both sit on the same kernels and per-graph host code. */
+typedef struct pg_sharded_graph pg_sharded_graph;
+pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, const int* devices, int n_devices);
+void pg_sharded_destroy(pg_sharded_graph* s);
+int pg_sharded_shard_count(pg_sharded_graph* s);
+int pg_sharded_set_max_blocks_per_launch(pg_sharded_graph* s, int n_blocks);   /* a write holds at most n_blocks x max_frames frames */
+int pg_sharded_add_mixer(pg_sharded_graph* s);                                  /* Player::add_mixer(None) */
+int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id);          /* nested: lives on its parent's shard */
+int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init);
+int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
+                         const pg_voice_options* opt);
+int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id);
+int pg_sharded_schedule_param(pg_sharded_graph* s, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time);
+int pg_sharded_schedule_reset(pg_sharded_graph* s, int effect_id, uint64_t sample_time);
+int pg_sharded_set_voice_volume(pg_sharded_graph* s, int voice_id, float volume, uint64_t sample_time);
+int pg_sharded_set_voice_panning(pg_sharded_graph* s, int voice_id, float panning, uint64_t sample_time);
+int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time);
+int pg_sharded_stop_all_voices(pg_sharded_graph* s);
+/* Source::write: host buffer (waits for the result) / buffer on the root device (asynchronous on the root shard's stream; at most
+ * max_blocks x max_frames frames per call; pg_sharded_synchronize waits for it). Both return the samples written, 0 when nothing plays. */
+size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames);
+size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames);
+int pg_sharded_synchronize(pg_sharded_graph* s);
+int pg_sharded_device_errors(pg_sharded_graph* s);
+
 /* Introspection used by the harness */
 int pg_graph_voice_count(pg_graph* g);
 int pg_graph_is_voice_playing(pg_graph* g, int voice_id);

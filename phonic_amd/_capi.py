@@ -235,6 +235,22 @@ def load():
     lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
     lib.pg_graph_set_max_blocks_per_launch.restype = C.c_int
     lib.pg_graph_set_max_blocks_per_launch.argtypes = [vp, C.c_int]
+    lib.pg_sharded_create.restype = vp
+    lib.pg_sharded_create.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t, P(C.c_int), C.c_int]
+    lib.pg_sharded_destroy.restype = None
+    lib.pg_sharded_destroy.argtypes = [vp]
+    for name, args in (("shard_count", []), ("set_max_blocks_per_launch", [C.c_int]), ("add_mixer", []), ("add_mixer_to", [C.c_int]),
+                       ("add_effect", [C.c_int, C.c_int, P(EffectInit)]), ("add_voice", [C.c_int, P(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, P(VoiceOptions)]),
+                       ("shard_of_mixer", [C.c_int]), ("schedule_param", [C.c_int, C.c_uint32, C.c_float, C.c_int, C.c_uint64]), ("schedule_reset", [C.c_int, C.c_uint64]),
+                       ("set_voice_volume", [C.c_int, C.c_float, C.c_uint64]), ("set_voice_panning", [C.c_int, C.c_float, C.c_uint64]),
+                       ("stop_voice", [C.c_int, C.c_uint64]), ("stop_all_voices", []), ("synchronize", []), ("device_errors", [])):
+        fn = getattr(lib, "pg_sharded_" + name)
+        fn.restype = C.c_int
+        fn.argtypes = [vp] + args
+    lib.pg_sharded_write.restype = C.c_size_t
+    lib.pg_sharded_write.argtypes = [vp, P(C.c_float), C.c_size_t, C.c_uint64]
+    lib.pg_sharded_write_device.restype = C.c_size_t
+    lib.pg_sharded_write_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64]
     lib.pg_debug_hip_calls.restype = None
     lib.pg_debug_hip_calls.argtypes = [P(C.c_uint64)]
     lib.pg_graph_device_errors.restype = C.c_int

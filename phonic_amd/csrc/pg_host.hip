@@ -1557,10 +1557,10 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
   return total;
 }
 
-int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
+// `bus_audible`: device flag "the summed input is audible" (audible_input of process_effects, mixed.rs:627-655); nullptr = audible
+static int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, hipStream_t s, int* bus_audible) {
   if (g->failed) return PG_ERR_DEVICE;
   (void)hipSetDevice(g->device);
-  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
   if (g->mixers[0].fx.empty()) return PG_OK;
   if (g->last_stream && g->last_stream != s) { HIP_TRY(pg_stream_sync(g->last_stream)); g->cmds_since_sync = 0; }
   g->last_stream = s;
@@ -1591,11 +1591,252 @@ int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uin
     B.cmds = d_cmds; B.n_cmds = (int)cmds.size(); B.error_word = g->d_error;
     B.n_frames = n; B.pos = now; B.sample_rate = g->sample_rate; B.fast = g->fast;
     B.n_units = 1; B.unit_base = main.unit_slot;
-    B.bus = d_bus + done * 2; B.bus_audible = nullptr;
+    B.bus = d_bus + done * 2; B.bus_audible = bus_audible;
     HIP_TRY(pg_launch_units(B, s));
     done += n;
   }
   return PG_OK;
+}
+int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
+  return process_bus_impl(g, d_bus, n_samples, pos_in_frames, hip_stream ? (hipStream_t)hip_stream : g->stream, nullptr);
+}
+
+// ---- voice-sharded graph: one object, n per-device graphs (SURVEY §8b `n_gpus`, §8e) ----------------------------------------------
+// The reference's only parallel axis is independent sub-mixers handed to worker threads, each rendering into a private buffer that the
+// caller sums (SubMixerThreadPool, src/source/mixed/submixer/thread_pool.rs:92-121,350-412; src/source/mixed.rs:522-536). Here the
+// workers are GPUs: every sub-mixer (with everything under it) and every main-mixer source lives on ONE shard — the least loaded one
+// when it is added, the greedy placement of WorkerTaskBatcher — state never migrates, each shard renders a partial master bus on its
+// own device and stream, the partials travel to the root device (peer copies over xGMI) and are summed there in shard order, and the
+// main mixer's effect chain runs once, on the root, behind the sum. One process, one caller thread; the measured multi-GPU path of
+// bench.py (one process per GPU, RCCL reduce) shares everything below the ABI with this one.
+__global__ void pg_shard_sum_kernel(float* __restrict__ bus, const float* __restrict__ own, const float* __restrict__ gathered, int n_peers, size_t peer_stride, int n,
+                                    const int* __restrict__ flags, int n_flags, int* __restrict__ audible_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && audible_out) { int a = 0; for (int k = 0; k < n_flags; ++k) a |= flags[k]; *audible_out = a; }
+  if (i >= n) return;
+  float acc = own[i];
+  for (int p = 0; p < n_peers; ++p) acc = acc + gathered[(size_t)p * peer_stride + i];  // shard order: deterministic
+  bus[i] = acc;
+}
+
+struct pg_sharded_graph {
+  std::vector<pg_graph*> shards;
+  std::vector<int> load;                 // sub-mixers + main-mixer sources placed on each shard
+  uint32_t sample_rate = 48000;
+  size_t max_frames = 0, max_blocks = 1, stride = 0;
+  std::vector<float*> d_partial;         // per shard, on its device: [max_blocks * stride] partial master bus
+  float* d_gather = nullptr;             // root device: the peers' partials [(n - 1)][max_blocks * stride]
+  int* d_flags = nullptr;                // root device: the shards' "audible" flags [n]
+  float* d_bus = nullptr;                // root device: the summed bus of a write with a host buffer
+  float* h_pinned = nullptr;
+  std::vector<hipEvent_t> done;          // per shard: partial (and flag) arrived on the root
+  bool failed = false;
+  // global id -> shard << 24 | local id; append-only, readable from any thread (control calls)
+  pgc::ChunkTable<int32_t> mixer_map, fx_map, voice_map;
+};
+static inline int shard_of(int32_t packed) { return (int)((uint32_t)packed >> 24); }
+static inline int local_of(int32_t packed) { return (int)((uint32_t)packed & 0xffffffu); }
+
+static int sharded_alloc_buffers(pg_sharded_graph* s) {
+  const size_t words = s->stride * s->max_blocks + 4;
+  const size_t n = s->shards.size();
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(hipSetDevice(s->shards[i]->device));
+    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
+    s->d_partial[i] = nullptr;
+    HIP_TRY(pg_malloc((void**)&s->d_partial[i], words * sizeof(float)));
+  }
+  HIP_TRY(hipSetDevice(s->shards[0]->device));
+  if (s->d_gather) (void)pg_free(s->d_gather);
+  if (s->d_bus) (void)pg_free(s->d_bus);
+  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
+  s->d_gather = nullptr; s->d_bus = nullptr; s->h_pinned = nullptr;
+  HIP_TRY(pg_malloc((void**)&s->d_gather, std::max<size_t>(n - 1, 1) * words * sizeof(float)));
+  HIP_TRY(pg_malloc((void**)&s->d_bus, words * sizeof(float)));
+  HIP_TRY(pg_host_malloc((void**)&s->h_pinned, words * sizeof(float), hipHostMallocDefault));
+  return PG_OK;
+}
+
+pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, const int* devices, int n_devices) {
+  if (n_devices < 1 || n_devices > 64 || !devices) { set_error(PG_ERR_PARAMETER, "1..=64 shards"); return nullptr; }
+  std::unique_ptr<pg_sharded_graph> s(new pg_sharded_graph());
+  s->sample_rate = sample_rate; s->max_frames = max_frames; s->stride = 2 * max_frames;
+  for (int i = 0; i < n_devices; ++i) {
+    pg_graph* g = pg_graph_create(sample_rate, channel_count, max_frames, devices[i]);
+    if (!g) { for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
+    g->defer_bus = true;  // the main mixer's chain runs once, behind the sum of all shards
+    s->shards.push_back(g);
+    s->load.push_back(0);
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipEventCreate failed"); for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
+    s->done.push_back(e);
+  }
+  s->d_partial.assign((size_t)n_devices, nullptr);
+  (void)hipSetDevice(devices[0]);
+  if (pg_malloc((void**)&s->d_flags, 64 * sizeof(int)) != hipSuccess || sharded_alloc_buffers(s.get())) { set_error(PG_ERR_DEVICE, "device allocation failed"); return nullptr; }
+  (void)pg_memset(s->d_flags, 0, 64 * sizeof(int));
+  s->mixer_map.append(0);  // global mixer 0 = the main mixer (its chain lives on the root shard)
+  return s.release();
+}
+void pg_sharded_destroy(pg_sharded_graph* s) {
+  if (!s) return;
+  for (size_t i = 0; i < s->shards.size(); ++i) {
+    (void)hipSetDevice(s->shards[i]->device);
+    (void)pg_stream_sync(s->shards[i]->stream);
+    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
+    (void)hipEventDestroy(s->done[i]);
+  }
+  (void)hipSetDevice(s->shards[0]->device);
+  if (s->d_gather) (void)pg_free(s->d_gather);
+  if (s->d_bus) (void)pg_free(s->d_bus);
+  if (s->d_flags) (void)pg_free(s->d_flags);
+  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
+  for (pg_graph* g : s->shards) pg_graph_destroy(g);
+  delete s;
+}
+int pg_sharded_shard_count(pg_sharded_graph* s) { return (int)s->shards.size(); }
+int pg_sharded_set_max_blocks_per_launch(pg_sharded_graph* s, int n_blocks) {
+  for (pg_graph* g : s->shards) { int rc = pg_graph_set_max_blocks_per_launch(g, n_blocks); if (rc) return rc; }
+  s->max_blocks = (size_t)n_blocks;
+  return sharded_alloc_buffers(s);
+}
+static int sharded_least_loaded(const pg_sharded_graph* s) {
+  int best = 0;
+  for (size_t i = 1; i < s->load.size(); ++i) if (s->load[i] < s->load[best]) best = (int)i;
+  return best;
+}
+static bool sharded_mixer(pg_sharded_graph* s, int mixer_id, int32_t& packed) {
+  if (mixer_id < 0 || (size_t)mixer_id >= s->mixer_map.size()) { set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id); return false; }
+  packed = s->mixer_map.get((size_t)mixer_id);
+  return true;
+}
+int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id) {
+  int32_t pk;
+  if (!sharded_mixer(s, parent_mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = parent_mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);  // a nested sub-mixer lives with its parent
+  const int local = pg_graph_add_mixer_to(s->shards[shard], parent_mixer_id == 0 ? 0 : local_of(pk));
+  if (local < 0) return local;
+  if (parent_mixer_id == 0) s->load[shard] += 1;
+  const int id = (int)s->mixer_map.size();
+  if (local > 0xffffff || !s->mixer_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many mixers");
+  return id;
+}
+int pg_sharded_add_mixer(pg_sharded_graph* s) { return pg_sharded_add_mixer_to(s, 0); }
+int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = mixer_id == 0 ? 0 : shard_of(pk);  // main-mixer effects: the bus chain on the root
+  const int local = pg_graph_add_effect(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), kind, init);
+  if (local < 0) return local;
+  const int id = (int)s->fx_map.size();
+  if (local > 0xffffff || !s->fx_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many effects");
+  return id;
+}
+int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate, const pg_voice_options* opt) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);
+  const int local = pg_graph_add_voice(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), pcm, n_frames, src_channels, src_rate, opt);
+  if (local < 0) return local;
+  if (mixer_id == 0) s->load[shard] += 1;
+  const int id = (int)s->voice_map.size();
+  if (local > 0xffffff || !s->voice_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many voices");
+  return id;
+}
+int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  return mixer_id == 0 ? 0 : shard_of(pk);
+}
+// control calls (any thread): routed to the owning shard's message ring
+#define SHARDED_FX(s, effect_id, pk) \
+  if ((effect_id) < 0 || (size_t)(effect_id) >= (s)->fx_map.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", (effect_id)); \
+  const int32_t pk = (s)->fx_map.get((size_t)(effect_id))
+#define SHARDED_VOICE(s, voice_id, pk) \
+  if ((voice_id) < 0 || (size_t)(voice_id) >= (s)->voice_map.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", (voice_id)); \
+  const int32_t pk = (s)->voice_map.get((size_t)(voice_id))
+int pg_sharded_schedule_param(pg_sharded_graph* s, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
+  SHARDED_FX(s, effect_id, pk);
+  return pg_graph_schedule_param(s->shards[shard_of(pk)], local_of(pk), fourcc, value, is_normalized, sample_time);
+}
+int pg_sharded_schedule_reset(pg_sharded_graph* s, int effect_id, uint64_t sample_time) {
+  SHARDED_FX(s, effect_id, pk);
+  return pg_graph_schedule_reset(s->shards[shard_of(pk)], local_of(pk), sample_time);
+}
+int pg_sharded_set_voice_volume(pg_sharded_graph* s, int voice_id, float volume, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_set_voice_volume(s->shards[shard_of(pk)], local_of(pk), volume, sample_time);
+}
+int pg_sharded_set_voice_panning(pg_sharded_graph* s, int voice_id, float panning, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_set_voice_panning(s->shards[shard_of(pk)], local_of(pk), panning, sample_time);
+}
+int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_stop_voice(s->shards[shard_of(pk)], local_of(pk), sample_time);
+}
+int pg_sharded_stop_all_voices(pg_sharded_graph* s) {
+  for (pg_graph* g : s->shards) { int rc = pg_graph_stop_all_voices(g); if (rc) return rc; }
+  return PG_OK;
+}
+
+// Source::write of the sharded main mixer: n asynchronous renders, partials -> root, sum in shard order, bus chain, result in d_out
+// (root device) on the root shard's stream. Returns the samples written, 0 when every shard is empty and the main mixer has no chain.
+static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos) {
+  if (s->failed) return 0;
+  const size_t cap = s->stride * s->max_blocks;
+  if (n_samples > cap || n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "a sharded write holds at most max_blocks x max_frames stereo frames"); return 0; }
+  const size_t n = s->shards.size();
+  pg_graph* root = s->shards[0];
+  bool any = false;
+  for (size_t i = 0; i < n; ++i) {
+    pg_graph* g = s->shards[i];
+    (void)hipSetDevice(g->device);
+    const size_t w = graph_write_impl(g, s->d_partial[i], n_samples, pos, g->stream);
+    if (g->failed) { s->failed = true; return 0; }
+    if (w == 0) { if (hipMemsetAsync(s->d_partial[i], 0, n_samples * sizeof(float), g->stream) != hipSuccess) { s->failed = true; return 0; } }
+    else any = true;
+    if (i > 0) {  // partial bus and the shard's `audible` flag -> the root device; the root's stream waits for their arrival only
+      if (hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4), root->device, s->d_partial[i], g->device, n_samples * sizeof(float), g->stream) != hipSuccess ||
+          hipMemcpyPeerAsync(s->d_flags + i, root->device, g->d_audible, g->device, sizeof(int), g->stream) != hipSuccess ||
+          hipEventRecord(s->done[i], g->stream) != hipSuccess) { s->failed = true; return 0; }
+    }
+  }
+  if (!any && root->mixers[0].fx.empty()) return 0;
+  (void)hipSetDevice(root->device);
+  for (size_t i = 1; i < n; ++i) if (hipStreamWaitEvent(root->stream, s->done[i], 0) != hipSuccess) { s->failed = true; return 0; }
+  if (hipMemcpyAsync(s->d_flags, root->d_audible, sizeof(int), hipMemcpyDeviceToDevice, root->stream) != hipSuccess) { s->failed = true; return 0; }
+  hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_out, s->d_partial[0], s->d_gather, (int)n - 1, cap + 4,
+                     (int)n_samples, s->d_flags, (int)n, root->d_audible);
+  if (hipGetLastError() != hipSuccess) { s->failed = true; return 0; }
+  if (process_bus_impl(root, d_out, n_samples, pos, root->stream, root->d_audible)) { s->failed = true; return 0; }
+  return n_samples;
+}
+size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames) { return sharded_write_impl(s, d_out, n_samples, pos_in_frames); }
+int pg_sharded_synchronize(pg_sharded_graph* s) {
+  for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); HIP_TRY(pg_stream_sync(g->stream)); g->cmds_since_sync = 0; }
+  return PG_OK;
+}
+size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames) {
+  const size_t cap = s->stride * s->max_blocks;
+  size_t off = 0, total = 0;
+  uint64_t pos = pos_in_frames;
+  while (off < n_samples) {
+    const size_t n = std::min(cap, n_samples - off);
+    const size_t w = sharded_write_impl(s, s->d_bus, n, pos);
+    if (w == 0) { if (s->failed || off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
+    pg_graph* root = s->shards[0];
+    (void)hipSetDevice(root->device);
+    if (hipMemcpyAsync(s->h_pinned, s->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, root->stream) != hipSuccess || pg_sharded_synchronize(s) != PG_OK) { s->failed = true; return 0; }
+    memcpy(out + off, s->h_pinned, n * sizeof(float));
+    off += n; pos += n / 2; total += n;
+  }
+  return total;
+}
+int pg_sharded_device_errors(pg_sharded_graph* s) {
+  int e = 0;
+  for (pg_graph* g : s->shards) { const int r = pg_graph_device_errors(g); if (r < 0) return r; e |= r; }
+  return e;
 }
 
 // ---- standalone effect: a one-unit graph whose unit is UNIT_EFFECT -------------------------------------------

@@ -77,6 +77,100 @@ class Graph(GraphHandle):
         self._check(self._lib.pg_graph_set_staged(self._h, int(mode)))
 
 
+class ShardedGraph:
+    """The main mixer spread over several devices behind ONE handle (pg_sharded_*, include/phonic_gpu.h): same calls as `Graph` for
+    building, automation and `write`; sub-mixers and main-mixer sources are placed on the least loaded shard, the main mixer's effects
+    run on the root behind the sum of the shards' partial buses."""
+
+    def __init__(self, devices, sample_rate=48000, channels=2, max_frames=4096):
+        self._lib = _capi.load()
+        self.sample_rate, self.channels, self.max_frames = sample_rate, channels, max_frames
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = self._lib.pg_sharded_create(sample_rate, channels, max_frames, arr, len(devices))
+        if not self._h:
+            raise PhonicError(_capi.PG_ERR_DEVICE, (self._lib.pg_last_error_message() or b"").decode())
+
+    def _check(self, code):
+        if code != 0:
+            raise PhonicError(code, (self._lib.pg_last_error_message() or b"").decode())
+
+    def _id(self, v):
+        if v < 0:
+            raise PhonicError(-v, (self._lib.pg_last_error_message() or b"").decode())
+        return v
+
+    def shard_count(self):
+        return self._lib.pg_sharded_shard_count(self._h)
+
+    def set_max_blocks_per_launch(self, n_blocks):
+        self._check(self._lib.pg_sharded_set_max_blocks_per_launch(self._h, int(n_blocks)))
+
+    def add_mixer(self, parent=None):
+        return self._id(self._lib.pg_sharded_add_mixer_to(self._h, parent or 0))
+
+    def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None):
+        init = _capi.make_init(params, reverb_seeds)
+        return self._id(self._lib.pg_sharded_add_effect(self._h, mixer_id, kind, C.byref(init)))
+
+    def add_voice(self, mixer_id, pcm, src_channels, src_rate, **opts):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        o = _capi.default_voice_options(**opts)
+        return self._id(self._lib.pg_sharded_add_voice(self._h, mixer_id, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.size // src_channels, src_channels, src_rate, C.byref(o)))
+
+    def shard_of_mixer(self, mixer_id):
+        return self._id(self._lib.pg_sharded_shard_of_mixer(self._h, mixer_id))
+
+    def schedule_param(self, effect_id, id4, value, sample_time, normalized=False):
+        self._check(self._lib.pg_sharded_schedule_param(self._h, effect_id, _capi.fourcc(id4), float(value), 1 if normalized else 0, sample_time))
+
+    def schedule_reset(self, effect_id, sample_time):
+        self._check(self._lib.pg_sharded_schedule_reset(self._h, effect_id, sample_time))
+
+    def set_voice_volume(self, voice, volume, sample_time):
+        self._check(self._lib.pg_sharded_set_voice_volume(self._h, voice, float(volume), sample_time))
+
+    def set_voice_panning(self, voice, panning, sample_time):
+        self._check(self._lib.pg_sharded_set_voice_panning(self._h, voice, float(panning), sample_time))
+
+    def stop_voice(self, voice, sample_time):
+        self._check(self._lib.pg_sharded_stop_voice(self._h, voice, sample_time))
+
+    def stop_all_voices(self):
+        self._check(self._lib.pg_sharded_stop_all_voices(self._h))
+
+    def write(self, out, pos_in_frames):
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+        return self._lib.pg_sharded_write(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, pos_in_frames)
+
+    def write_device(self, d_out_ptr, n_samples, pos_in_frames):
+        return self._lib.pg_sharded_write_device(self._h, C.c_void_p(d_out_ptr), n_samples, pos_in_frames)
+
+    def synchronize(self):
+        self._check(self._lib.pg_sharded_synchronize(self._h))
+
+    def device_errors(self):
+        return self._id(self._lib.pg_sharded_device_errors(self._h))
+
+    def render(self, n_blocks, block_frames=1024, start_pos=0):
+        out = np.zeros((n_blocks, block_frames * self.channels), dtype=np.float32)
+        pos = start_pos
+        for b in range(n_blocks):
+            self.write(out[b], pos)
+            pos += block_frames
+        return out.reshape(-1)
+
+    def close(self):
+        if self._h:
+            self._lib.pg_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def hip_calls():
     """Process-wide counters of the library's own HIP calls: dict(alloc, free, sync, blocking_copy) — see pg_debug_hip_calls."""
     out = (C.c_uint64 * 4)()

@@ -1060,3 +1060,67 @@ def test_control_calls_from_another_thread_while_rendering():
             assert g.write(tail, (blocks + 1) * N) == 2 * N
         g.set_voice_panning(ids_g[1][2], 0.1, (blocks + 2) * N + 5)
     assert g.write(tail, (blocks + 2) * N) == 2 * N and np.isfinite(tail).all()
+
+
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_sharded_graph_object_matches_the_single_graph(n_shards):
+    """pg_sharded_*: ONE handle that owns a graph per device and renders the main mixer as n partial buses + a sum on the root + the
+    bus chain (the C-ABI form of the multi-GPU path; with 1-GPU boxes every shard sits on device 0). Same build / automation calls as
+    the plain graph: per-voice chains on sub-mixers (placed on the least loaded shard), plain main-mixer sources, a nested sub-mixer
+    (must land on its parent's shard), a bus chain with a limiter (non-linear: the sum must happen before it), parameter events on a
+    sub-mixer effect, on a bus effect and on voices, a stop, and a super-block write. Checked against the oracle and against the
+    unsharded graph (f32 order of the voice sum differs)."""
+    from phonic_amd.graph import Graph, ShardedGraph
+
+    N, blocks = 1024, 10
+
+    def build(g):
+        ids = {"fx": [], "v": []}
+        for i in range(7):
+            m = g.add_mixer()
+            ids["fx"].append(g.add_effect(m, _capi.FX_FILTER, params={"cuto": 1500.0 + 300 * i}))
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            ids["v"].append(g.add_voice(m, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.3, panning=workloads.voice_pan(i), has_repeat=1,
+                                        repeat=_capi.PG_REPEAT_FOREVER))
+            if i == 2:
+                child = g.add_mixer(m)
+                g.add_effect(child, _capi.FX_CHORUS)
+                g.add_voice(child, workloads.tone_buffer(30, 48000, 0.2), 2, 48000, volume=0.2, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+                ids["nested"] = (m, child)
+        for i in range(4):
+            ids["v"].append(g.add_voice(0, workloads.tone_buffer(10 + i, 48000, 0.2), 2, 48000, volume=0.2, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+        ids["eq"] = g.add_effect(0, _capi.FX_EQ5, params={"gan2": 4.0})
+        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -20.0, "rato": 20.0, "knee": 0.0, "gain": 0.0, "look": 0.02})
+        return ids
+
+    def automate(g, ids, b, pos):
+        if b == 3:
+            g.schedule_param(ids["fx"][1], "cuto", 500.0, pos + 300)
+            g.schedule_param(ids["eq"], "gan4", -9.0, pos + 600)
+            g.set_voice_volume(ids["v"][8], 0.05, pos + 100)
+            g.set_voice_panning(ids["v"][0], 0.9, pos + 900)
+        if b == 6:
+            g.stop_voice(ids["v"][9], pos + 200)
+
+    outs = []
+    for mode in ("sharded", "single", "oracle"):
+        g = ShardedGraph([0] * n_shards, SR, 2, N) if mode == "sharded" else (Graph(SR, 2, N, 0) if mode == "single" else oracle.OracleGraph(SR, 2, N))
+        ids = build(g)
+        if mode == "sharded":
+            assert g.shard_count() == n_shards
+            assert g.shard_of_mixer(ids["nested"][0]) == g.shard_of_mixer(ids["nested"][1])
+            if n_shards == 3:
+                assert len({g.shard_of_mixer(m) for m in range(1, 5)}) == 3     # placement spreads the sub-mixers
+        o = np.zeros((blocks, 2 * N), np.float32)
+        for b in range(blocks):
+            automate(g, ids, b, b * N)
+            assert g.write(o[b], b * N) == 2 * N
+        outs.append(o.reshape(-1))
+        if mode == "sharded":
+            assert g.device_errors() == 0
+            with pytest.raises(Exception):
+                g.schedule_param(9999, "cuto", 100.0, 0)
+    compare(outs[0], outs[2])
+    compare(outs[1], outs[2])
+    assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5
+    assert np.abs(outs[0]).max() > 1e-2
