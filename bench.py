@@ -172,10 +172,10 @@ def main():
     ap.add_argument("--voices", type=int, default=0, help="weak scaling: voices PER GPU (default: the config's count)")
     ap.add_argument("--total-voices", type=int, default=0, help="strong scaling: voices of the whole job (default: c5 8192, else the config's count)")
     ap.add_argument("--block", type=int, default=1024)
-    ap.add_argument("--superblock", type=int, default=16, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
+    ap.add_argument("--superblock", type=int, default=32, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
-    ap.add_argument("--time-every", type=int, default=4, help="hipEvent-time the dominant kernel every n-th launch round (the event pair costs ~8 us of stream time)")
+    ap.add_argument("--time-every", type=int, default=1, help="hipEvent-time the dominant kernel every n-th launch round (the event pair costs ~8 us of stream time: once per super-block by default)")
     ap.add_argument("--reduce-every", type=int, default=0, help="multi-GPU: blocks per RCCL master-bus reduce (default: the super-block; 1 = per block, the real-time setting)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()

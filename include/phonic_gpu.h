@@ -155,6 +155,11 @@ typedef struct pg_voice_options {
   uint64_t start_time;     /* sample time in output frames at which the source starts       */
   float fade_in_seconds;   /* < 0 or 0 = none                                               */
   float fade_out_seconds;  /* default 0.05 (file.rs:106); < 0 = none                        */
+  uint32_t source_rate;    /* output rate the file source itself is created with (PreloadedFileSource::from_shared_buffer(.., sample_rate),
+                              preloaded.rs:71-117); 0 = the graph's rate (what Player passes). When it differs, ConvertedSource puts a cubic
+                              ResampledSource — 512-frame input / output staging, src/source/resampled.rs:44-152 — between the file source
+                              and the channel mapping (src/source/converted.rs:15-45), exactly as for any source whose rate is not the mixer's */
+  uint32_t reserved;
 } pg_voice_options;
 
 void pg_voice_options_default(pg_voice_options* opt);

@@ -152,9 +152,11 @@ int po_graph_add_voice(po_graph* g, int mixer_id, const float* pcm, size_t n_fra
   fo.loop_start = opt->loop_start; fo.loop_end = opt->loop_end;
   fo.fade_in_seconds = opt->fade_in_seconds;
   fo.fade_out_seconds = opt->fade_out_seconds;
-  auto* file = new PreloadedFileSource(fb, fo, g->sample_rate);
+  // PreloadedFileSource::from_shared_buffer(.., sample_rate): Player passes the mixer's rate; pg_voice_options::source_rate asks for another
+  auto* file = new PreloadedFileSource(fb, fo, opt->source_rate ? opt->source_rate : g->sample_rate);
   std::unique_ptr<Source> src(file);
-  // ConvertedSource::new (converted.rs:15-45): file rate == mixer rate already; map channels if needed
+  // ConvertedSource::new (converted.rs:15-45): resample to the mixer's rate first if the source runs at another one, then map channels
+  if (src->sample_rate() != g->sample_rate) src.reset(new ResampledSource(std::move(src), g->sample_rate));
   if (src->channel_count() != g->channels) src.reset(new ChannelMappedSource(std::move(src), g->channels));
   auto* amp = new AmplifiedSource(std::move(src), fo.volume);
   std::unique_ptr<Source> s2(amp);

@@ -49,6 +49,8 @@ class VoiceOptions(C.Structure):
         ("start_time", C.c_uint64),
         ("fade_in_seconds", C.c_float),
         ("fade_out_seconds", C.c_float),
+        ("source_rate", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -92,6 +94,7 @@ def default_voice_options(**kw):
     o.loop_start = o.loop_end = 0
     o.start_time = 0
     o.fade_in_seconds, o.fade_out_seconds = 0.0, 0.05
+    o.source_rate, o.reserved = 0, 0
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)

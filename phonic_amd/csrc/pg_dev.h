@@ -172,6 +172,16 @@ struct PgVoice {
   uint32_t samples_to_next_speed_update;
   int32_t sched_class, sched_rep;  // resampler schedule cache: class of voices sharing a ratio; 1 = this voice publishes the schedule
   int32_t sched_hit, pad_sched;    // device: how the last resampling piece got its schedule: 0 serial replay, 1 schedule cache, 2 time-parallel
+  // ResampledSource around the file source (src/source/resampled.rs:27-98), present when the file source runs at a rate (`out_rate`) other
+  // than the mixer's (pg_voice_options::source_rate): cubic interpolator state per channel + the two 512-frame TempBuffers
+  int32_t outer_on, outer_pending_stop;
+  int32_t outer_init[2];
+  float outer_ratio, pad_outer;
+  float outer_sub_pos[2];
+  float outer_input[2][4];
+  uint32_t in_start, in_end, out_start, out_end;  // TempBuffer ranges (samples)
+  float* stage_in;   // device memory: 512 * channels floats each
+  float* stage_out;
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.

@@ -452,7 +452,7 @@ struct Event {  // MixerEvent (src/source/mixed.rs:47-109) resolved to a device 
   int mixer;  // owning mixer (0 = main)
 };
 
-struct HostVoice { int mixer; int dev_index; uint64_t start_time; void* d_pcm; };
+struct HostVoice { int mixer; int dev_index; uint64_t start_time; void* d_pcm; void* d_stage; bool outer; };
 struct HostMixer {
   int unit_slot = -1;              // sub-mixer unit; for the main mixer: the bus unit
   std::vector<int> voices;         // voice ids in playing order (sorted by start time, insert-before-equal)
@@ -624,6 +624,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     if (!mx.children.empty()) { u.static_defer = 1; u.staged = 0; }  // sums its sub-mixers' rows first: exact serial kernel
+    for (int v : mx.voices) if (g->voices[v].outer) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging: exact serial kernel
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
@@ -655,6 +656,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
     u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
+    u.static_defer = g->voices[v].outer ? 1 : 0;
     u.voice0 = g->voices[v].dev_index;
     vidx.push_back(g->voices[v].dev_index);
     g->order.push_back(slot);
@@ -810,7 +812,7 @@ void pg_graph_destroy(pg_graph* g) {
   (void)hipSetDevice(g->device);
   (void)pg_stream_sync(g->stream);
   if (g->last_stream && g->last_stream != g->stream) (void)pg_stream_sync(g->last_stream);
-  for (auto& v : g->voices) if (v.d_pcm) (void)pg_free(v.d_pcm);
+  for (auto& v : g->voices) { if (v.d_pcm) (void)pg_free(v.d_pcm); if (v.d_stage) (void)pg_free(v.d_stage); }
   for (auto& f : g->fx) if (f->d_mem) (void)pg_free(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
   g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release(); g->d_topo.release();
@@ -993,9 +995,11 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   if (pg_malloc(&d_pcm, n_samples * sizeof(float)) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pg_malloc(pcm) failed"));
   if (pg_memcpy(d_pcm, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -graph_fail(g, set_error(PG_ERR_DEVICE, "pcm upload failed"));
   v.pcm = (const float*)d_pcm;
-  v.n_samples = n_samples; v.channels = src_channels; v.src_rate = src_rate; v.out_rate = g->sample_rate;
+  // the rate the file source is created with: the mixer's, unless the caller asks for a ResampledSource behind it (source_rate)
+  const uint32_t inner_rate = opt->source_rate ? opt->source_rate : g->sample_rate;
+  v.n_samples = n_samples; v.channels = src_channels; v.src_rate = src_rate; v.out_rate = inner_rate;
   // FileSourceImpl::new: resampler file_rate -> (out_rate / speed) as u32  (file/common.rs:78-86); ratio = (in/out as f64) as f32 (cubic.rs:164)
-  uint32_t res_out = (uint32_t)d2u64((double)g->sample_rate / opt->speed);
+  uint32_t res_out = (uint32_t)d2u64((double)inner_rate / opt->speed);
   if (res_out == 0) return -set_error(PG_ERR_PARAMETER, "Invalid resampling ratio");
   v.ratio = (float)((double)src_rate / (double)res_out);
   if (!(v.ratio > 0.0f) || v.ratio > 64.0f) return -set_error(PG_ERR_PARAMETER, "Invalid resampling ratio");
@@ -1013,7 +1017,7 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   v.fader_state = 0; v.fader_current = 1.0f; v.fader_target = 1.0f; v.fader_inertia = 1.0f;
   if (opt->fade_in_seconds > 0.0f) {
     v.fader_state = 1; v.fader_current = 0.0f; v.fader_target = 1.0f;
-    float samples_duration = (float)g->sample_rate * opt->fade_in_seconds / 4.605f;
+    float samples_duration = (float)inner_rate * opt->fade_in_seconds / 4.605f;
     v.fader_inertia = 1.0f - std::exp(-1.0f / samples_duration);
   }
   v.fade_out_seconds = opt->fade_out_seconds;
@@ -1038,11 +1042,23 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
     }
     v.sched_class = it->second;
   }
+  // ConvertedSource::new (converted.rs:15-45): a source whose rate is not the mixer's gets ResampledSource::new(source, mixer rate, Default)
+  // = a cubic resampler inner rate -> mixer rate (speed 1.0, resampled.rs:44-98) with two TempBuffers of 512 frames
+  void* d_stage = nullptr;
+  if (inner_rate != g->sample_rate) {
+    v.outer_on = 1;
+    v.outer_ratio = (float)((double)inner_rate / (double)g->sample_rate);
+    const size_t stage_floats = 2 * 512 * (size_t)src_channels;
+    if (pg_malloc(&d_stage, stage_floats * sizeof(float)) != hipSuccess || pg_memset(d_stage, 0, stage_floats * sizeof(float)) != hipSuccess)
+      return -graph_fail(g, set_error(PG_ERR_DEVICE, "hipMalloc(staging) failed"));
+    v.stage_in = (float*)d_stage; v.stage_out = v.stage_in + 512 * src_channels;
+    v.sched_class = -1;  // (rendered serially on the generic kernel: no schedule cache)
+  }
   int dev_index = -1;
   int rc = g->d_voices.push(v, &dev_index);
   if (rc) return -graph_fail(g, rc);
   int id = (int)g->voices.size();
-  g->voices.push_back(HostVoice{mixer_id, dev_index, opt->start_time, d_pcm});
+  g->voices.push_back(HostVoice{mixer_id, dev_index, opt->start_time, d_pcm, d_stage, inner_rate != g->sample_rate});
   g->source_unit_of_voice.push_back(-1);
   // AddSource: sort by start time, insert BEFORE equal start times (mixed.rs:324-329)
   HostMixer& mx = g->mixers[mixer_id];

@@ -462,13 +462,13 @@ DEVO void voice_seek(PgVoice* v, double seconds) {
   for (int c = 0; c < 2; ++c) { for (int k = 0; k < 4; ++k) v->input[c][k] = 0.0f; v->sub_pos[c] = 0.0f; v->initialized[c] = 0; }  // resampler.reset()
 }
 
-// PreloadedFileSource::write (preloaded.rs:396-475) + ChannelMappedSource::write (mapped.rs:61-99) +
-// AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
-// Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
+// PreloadedFileSource::write (preloaded.rs:396-475): `frames` frames of the FILE's channel layout into `out` (LDS or global memory),
+// VolumeFader applied, `finished` kept. Returns frames written. `post_on` (out): the fader / gain / pan of a steady stereo voice were
+// fused into the resampler's output loop (and, with `acc`, added straight into the mixer's block): nothing is left to do for the caller.
 // GLIDE = false: the kernel variant never sees a gliding voice (the fast kernel defers such units), so the loop is left out.
 template <bool GLIDE>
-DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
-  *added = 0;
+DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, bool allow_post, int* post_on) {
+  *post_on = 0;
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
   // process_messages: Stop (preloaded.rs:195-208)
@@ -486,7 +486,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   __syncthreads();
   if (v->finished) return 0;
   SrcPost P;
-  P.on = (C == 2 && v->fader_state != 1 && !sm_need_ramp(v->volume) && !sm_need_ramp(v->panning)) ? 1 : 0;
+  P.on = (allow_post && C == 2 && v->fader_state != 1 && !sm_need_ramp(v->volume) && !sm_need_ramp(v->panning)) ? 1 : 0;
   P.fs = v->fader_target; P.use_f = P.fs != 1.0f;
   P.gain = v->volume.target; P.use_g = fabsf(1.0f - P.gain) > 0.000001f;
   P.use_p = fabsf(v->panning.target) > 0.000001f; P.pl = 1.0f; P.pr = 1.0f;
@@ -516,30 +516,22 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
     if (tid == 0) v->samples_to_next_speed_update = 0;
     wf = src_write_buffer(v, out, frames, S, P, P.on ? acc : nullptr);  // frames of the file layout
   }
-  *added = P.on && acc ? 1 : 0;
-  int total = wf * C;
-  if (P.on) {  // fader / gain / pan were applied in the resampler's output loop; only the end-of-block bookkeeping is left
-    __syncthreads();
-    if (tid == 0) {  // preloaded.rs:465-472
-      bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;
-      if (v->pos_eof || fade_out_completed) v->finished = 1;
-    }
-    __syncthreads();
-    return total;
-  }
-  // VolumeFader::process  fader.rs:103-122
-  if (v->fader_state != 1) {
-    float tv = v->fader_target;
-    if (tv != 1.0f) for (int i = tid; i < total; i += nt) out[i] = out[i] * tv;
-  } else {
-    if (tid == 0) {
-      float cur = v->fader_current, tgt = v->fader_target, inertia = v->fader_inertia;
-      for (int f = 0; f < wf; ++f) {
-        cur += (tgt - cur) * inertia;
-        for (int c = 0; c < C; ++c) out[f * C + c] *= cur;
+  *post_on = P.on;
+  const int total = wf * C;
+  if (!P.on) {  // VolumeFader::process  fader.rs:103-122 (a steady voice had it applied in the resampler's output loop)
+    if (v->fader_state != 1) {
+      float tv = v->fader_target;
+      if (tv != 1.0f) for (int i = tid; i < total; i += nt) out[i] = out[i] * tv;
+    } else {
+      if (tid == 0) {
+        float cur = v->fader_current, tgt = v->fader_target, inertia = v->fader_inertia;
+        for (int f = 0; f < wf; ++f) {
+          cur += (tgt - cur) * inertia;
+          for (int c = 0; c < C; ++c) out[f * C + c] *= cur;
+        }
+        v->fader_current = cur;
+        if (fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
       }
-      v->fader_current = cur;
-      if (fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
     }
   }
   __syncthreads();
@@ -547,6 +539,125 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
     bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;
     if (v->pos_eof || fade_out_completed) v->finished = 1;
   }
+  __syncthreads();
+  return wf;
+}
+
+// CubicInterpolator::process for ONE channel of interleaved staging buffers (cubic.rs:36-114): the exact serial recurrence, one lane.
+DEVO void outer_cubic_channel(PgVoice* v, int ch, int C, const float* in, int in_samples, float* out, int out_samples, int* consumed_samples, int* produced_samples) {
+  const int num_in = in_samples / C, num_out = out_samples / C;
+  int num_consumed = 0, num_produced = 0;
+  const float ratio = v->outer_ratio;
+  float i0 = v->outer_input[ch][0], i1 = v->outer_input[ch][1], i2 = v->outer_input[ch][2], i3 = v->outer_input[ch][3];
+  float sub_pos = v->outer_sub_pos[ch];
+  int initialized = v->outer_init[ch];
+#define OUTER_PUSH(x) do { i3 = i2; i2 = i1; i1 = i0; i0 = (x); } while (0)
+  if (!initialized && num_in >= 3) {  // cubic.rs:61-69
+    initialized = 1;
+    for (int f = 0; f < 3; ++f) { OUTER_PUSH(in[f * C + ch]); num_consumed += 1; }
+  }
+  if (ratio < 1.0f) {  // cubic.rs:72-90
+    while (num_produced < num_out) {
+      if (sub_pos >= 1.0f) {
+        if (num_consumed >= num_in) break;
+        OUTER_PUSH(in[num_consumed * C + ch]);
+        num_consumed += 1;
+        sub_pos -= 1.0f;
+      }
+      out[num_produced * C + ch] = cubic_interp(i3, i2, i1, i0, sub_pos);
+      num_produced += 1;
+      sub_pos += ratio;
+    }
+  } else {  // cubic.rs:92-111
+    bool brk = false;
+    while (num_produced < num_out && !brk) {
+      while (sub_pos < ratio) {
+        if (num_consumed >= num_in) { brk = true; break; }
+        OUTER_PUSH(in[num_consumed * C + ch]);
+        num_consumed += 1;
+        sub_pos += 1.0f;
+      }
+      if (brk) break;
+      sub_pos -= ratio;
+      out[num_produced * C + ch] = cubic_interp(i3, i2, i1, i0, 1.0f - sub_pos);
+      num_produced += 1;
+    }
+  }
+#undef OUTER_PUSH
+  v->outer_input[ch][0] = i0; v->outer_input[ch][1] = i1; v->outer_input[ch][2] = i2; v->outer_input[ch][3] = i3;
+  v->outer_sub_pos[ch] = sub_pos; v->outer_init[ch] = initialized;
+  *consumed_samples = num_consumed * C; *produced_samples = num_produced * C;
+}
+
+// ResampledSource::write (src/source/resampled.rs:101-152) around the file source: the voice's PreloadedFileSource runs at
+// `out_rate` != the mixer's rate (pg_voice_options::source_rate), ConvertedSource puts a cubic ResampledSource behind it
+// (converted.rs:15-45). Two TempBuffers of 512 frames (buffer.rs:499-610) in device memory, ranges in samples; the input range is NOT
+// shrunk to what the source delivered (only resamplers with a required input size pad, :120-127), so an exhausted source leaves a
+// stale tail that is resampled like the reference does. `frames` frames of the file layout into `out`; returns frames written.
+DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S) {
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int C = (int)v->channels;
+  const int cap = 512 * C;  // DEFAULT_CHUNK_SIZE * channel_count
+  const int out_len = frames * C;
+  int total_written = 0;
+  __syncthreads();
+  if (tid == 0 && pending_stop) v->outer_pending_stop = 1;  // FilePlaybackMessage::Stop waits in the file source's queue for its next write
+  __syncthreads();
+  while (total_written < out_len) {
+    if (v->out_start >= v->out_end) {  // output_buffer.is_empty()
+      if (v->in_start >= v->in_end) {  // input_buffer.is_empty(): fetch new input from the source
+        const int stop = v->outer_pending_stop;
+        __syncthreads();
+        if (tid == 0) { v->in_start = 0; v->in_end = (uint32_t)cap; v->outer_pending_stop = 0; }
+        __syncthreads();
+        int post_on;
+        (void)file_source_write<true>(v, v->stage_in, 512, stop, S, nullptr, false, &post_on);
+        __threadfence_block();
+        __syncthreads();
+      }
+      // resampler.process(input_buffer.get(), output_buffer.get_mut()): channels are independent recurrences, one lane each;
+      // (consumed, written) of the LAST channel count (cubic.rs:179-186)
+      if (tid < C) {
+        int consumed, produced;
+        outer_cubic_channel(v, tid, C, v->stage_in + v->in_start, (int)(v->in_end - v->in_start), v->stage_out, cap, &consumed, &produced);
+        if (tid == C - 1) { S.ctl[0] = consumed; S.ctl[1] = produced; }
+      }
+      __threadfence_block();
+      __syncthreads();
+      const int consumed = S.ctl[0], produced = S.ctl[1];
+      __syncthreads();
+      if (tid == 0) { v->in_start += (uint32_t)consumed; v->out_start = 0; v->out_end = (uint32_t)produced; }
+      __syncthreads();
+      if (v->finished && produced == 0) break;  // source and resampler produced no more output
+    }
+    const int avail = (int)(v->out_end - v->out_start);
+    const int n = out_len - total_written < avail ? out_len - total_written : avail;
+    for (int i = tid; i < n; i += nt) out[total_written + i] = v->stage_out[v->out_start + i];
+    __syncthreads();
+    if (tid == 0) v->out_start += (uint32_t)n;
+    __syncthreads();
+    total_written += n;
+  }
+  return total_written / C;
+}
+
+// PreloadedFileSource::write [+ ResampledSource::write] + ChannelMappedSource::write (mapped.rs:61-99) +
+// AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
+// Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
+template <bool GLIDE>
+DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
+  *added = 0;
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int C = (int)v->channels;
+  int wf;
+  if (GLIDE && v->outer_on) {  // (units holding such a voice always render on the generic kernel)
+    wf = resampled_source_write(v, out, frames, pending_stop, S);
+  } else {
+    int post_on;
+    wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on);
+    if (post_on) { *added = acc ? 1 : 0; return wf * C; }
+  }
+  __syncthreads();
   // ChannelMappedSource: mono -> stereo (buffer.rs:209-217)
   if (C == 1) {
     // in-place expansion runs back to front, one tile of blockDim.x frames at a time, staged through registers
@@ -637,7 +748,9 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     __syncthreads();
     total_written += written;
     produced_output |= written > 0;
-    if (lv->finished) {  // is_transient && is_exhausted
+    // is_transient && is_exhausted (ResampledSource: the source is exhausted AND both staging buffers are empty, resampled.rs:162-164)
+    const bool exhausted = lv->outer_on ? (lv->finished && lv->in_start >= lv->in_end && lv->out_start >= lv->out_end) : lv->finished != 0;
+    if (exhausted) {
       if (tid == 0) lv->active = 0;
       break;
     } else if (written == 0) break;

@@ -1124,3 +1124,49 @@ def test_sharded_graph_object_matches_the_single_graph(n_shards):
     compare(outs[1], outs[2])
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5
     assert np.abs(outs[0]).max() > 1e-2
+
+
+@pytest.mark.parametrize("file_rate,source_rate,channels", [(44100, 32000, 2), (48000, 96000, 2), (22050, 22050, 1), (44100, 44100, 2)])
+def test_resampled_source_behind_the_file_source(file_rate, source_rate, channels):
+    """SURVEY §8 row a4: ResampledSource::write + TempBuffer (src/source/resampled.rs:101-152, src/utils/buffer.rs:499-610). A file source
+    created with an output rate other than the mixer's (pg_voice_options::source_rate) gets ConvertedSource's cubic ResampledSource
+    behind it (converted.rs:15-45): 512-frame input and output staging, ranges carried across write calls, (consumed, produced) of the
+    last channel, the ratio < 1 and >= 1 branches (96 kHz -> 48 kHz), mono sources mapped AFTER the resampler. Ragged block sizes move
+    the staging ranges through every alignment; a looping voice on the main mixer is compared bit for bit, a one-shot voice into a
+    sub-mixer with a Filter (the reference keeps resampling the stale tail of its input buffer once the source has ended) within tolerance."""
+    sizes = [1, 7, 511, 512, 513, 1024, 100, 1023, 2, 640, 1024, 333] * 2
+
+    def render(g):
+        g.add_voice(0, workloads.tone_buffer(3, file_rate, 0.11, channels=channels), channels, file_rate, volume=1.0, panning=0.0, has_repeat=1,
+                    repeat=_capi.PG_REPEAT_FOREVER, source_rate=source_rate)
+        chunks, pos = [], 0
+        for n in sizes:
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        return np.concatenate(chunks)
+
+    gg, gc = graphs(1024)
+    a, b = render(gg), render(gc)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 1e-2
+
+    def render2(g):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_FILTER, params={"cuto": 3000.0})
+        g.add_voice(m, workloads.tone_buffer(5, file_rate, 0.09, channels=channels), channels, file_rate, volume=0.7, panning=-0.3, source_rate=source_rate,
+                    fade_in_seconds=0.01, speed=1.25)
+        g.add_voice(m, workloads.tone_buffer(6, 48000, 0.3), 2, 48000, volume=0.2, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        chunks, pos = [], 0
+        for n in sizes:
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        return np.concatenate(chunks)
+
+    gg, gc = graphs(1024)
+    a, b = render2(gg), render2(gc)
+    compare(a, b, 1e-6, 1e-5)
+    assert gg.device_errors() == 0
