@@ -132,6 +132,12 @@ int pg_effect_set_parameter(pg_effect* fx, uint32_t fourcc, float value, int is_
 /* Effect::process_message(Reset) (ReverbEffectMessage::Reset etc., src/effect/reverb.rs:24-27) */
 int pg_effect_message_reset(pg_effect* fx);
 void pg_effect_destroy(pg_effect* fx);
+/* Test hook (index streams are compared separately from sample values). With out == NULL the effect (re)arms a log of
+ * `words` slots, all -1; the following process calls record the floor()-derived ring index of every delay-line read their time-parallel
+ * path takes — Reverb: slot ((frame * 8 + line) * 2 + channel) = read_1 of ReverbDelayLine::get (src/effect/reverb.rs:563-570); Delay and
+ * Chorus: slot (frame * 2 + channel) = read_idx1 of InterpolatedDelayLine::process (src/utils/dsp/delay.rs:120-133); frame counts from the
+ * start of each process call. With out != NULL the log is copied out. */
+int pg_effect_debug_index_log(pg_effect* fx, int32_t* out, size_t words);
 
 /* ---- batched mixer graph: `MixedSource` as a `Source` (src/source/mixed.rs, src/source.rs:80-110)
  *

@@ -314,6 +314,16 @@ int po_graphs_render_parallel(po_graph** graphs, int n_graphs, int threads, floa
   return PG_OK;
 }
 
+// index-stream log (test hook): arm, run effects on this thread, collect
+static thread_local std::vector<int32_t> g_index_log_storage;
+void po_index_log_begin(void) { g_index_log_storage.clear(); index_log() = &g_index_log_storage; }
+size_t po_index_log_end(int32_t* out, size_t cap) {
+  index_log() = nullptr;
+  size_t n = g_index_log_storage.size();
+  for (size_t i = 0; i < n && i < cap; ++i) out[i] = g_index_log_storage[i];
+  return n;
+}
+
 #ifndef PO_BUILD_FLAGS
 #define PO_BUILD_FLAGS "unknown"
 #endif

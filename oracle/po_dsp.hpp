@@ -185,6 +185,7 @@ struct InterpolatedDelayLine {  // :79-156
     int64_t index2 = index1 + 1;
     size_t read_idx1 = ((size_t)index1) & buffer_mask;
     size_t read_idx2 = ((size_t)index2) & buffer_mask;
+    log_index(read_idx1);
     double f1[CH], f2[CH];
     for (int c = 0; c < CH; ++c) { f1[c] = buffer[read_idx1 * CH + c]; f2[c] = buffer[read_idx2 * CH + c]; }
     for (int c = 0; c < CH; ++c) output[c] = (float)(f1[c] + (f2[c] - f1[c]) * fraction);

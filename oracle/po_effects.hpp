@@ -513,6 +513,7 @@ struct ReverbDelayLine {  // :518-615 (CHANNELS = 2)
       if (read_1 > delay) read_1 -= delay + 1;
       size_t read_2 = w_int + 1;
       if (read_2 > delay) read_2 -= delay + 1;
+      log_index(read_1);
       double val1 = buffer[read_1 * 2 + ch];
       double val2 = buffer[read_2 * 2 + ch];
       double interpol = val1 * (1.0 - w_frac) + val2 * w_frac;

@@ -95,6 +95,11 @@ inline void remap_buffer_channels(const float* in, size_t in_ch, float* out, siz
 }
 
 // src/utils/buffer.rs:499-610
+// Test hook: the floor()-derived ring indices of the delay-line reads, in call order, while a log is armed
+// (po_index_log_begin / po_index_log_end): ReverbDelayLine::get logs read_1 per channel, InterpolatedDelayLine::process logs read_idx1.
+inline std::vector<int32_t>*& index_log() { static thread_local std::vector<int32_t>* log = nullptr; return log; }
+inline void log_index(size_t v) { if (index_log()) index_log()->push_back((int32_t)v); }
+
 struct TempBuffer {
   std::vector<float> buffer;
   size_t start = 0, end = 0;

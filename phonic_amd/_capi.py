@@ -204,6 +204,8 @@ def load():
     lib.pg_device_count.restype = C.c_int
     lib.pg_effect_create.restype = vp
     lib.pg_effect_create.argtypes = [C.c_int, P(EffectInit), C.c_int]
+    lib.pg_effect_debug_index_log.restype = C.c_int
+    lib.pg_effect_debug_index_log.argtypes = [vp, P(C.c_int32), C.c_size_t]
     lib.pg_effect_process_started.restype = C.c_int
     lib.pg_effect_process_started.argtypes = [vp]
     lib.pg_effect_process_stopped.restype = C.c_int

@@ -227,6 +227,7 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const long long index1 = (long long)read_pos_floor;
       const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
       const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+      if (fc.idx_log) fc.idx_log[(done + nn) * 2 + ch] = (int32_t)i1;  // test hook: read_idx1 of InterpolatedDelayLine::process (dsp/delay.rs:120-133)
       const double v1 = line[i1], v2 = line[i2];
       buf[REV_IDX(nn, ch)] = (double)(float)(v1 + (v2 - v1) * fraction);
     }

@@ -296,6 +296,7 @@ struct PgLaunch {
   int32_t pad_chunks;
   uint64_t chunk_stride;  // floats between the per-unit output tables of consecutive blocks
   int32_t* error_word;    // device word of sticky consistency flags (PG_DEVERR_*), nullptr: not collected
+  int32_t* index_log;     // test hook (generic kernel only, see FastCtx::idx_log): read indices of the time-parallel delay-line paths
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
 enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take

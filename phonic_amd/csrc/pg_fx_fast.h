@@ -16,6 +16,8 @@ struct FastCtx {
   float* red;        // LDS: 16 floats for reductions
   unsigned long long* diag;
   int32_t* err;      // device word of sticky consistency flags (PgLaunch::error_word), may be nullptr
+  int32_t* idx_log;  // test hook (PgLaunch::index_log): the floor()-derived read indices of the delay lines, one slot per (frame[, line], channel)
+                     // of the current process call; nullptr (a compile-time constant in the hot kernels: the stores fold away) = not collected
 };
 
 constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets

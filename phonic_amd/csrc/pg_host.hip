@@ -1868,6 +1868,8 @@ struct pg_effect {
   int32_t* d_fx_index = nullptr;
   PgCmd* d_cmds = nullptr;
   float* d_buf = nullptr;
+  int32_t* d_idx_log = nullptr;  // test hook (pg_effect_debug_index_log)
+  size_t idx_log_words = 0;
   std::vector<PgCmd> pending;
 };
 
@@ -1884,6 +1886,7 @@ void pg_effect_destroy(pg_effect* e) {
     (void)pg_stream_sync(e->stream);
     (void)pg_free(e->d_unit); (void)pg_free(e->d_fx); (void)pg_free(e->d_fx_index); (void)pg_free(e->d_cmds); (void)pg_free(e->d_buf);
     if (e->host.d_mem) (void)pg_free(e->host.d_mem);
+    if (e->d_idx_log) (void)pg_free(e->d_idx_log);
     (void)hipStreamDestroy(e->stream);
   }
   delete e;
@@ -1912,6 +1915,27 @@ int pg_effect_initialize(pg_effect* e, uint32_t sample_rate, size_t channel_coun
   e->sample_rate = sample_rate; e->max_frames = max_frames; e->initialized = true;
   return PG_OK;
 }
+// Test hook: collect the floor()-derived read indices of the effect's delay lines during the following process calls (time-parallel
+// paths of Reverb: ((frame * 8 + line) * 2 + channel) -> read_1 of ReverbDelayLine::get; Delay / Chorus: (frame * 2 + channel) ->
+// read_idx1 of InterpolatedDelayLine::process), `words` slots, -1 = not written. out == nullptr: (re)arm the log; else copy it out.
+int pg_effect_debug_index_log(pg_effect* e, int32_t* out, size_t words) {
+  if (!e->initialized) return set_error(PG_ERR_STATE, "effect is not initialized");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(pg_stream_sync(e->stream));
+  if (!out) {
+    if (words > e->idx_log_words) {
+      if (e->d_idx_log) (void)pg_free(e->d_idx_log);
+      e->d_idx_log = nullptr;
+      HIP_TRY(pg_malloc((void**)&e->d_idx_log, words * sizeof(int32_t)));
+      e->idx_log_words = words;
+    }
+    if (e->d_idx_log) HIP_TRY(pg_memset(e->d_idx_log, 0xff, e->idx_log_words * sizeof(int32_t)));
+    return PG_OK;
+  }
+  if (!e->d_idx_log || words > e->idx_log_words) return set_error(PG_ERR_PARAMETER, "index log is not armed for %zu words", words);
+  HIP_TRY(pg_memcpy(out, e->d_idx_log, words * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return PG_OK;
+}
 int pg_effect_process_started(pg_effect*) { return PG_OK; }  // no-ops for all stock effects (src/effect.rs:127-139)
 int pg_effect_process_stopped(pg_effect*) { return PG_OK; }
 
@@ -1925,6 +1949,7 @@ static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t 
   L.cmds = e->d_cmds; L.n_cmds = (int)e->pending.size();
   L.n_units = 1; L.unit_base = 0; L.n_frames = (uint32_t)(n_samples / 2); L.pos = pos; L.sample_rate = e->sample_rate; L.fast = 1;
   L.bus = e->d_buf;
+  L.index_log = e->d_idx_log;
   HIP_TRY(pg_launch_units(L, e->stream));
   if (n_samples) HIP_TRY(hipMemcpyAsync(host_buf, e->d_buf, n_samples * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(pg_stream_sync(e->stream));

@@ -327,6 +327,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   S.sched_rd = nullptr;
   FastCtx fc;
   fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
+  fc.idx_log = FAST_ONLY ? nullptr : L.index_log;  // (a constant in the fast kernels: the logging stores are compiled out)
   if (L.mode != 2) PG_STAMP(L.diag, 0);
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
@@ -610,7 +611,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   S.diag = L.diag;
   S.sched_rd = nullptr;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = m0.arena; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
+  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = m0.arena; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word; fc.idx_log = nullptr;
   PG_STAMP(L.diag, 0);
   // deferral decision: identical to the fused fast kernel
   if (tid == 0) {

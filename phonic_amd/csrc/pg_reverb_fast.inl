@@ -116,7 +116,7 @@ DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
 
 // one ReverbDelayLine::get for one channel at ring count `cnt` and vibrato phase `ph`  (reverb.rs:554-586)
 // `sn` = sin(vib_phase)
-DEVO double rev_get(const double* buf_generic, uint32_t cnt, uint32_t delay, int ch, double sn, double blend) {
+DEVO double rev_get(const double* buf_generic, uint32_t cnt, uint32_t delay, int ch, double sn, double blend, int32_t* idx_out = nullptr) {
   const gdouble* buf = (const gdouble*)buf_generic;
   double offset = (sn + 1.0) * 7.0;
   double working = (double)cnt + offset;
@@ -127,6 +127,7 @@ DEVO double rev_get(const double* buf_generic, uint32_t cnt, uint32_t delay, int
   if (read_1 > delay) read_1 -= delay + 1;
   uint32_t read_2 = w_int + 1;
   if (read_2 > delay) read_2 -= delay + 1;
+  if (idx_out) *idx_out = (int32_t)read_1;
   double val1 = buf[read_1 * 2 + ch];
   double val2 = buf[read_2 * 2 + ch];
   double interpol = val1 * (1.0 - w_frac) + val2 * w_frac;
@@ -346,7 +347,9 @@ DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const 
 }
 
 // ---- mid: allpasses + vibrato lines ----
-DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag) {
+// idx_log (test hook, nullptr in the kernels that matter for speed): slot ((frame * 8 + line) * 2 + channel) receives `read_1` of that
+// frame's ReverbDelayLine::get (reverb.rs:563-570) — the index stream SURVEY §8c asks to be compared separately from the samples.
+DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag, int32_t* idx_log = nullptr) {
   const int tid = pg_tid(), nt = blockDim.x;
   RevRec* rec = m.rec; double* gl = m.gl; RevDesc* desc = m.desc; double* anch = m.anch; double* vtab = m.vtab;
   const double blend = b.blend, regen = b.regen, wet = b.wet;
@@ -443,6 +446,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
             const double w_floor = floor(working);
             tfr[i] = (uint32_t)((working - w_floor) * 4294967296.0);
             const uint32_t w_int = (uint32_t)w_floor;                 // < count + 15 <= delay + 15 < 2 * (delay + 1)
+            if (idx_log) idx_log[((done + n - 1) * 8 + i) * 2 + ch] = (int32_t)ring_wrap(w_int, ld.m);  // (the get of frame n - 1)
             tv1[i] = *ring_ptr(ld, ring_wrap(w_int, ld.m), ch);       // `if read > delay { read -= delay + 1 }`
             tv2[i] = *ring_ptr(ld, ring_wrap(w_int + 1, ld.m), ch);
           }
@@ -507,7 +511,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
       const double ph = gl[tid];  // exact phase after the chunk's last step (anchor slot 8)
       const double sn = anch[(8 * 16 + tid) * 2];
       r.line[i].vib_phase[ch] = ph;
-      gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sn, blend);
+      gl[tid] = rev_get(ld.buf, rev_at(ld, T), ld.delay, ch, sn, blend, idx_log ? idx_log + ((done + T - 1) * 8 + i) * 2 + ch : nullptr);
     }
     __syncthreads();
     if (tid < 2) {
@@ -574,7 +578,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     const int T = frames - done < REV_T_CAP ? frames - done : REV_T_CAP;
     float* s0 = sig + 2 * done;
     rev_front(r, s0, T, m, b, fc.diag);
-    rev_mid(r, T, m, b, fc.ctl, fc.diag);
+    rev_mid(r, T, m, b, fc.ctl, fc.diag, fc.idx_log ? fc.idx_log + (size_t)done * 16 : nullptr);
     rev_tail(r, s0, T, m, b, fc.diag);
   }
   return true;

@@ -54,6 +54,10 @@ def lib():
         l.po_interp_delay_run.argtypes = [sz, f32, f32, P(f32), sz]
         l.po_effect_reverb_state.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
         l.po_graphs_render_parallel.argtypes = [P(C.c_void_p), C.c_int, C.c_int, P(f32), sz, sz, C.c_uint64]
+        l.po_index_log_begin.argtypes = []
+        l.po_index_log_begin.restype = None
+        l.po_index_log_end.argtypes = [P(C.c_int32), sz]
+        l.po_index_log_end.restype = sz
         _LIB = l
     return _LIB
 

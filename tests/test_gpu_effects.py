@@ -245,3 +245,58 @@ def test_compressor_time_parallel_path(params):
     check(a, b)
     a, b, _, _ = run_pair(_capi.FX_COMPRESSOR, params, None, blocks=9, frames=700, signal="noise")
     check(a, b)
+
+
+INDEX_CASES = [
+    ("reverb_default", _capi.FX_REVERB, None, workloads.reverb_seeds(3), 16),
+    ("reverb_big_room", _capi.FX_REVERB, {"room": 1.0, "wet ": 0.5}, workloads.reverb_seeds(5), 16),
+    ("reverb_small_room", _capi.FX_REVERB, {"room": 0.0, "wet ": 1.0}, workloads.reverb_seeds(4), 16),
+    ("delay_lfo_time", _capi.FX_DELAY, {"dlay": 10.0, "lfdt": 0.1, "ldfb": 0.3, "lfor": 5.0, "lfos": 1}, None, 2),
+    ("delay_short", _capi.FX_DELAY, {"mode": 1, "dlay": 3.5, "fdbk": 0.6}, None, 2),
+    ("chorus_default", _capi.FX_CHORUS, None, None, 2),
+    ("chorus_fast_lfo", _capi.FX_CHORUS, {"rate": 9.0, "dpth": 1.0, "fdbk": -0.8, "dlay": 3.0}, None, 2),
+]
+INDEX_FLIP_RATE_MAX = 1e-4   # flips per logged read; a flip moves one tap by one frame (its weight is the interpolation fraction ~ 0 there)
+
+
+@pytest.mark.parametrize("name,kind,params,seeds,per_frame", INDEX_CASES, ids=[c[0] for c in INDEX_CASES])
+def test_delay_line_read_index_streams(name, kind, params, seeds, per_frame):
+    """no index is derived from a transcendental EXCEPT the read positions of the reverb's vibrato lines
+    (floor(count + (sin(phase) + 1) * 7), reverb.rs:563-567) and of the interpolated delay lines of Delay / Chorus (floor(write_pos -
+    delay), dsp/delay.rs:120-126): device libm (and, in the reverb, the angle-addition form of sin) may land on the other side of an
+    integer where glibc does not. Those index streams are exported by both sides (pg_effect_debug_index_log / po_index_log_*) and compared
+    on their own — a flipped index must not hide inside the RMS figure. 24 blocks of 1024 frames: every read of every line is logged."""
+    import ctypes as C
+
+    blocks, frames = 24, 1024
+    words = frames * per_frame
+    e_gpu = gpu_effect(kind, params, seeds)
+    e_cpu = oracle.OracleEffect(kind, params, seeds)
+    for e in (e_gpu, e_cpu):
+        e.initialize(SR, 2, 4096)
+    lib = e_gpu._lib
+    x = workloads.test_signal(blocks * frames, seed=kind + 31, kind="noise")
+    a, b = x.copy(), x.copy()
+    flips = total = 0
+    worst = 0
+    for blk in range(blocks):
+        sl = slice(blk * frames * 2, (blk + 1) * frames * 2)
+        assert lib.pg_effect_debug_index_log(e_gpu._h, None, words) == 0
+        e_gpu.process(a[sl])
+        got = np.zeros(words, np.int32)
+        assert lib.pg_effect_debug_index_log(e_gpu._h, got.ctypes.data_as(C.POINTER(C.c_int32)), words) == 0
+        oracle.lib().po_index_log_begin()
+        e_cpu.process(b[sl])
+        want = np.zeros(words, np.int32)
+        n = oracle.lib().po_index_log_end(want.ctypes.data_as(C.POINTER(C.c_int32)), words)
+        assert n == words, (n, words)
+        assert (got >= 0).all(), "the time-parallel path did not log every read (serial fallback?)"
+        diff = got != want
+        flips += int(diff.sum())
+        total += words
+        if diff.any():
+            worst = max(worst, int(np.abs(got[diff].astype(np.int64) - want[diff]).max()))
+    rate = flips / total
+    print(f"{name}: {flips} index flips in {total} reads (rate {rate:.2e}, largest distance {worst})")
+    assert rate <= INDEX_FLIP_RATE_MAX, f"{flips} flips in {total} reads"
+    check(a, b)
