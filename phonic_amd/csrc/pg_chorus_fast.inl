@@ -14,9 +14,9 @@
 struct ChorusPiece { int k0; float p0; double du; };  // phases of frames k0 .. next piece: p0 + (k - k0) * du (exact in f64)
 constexpr int CHORUS_PIECE_CAP = 56;
 
-// One lane: lists the exact pieces of `steps` phase updates starting at p; frames beyond the piece capacity are written to
-// `ph` directly. Returns the number of pieces; *covered = frames described by pieces. Advances p.
-DEVO int chorus_phase_pieces(float& p, float d, int steps, ChorusPiece* rec, float* ph, int* covered) {
+// One lane: lists the exact pieces of up to `steps` phase updates starting at p, as many as fit the piece table. Returns the number of
+// pieces; *covered = frames described by them (== steps unless the table filled up); p = the phase after `*covered` updates.
+DEVO int chorus_phase_pieces(float& p, float d, int steps, ChorusPiece* rec, int* covered) {
   int n_rec = 0, k = 0;
   while (k < steps && n_rec < CHORUS_PIECE_CAP) {
     const uint32_t bits = __float_as_uint(p);
@@ -39,8 +39,13 @@ DEVO int chorus_phase_pieces(float& p, float d, int steps, ChorusPiece* rec, flo
     else { p += d; if (p >= 1.0f) p -= 1.0f; k += 1; }                // the plain hardware step: this piece covers one frame
   }
   *covered = k;
-  for (; k < steps; ++k) { ph[k] = p; p += d; if (p >= 1.0f) p -= 1.0f; }
   return n_rec;
+}
+// the phase frame k reads (any lane): its piece is found by a walk over the (few, LDS-resident) piece records
+DEVO float chorus_phase_at(const ChorusPiece* r, int nr, int k) {
+  int i = 0;
+  while (i + 1 < nr && r[i + 1].k0 <= k) ++i;
+  return (float)((double)r[i].p0 + (double)(k - r[i].k0) * r[i].du);
 }
 
 DEVO bool chorus_fast_eligible(const PgFx& fx) {
@@ -65,10 +70,12 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   double* xchg = (double*)lp;                 lp += 4 * 8;
   PgBiquadCoef* lco = (PgBiquadCoef*)lp;      lp += sizeof(PgBiquadCoef);
   ChorusPiece* rec = (ChorusPiece*)lp;        lp += 2 * CHORUS_PIECE_CAP * sizeof(ChorusPiece);
-  int* pctl = (int*)lp;                       lp += 16;   // [osc]: pieces, covered frames
-  float* ph = (float*)lp;                     lp += 2 * 1024 * 4;   // [osc][frame] LFO phase read by that frame
-  float* o32 = (float*)lp;                                         // [frame][2] interpolated line output
-  static_assert(REV_BUF_DOUBLES * 8 + 32 + sizeof(PgBiquadCoef) + 2 * CHORUS_PIECE_CAP * sizeof(ChorusPiece) + 16 + 2 * 1024 * 4 + 2 * 1024 * 4 <= FAST_SCRATCH_BYTES,
+  int* pctl = (int*)lp;                       lp += 32;   // [osc]: pieces, covered frames; then the phases after the piece (f32 bits)
+  // [frame][2] interpolated line output: in the free `tmp` rows of the unit (2 floats per frame of the block) — 8 KB less arena, which
+  // takes a Filter -> Chorus unit from 55 KB to 46 KB of LDS: three workgroups per CU instead of two
+  float* o32 = fc.tmp_floats >= 2 * (frames < 1024 ? frames : 1024) ? fc.tmp : nullptr;
+  if (!o32) return false;
+  static_assert(REV_BUF_DOUBLES * 8 + 32 + sizeof(PgBiquadCoef) + 2 * CHORUS_PIECE_CAP * sizeof(ChorusPiece) + 32 <= FAST_SCRATCH_CHORUS_BYTES,
                 "chorus fast path: LDS arena too small");
   const float srf = (float)fx.sample_rate;
   const float delay_ms = c.delay.target, depth = c.depth.target;
@@ -87,28 +94,29 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     else { b.m0 = 1.0; b.m1 = -c.coef.k; b.m2 = -1.0; }
     *lco = b;
   }
-  for (int p0 = 0; p0 < frames; p0 += 1024) {
-    const int P = frames - p0 < 1024 ? frames - p0 : 1024;
+  for (int p0 = 0; p0 < frames;) {
+    int P = frames - p0 < 1024 ? frames - p0 : 1024;
     float* sp = sig + 2 * p0;
     __syncthreads();
-    // 0. LFO phases (lfo.run() once per frame and oscillator, chorus.rs:353-354)
-    if (tid == 0 || tid == 64) {
-      const int o = tid >> 6;
-      pctl[2 * o] = chorus_phase_pieces(c.osc[o].phase, c.osc[o].phase_inc, P, rec + o * CHORUS_PIECE_CAP, ph + o * 1024, &pctl[2 * o + 1]);
+    // 0. LFO phases (lfo.run() once per frame and oscillator, chorus.rs:353-354): one lane per oscillator lists the exact pieces; the piece
+    // of the signal ends where the shorter of the two lists ends (a full table: only at phase increments far above the 10 Hz the rate allows)
+    for (int pass = 0; pass < 2; ++pass) {
+      if (tid == 0 || tid == 64) {
+        const int o = tid >> 6;
+        float p = c.osc[o].phase;
+        pctl[2 * o] = chorus_phase_pieces(p, c.osc[o].phase_inc, P, rec + o * CHORUS_PIECE_CAP, &pctl[2 * o + 1]);
+        pctl[4 + o] = (int)__float_as_uint(p);
+      }
+      __syncthreads();
+      const int covered = pctl[1] < pctl[3] ? pctl[1] : pctl[3];
+      __syncthreads();
+      if (covered >= P) break;
+      P = covered;  // (second pass: both lists describe exactly P frames)
     }
+    if (tid == 0 || tid == 64) c.osc[tid >> 6].phase = __uint_as_float((uint32_t)pctl[4 + (tid >> 6)]);
     // 1. pre-filter over the piece (svf.rs:211-222)
     for (int s = tid; s < 2 * P; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sp[s];
     __syncthreads();
-    for (int s = tid; s < 2 * P; s += nt) {
-      const int k = s >> 1, o = s & 1;
-      if (k < pctl[2 * o + 1]) {
-        const ChorusPiece* r = rec + o * CHORUS_PIECE_CAP;
-        int i = 0;
-        const int nr = pctl[2 * o];
-        while (i + 1 < nr && r[i + 1].k0 <= k) ++i;
-        ph[o * 1024 + k] = (float)((double)r[i].p0 + (double)(k - r[i].k0) * r[i].du);
-      }
-    }
     rev_biquad_scan(*lco, c.flt, buf, P, xchg);
     __syncthreads();
     // 2. chunks
@@ -120,7 +128,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       __syncthreads();
       for (int s = tid; s < 2 * T; s += nt) {
         const int nn = done + (s >> 1), ch = s & 1;
-        PgLfo l; l.phase = ph[ch * 1024 + nn]; l.phase_inc = 0.0f; l.waveform = c.osc[ch].waveform;
+        PgLfo l; l.phase = chorus_phase_at(rec + ch * CHORUS_PIECE_CAP, pctl[2 * ch], nn); l.phase_inc = 0.0f; l.waveform = c.osc[ch].waveform;
         const float lfo = lfo_value(l);
         const float delay_pos = 2.0f + delay_in_samples + (1.0f + lfo) * depth_in_samples;
         const gdouble* line = (const gdouble*)c.line[ch];
@@ -149,6 +157,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       __syncthreads();
       done += T;
     }
+    p0 += P;
   }
   if (tid == 0) {  // block-end phase bookkeeping (chorus.rs:388-393)
     const double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;

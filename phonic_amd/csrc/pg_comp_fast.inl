@@ -38,7 +38,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   float* a1 = a0 + COMP_FAST_CAP;              // ping-pong partner of the doubling; later the copy of the block's input
   float* env = a1 + COMP_FAST_CAP;             // [1024] input dB, then envelope
   int* red = (int*)(env + 1024);               // [8] reductions
-  static_assert((2 * COMP_FAST_CAP + 1024 + 8) * 4 <= FAST_SCRATCH_BYTES, "compressor fast path: LDS arena too small");
+  static_assert((2 * COMP_FAST_CAP + 1024 + 8) * 4 <= FAST_SCRATCH_COMP_BYTES, "compressor fast path: LDS arena too small");
   const int W = (int)c.delay_frames, H = W - 1;
   const uint32_t mask = c.mask;
   gdouble* line = (gdouble*)c.line;

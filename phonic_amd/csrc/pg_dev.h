@@ -269,7 +269,7 @@ struct PgLaunch {
   uint64_t pos;           // SourceTime.pos_in_frames of the first frame
   uint32_t sample_rate;
   int32_t fast;           // 1: time-parallel paths enabled
-  int32_t wide;           // fast kernel variant: 0 = lean (Gain/Panning/Reverb), 1 = all fast-capable kinds
+  int32_t wide;           // fast kernel variant: 0 = lean (Gain/Panning/Reverb), 1 = all fast-capable kinds, 2 = all but Reverb / Compressor (four workgroups per CU)
   int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only
   float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
   uint32_t out_stride;    // floats per unit row
@@ -296,6 +296,8 @@ struct PgLaunch {
   int32_t pad_chunks;
   uint64_t chunk_stride;  // floats between the per-unit output tables of consecutive blocks
   int32_t* error_word;    // device word of sticky consistency flags (PG_DEVERR_*), nullptr: not collected
+  uint32_t fast_scratch_bytes;  // host: LDS arena of the fast kernels for the effect kinds this graph holds (0: the full arena)
+  uint32_t pad_scratch;
   int32_t* index_log;     // test hook (generic kernel only, see FastCtx::idx_log): read indices of the time-parallel delay-line paths
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.

@@ -21,6 +21,12 @@ struct FastCtx {
 };
 
 constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
+// What the other time-parallel paths carve from the arena: a launch whose units hold no Reverb gets a smaller arena (pg_fast_scratch_bytes)
+// and with it more resident workgroups per CU.
+constexpr size_t FAST_SCRATCH_SCAN_BYTES = (2 * 1024 + 128 + 8) * 8 + 512;                           // Filter / Eq5 / Delay / Gain's DC filter: chunk buffer + scan hand-over + coefficients
+constexpr size_t FAST_SCRATCH_CHORUS_BYTES = (2 * 1024 + 128 + 8) * 8 + 32 + 80 + 2 * 56 * 16 + 32 + 64;  // + the LFOs' phase pieces
+constexpr size_t FAST_SCRATCH_COMP_BYTES = (2 * 4096 + 1024 + 8) * 4;                                  // Compressor: peak history + block
+constexpr size_t FAST_SCRATCH_GATE_BYTES = 2 * 1024 * 4 + 256;
 
 #include "pg_reverb_fast.inl"
 #include "pg_delay_fast.inl"

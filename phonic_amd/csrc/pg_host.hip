@@ -27,7 +27,7 @@
 using namespace pgd;
 using namespace pgh;
 
-size_t pg_unit_lds_bytes(uint32_t n_frames);
+size_t pg_fast_scratch_bytes(uint32_t kind_mask);
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
@@ -478,6 +478,7 @@ struct pg_graph {
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
+  uint32_t fast_kind_mask = 0;  // effect kinds held by the units the fast kernels render: sizes their LDS arena (pg_fast_scratch_bytes)
   int timing_period = 0;   // time every n-th round with a hipEvent pair (0: never, the default); pg_graph_set_timing_period creates the pairs
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
@@ -596,6 +597,7 @@ static int new_unit(pg_graph* g, int kind) {
 
 static int rebuild_topology(pg_graph* g, hipStream_t stream) {
   std::vector<int32_t> vidx, fidx;
+  uint32_t kind_mask = 0;
   std::vector<PgUnit> topo = g->h_units;
   // sub-mixers and the bus
   for (size_t m = 0; m < g->mixers.size(); ++m) {
@@ -607,6 +609,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     for (int f : mx.fx) {
       fidx.push_back(f);
       const int k = g->fx[f]->kind;  // kinds with a time-parallel path (pg_fx_fast.h: fx_fast_eligible)
+      if (m != 0 && !mx.removed) kind_mask |= 1u << k;
       if (m != 0 && (k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DISTORTION || k == PG_FX_DELAY || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE)) g->wide = true;
       if (!(k == PG_FX_GAIN || k == PG_FX_PANNING || k == PG_FX_FILTER || k == PG_FX_EQ5 || k == PG_FX_DELAY || k == PG_FX_REVERB || k == PG_FX_CHORUS || k == PG_FX_COMPRESSOR || k == PG_FX_GATE || k == PG_FX_DISTORTION)) u.static_defer = 1;
       if (m != 0 && k == PG_FX_GAIN && (int)g->fx[f]->init_raw[1] != 0) g->wide = true;  // DC filter: blocked scan, compiled into the wide variants only
@@ -683,6 +686,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     g->n_staged += lv.n_staged; g->n_staged_wide += lv.n_staged_wide; g->n_static_defer += lv.n_static_defer;
   }
   g->h_units = topo;
+  g->fast_kind_mask = kind_mask;
   if ((rc = g->d_voice_index.upload_async(vidx, stream))) return rc;
   if ((rc = g->d_fx_index.upload_async(fidx, stream))) return rc;
   if ((rc = g->d_order.upload_async(g->order, stream))) return rc;
@@ -1224,7 +1228,7 @@ const char* pg_graph_dominant_kernel(pg_graph* g) {
     if (n_lean > 0 && g->n_staged_wide > 0) return "pg_stage_fused_kernel + pg_stage_fused_wide_kernel";
     return g->n_staged_wide > 0 ? "pg_stage_fused_wide_kernel" : "pg_stage_fused_kernel";
   }
-  return g->wide ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast";
+  return g->wide ? ((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast_mid") : "pg_unit_kernel_fast";
 }
 int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) {
   g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds;
@@ -1347,6 +1351,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
   L.diag = g->d_diag;
   L.n_chunks = n_chunks; L.chunk_stride = (uint64_t)g->unit_out_rows * g->stride; L.error_word = g->d_error;
+  L.fast_scratch_bytes = (uint32_t)pg_fast_scratch_bytes(g->fast_kind_mask);
   const uint64_t round = g->launch_counter;
   if (!cmds.empty()) g->last_change_round = round;
   L.round = (uint32_t)round; L.host_feedback = g->d_feedback;
@@ -1380,7 +1385,8 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     const bool time_generic = g->fast && lv.n_static_defer * 2 > lv.cnt;
     hipEvent_t e0 = timed_here ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed_here ? g->ev_pool[g->ev_used].second : nullptr;
     if (g->fast) {
-      L.mode = 1; L.wide = g->wide ? 1 : 0;  // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+      // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+      L.mode = 1; L.wide = g->wide ? ((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) ? 1 : 2) : 0;
       // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
       const int n_lean = lv.n_staged - lv.n_staged_wide;
       const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;

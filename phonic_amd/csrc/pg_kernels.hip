@@ -519,6 +519,13 @@ __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(P
   pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, 0);
   for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, c); }
 }
+// Chains without Reverb and Compressor (C3: Filter -> Chorus per voice): those two carry the large register footprints and LDS arenas.
+// Without them the same body compiles for four workgroups per CU (128 VGPRs) and its arena fits 40 KB.
+#define PG_KMASK_MID (PG_KMASK_ALL & ~((1 << 5) | (1 << 7)))
+__global__ void __launch_bounds__(256, 4) pg_unit_kernel_fast_mid(PgLaunch L) {
+  pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, 0);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, c); }
+}
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
 // walks its share of the units, so the launch that finds nothing deferred costs 256 workgroup starts instead of n_units.
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
@@ -976,9 +983,22 @@ __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ u
 }
 
 // ---- host-callable launchers (C++ linkage, used by pg_host.cpp) ------------------------------------------
-size_t pg_unit_lds_bytes(uint32_t n_frames) {
+// LDS arena the time-parallel paths of the effect kinds in `kind_mask` (bit k = pg_effect_kind k) carve up — what a fast-kernel launch
+// needs besides the signal rows. Without a Reverb (and without a Compressor) a unit kernel fits three workgroups per CU instead of two.
+size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
+  size_t need = SRC_SCRATCH_BYTES;
+  auto up = [&](size_t b) { if (b > need) need = b; };
+  if (kind_mask & (1u << 5)) up(FAST_SCRATCH_BYTES);
+  if (kind_mask & (1u << 7)) up(FAST_SCRATCH_COMP_BYTES);
+  if (kind_mask & (1u << 6)) up(FAST_SCRATCH_CHORUS_BYTES);
+  if (kind_mask & ((1u << 0) | (1u << 2) | (1u << 3) | (1u << 4))) up(FAST_SCRATCH_SCAN_BYTES);
+  if (kind_mask & (1u << 8)) up(FAST_SCRATCH_GATE_BYTES);
+  return need;
+}
+size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0) {
   size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
   size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
+  if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
@@ -1003,7 +1023,7 @@ static hipError_t pg_ensure_func_attributes() {
   std::lock_guard<std::mutex> lock(mtx);
   if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
   const void* fns[] = {(const void*)pg_stage1_kernel, (const void*)pg_stage2_kernel, (const void*)pg_stage3_kernel, (const void*)pg_unit_kernel,
-                       (const void*)pg_unit_kernel_fast, (const void*)pg_unit_kernel_fast_wide};
+                       (const void*)pg_unit_kernel_fast, (const void*)pg_unit_kernel_fast_wide, (const void*)pg_unit_kernel_fast_mid};
   for (const void* f : fns) if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
@@ -1027,9 +1047,10 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
 }
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
-  size_t lds = pg_unit_lds_bytes(L.n_frames);
+  size_t lds = pg_unit_lds_bytes(L.n_frames, L.mode == 1 ? L.fast_scratch_bytes : 0);  // (the generic kernel renders any chain: full arena)
   { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
-  if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
+  if (L.mode == 1 && L.wide == 2) hipExtLaunchKernelGGL(pg_unit_kernel_fast_mid, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
+  else if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else if (L.mode == 1) hipExtLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   return hipGetLastError();
