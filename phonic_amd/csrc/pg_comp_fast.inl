@@ -1,4 +1,5 @@
-// Time-parallel CompressorEffect / limiter (reference src/effect/compressor.rs:230-294) for one workgroup, makeup gain not ramping.
+// Time-parallel CompressorEffect / limiter (reference src/effect/compressor.rs:230-294) for one workgroup (the makeup gain may ramp: its
+// smoother's per-frame values are laid out by the lane that walks the envelope).
 //
 // The serial loop pays one dependent HBM read per frame (the look-ahead line): 1.2 ms per 1024-frame block on one lane. Here
 //   * the delayed frame is  line[wp + n - delay]  for n < delay and the block's own input for n >= delay: read in parallel;
@@ -27,7 +28,7 @@ constexpr int COMP_FAST_CAP = 4096;  // history + block frames held in LDS
 
 DEVO bool comp_fast_eligible(const PgFx& fx) {
   const PgComp& c = fx.u.comp;
-  return !sm_need_ramp(c.makeup) && c.delay_frames >= 1 && c.delay_frames <= c.mask && (int)c.delay_frames - 1 + 1024 <= COMP_FAST_CAP;
+  return c.delay_frames >= 1 && c.delay_frames <= c.mask && (int)c.delay_frames - 1 + 1024 <= COMP_FAST_CAP;
 }
 
 DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
@@ -44,6 +45,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   gdouble* line = (gdouble*)c.line;
   const bool limiter = c.ratio >= 20.0f;
   const float makeup = c.makeup.target;
+  const bool makeup_ramps = sm_need_ramp(c.makeup);  // decided once per process call, like `need_ramp` in the serial loop's next_value()
   const int total = n_samples / 2;
   for (int f0 = 0; f0 < total; f0 += 1024) {   // pieces of <= 1024 frames
     const int N = total - f0 < 1024 ? total - f0 : 1024, TOT = H + N;
@@ -95,6 +97,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const float att = c.env_attack, rel = c.env_release;
       for (int n = 0; n < N; ++n) env[n] = env_run(cur, att, rel, env[n]);
       c.env_current = cur;
+      if (makeup_ramps) { PgSmooth m = c.makeup; for (int n = 0; n < N; ++n) a0[n] = sm_next(m); c.makeup = m; }  // makeup_gain.next_value() per frame (a0 is free by now)
       c.peak_value = (double)__uint_as_float((uint32_t)red[0]);
       c.peak_pos = (wp0 + (uint32_t)red[1]) & mask;
       c.write_pos = (wp0 + (uint32_t)N) & mask;
@@ -105,7 +108,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     // 5. gain and output (compressor.rs:257-292); 6. the block's input goes into the line
     for (int s = tid; s < 2 * N; s += nt) {
       const int n = s >> 1, ch = s & 1;
-      const float total_gain = db_to_linear(makeup - comp_gain_reduction_db(c, env[n]));
+      const float total_gain = db_to_linear((makeup_ramps ? a0[n] : makeup) - comp_gain_reduction_db(c, env[n]));
       const float delayed = n < W ? (float)line[((wp0 + (uint32_t)(n - W)) & mask) * 2 + ch] : a1[2 * (n - W) + ch];
       sp[s] = delayed * total_gain;
     }

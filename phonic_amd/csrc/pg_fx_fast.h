@@ -100,6 +100,52 @@ DEVO void filter_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   }
   __syncthreads();
 }
+// Eq5Effect while any of its fifteen smoothers ramps (eq5.rs:190-207,297-326): per band, three lanes lay out the band's bandwidth /
+// frequency / gain sequences (the same sm_next calls as the serial loop, each smoother on its own: they do not interact), every frame's
+// coefficients are recomputed from them as ramp_filter_coefficients does — q = bandwidth for the shelves, 1 / max(bandwidth, 0.001) for the
+// bells — and the band runs as the time-varying blocked scan, f32 rounding between the cascaded bands as in the reference.
+DEVO void eq5_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  PgEq5& e = fx.u.eq5;
+  const int tid = pg_tid(), nt = blockDim.x;
+  double* buf = (double*)fc.scratch;
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  PgState2* lst = (PgState2*)(xchg + 4);
+  const int frames = n_samples / 2;
+  const int piece = fc.tmp_floats / 3 < 1024 ? fc.tmp_floats / 3 : 1024;
+  float* qv = fc.tmp;  // [piece] q, [piece] clamped cutoff, [piece] gain of the band being processed
+  const float nyq = (float)fx.sample_rate / 2.0f;
+  const uint32_t sr = fx.sample_rate;
+  for (int done = 0; done < frames; done += piece) {
+    const int T = frames - done < piece ? frames - done : piece;
+    float* cut = qv + T;
+    float* gn = cut + T;
+    __syncthreads();
+    for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
+    for (int i = 0; i < 5; ++i) {
+      __syncthreads();
+      if (tid == 0) { PgSmooth s = e.bws[i]; for (int k = 0; k < T; ++k) { const float b = sm_next(s); qv[k] = (i == 0 || i == 4) ? b : 1.0f / fmaxf(b, 0.001f); } e.bws[i] = s; }
+      else if (tid == 64) { PgSmooth s = e.freqs[i]; for (int k = 0; k < T; ++k) cut[k] = clampf(sm_next(s), 20.0f, nyq); e.freqs[i] = s; }
+      else if (tid == 128) { PgSmooth s = e.gains[i]; for (int k = 0; k < T; ++k) gn[k] = sm_next(s); e.gains[i] = s; }
+      if (tid < 2) lst[tid] = e.st[tid][i];
+      __syncthreads();
+      const int btype = eq5_band_type(i);
+      auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
+        PgBiquadCoef c;
+        c.type = btype; c.sample_rate = sr; c.cutoff = cut[n]; c.q = qv[n]; c.gain = gn[n];
+        c.a1 = 0.0; c.a2 = 0.0; c.a3 = 0.0; c.m0 = 0.0; c.m1 = 0.0; c.m2 = 0.0;
+        (void)biquad_apply(c);
+        a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
+      };
+      svf_scan_time_varying<true>(coef, lst, buf, T, xchg);
+      __syncthreads();
+      if (tid < 2) e.st[tid][i] = lst[tid];
+      if (tid == 0) (void)biquad_set(e.coef[i], btype, sr, cut[T - 1], qv[T - 1], gn[T - 1]);  // the set the serial loop ends the block with
+    }
+    __syncthreads();
+    for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)];
+  }
+  __syncthreads();
+}
 DEVO bool eq5_steady(const PgEq5& e) {
   bool ramp = false;
   for (int i = 0; i < 5; ++i) ramp = ramp || sm_need_ramp(e.freqs[i]) || sm_need_ramp(e.bws[i]) || sm_need_ramp(e.gains[i]);
@@ -112,7 +158,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
     case 0: return !sm_need_ramp(fx.u.gain.gain);
     case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
     case 2: return !staged_unit || !(sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q: time-varying scan (not in the staged kernels)
-    case 3: return eq5_steady(fx.u.eq5);
+    case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
     case 4: return delay_fast_eligible(fx);
     case 5: return reverb_fast_eligible(fx);
     case 6: return chorus_fast_eligible(fx);
@@ -196,7 +242,13 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     } else return false;
     case 3: if constexpr ((KMASK >> 3) & 1) {  // Eq5Effect, no ramp (eq5.rs:297-326)
       PgEq5& e = fx.u.eq5;
-      if (!eq5_steady(e)) return false;
+      if (!eq5_steady(e)) {
+        if constexpr ((KMASK >> 10) & 1) {
+          if (fc.tmp_floats < 24) return false;
+          eq5_ramp_fast(fx, sig, n, fc);
+          return true;
+        } else return false;
+      }
       biquad_chain_fast(sig, n, e.coef, &e.st[0][0], 5, 5, fc);
       return true;
     } else return false;

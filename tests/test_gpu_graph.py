@@ -1170,3 +1170,45 @@ def test_resampled_source_behind_the_file_source(file_rate, source_rate, channel
     a, b = render2(gg), render2(gc)
     compare(a, b, 1e-6, 1e-5)
     assert gg.device_errors() == 0
+
+
+def test_eq5_and_compressor_makeup_ramps_stay_on_the_time_parallel_kernels():
+    """While a smoother moves, FilterEffect (round 1), Eq5Effect and the Compressor's makeup gain (round 2) keep a time-parallel path: the
+    smoothers' f32 value sequences are laid out by single lanes, the per-frame coefficients / gains are computed by all lanes, the
+    recurrence runs as the time-varying blocked scan. A sub-mixer Eq5 -> Compressor gets gain / frequency / bandwidth / makeup updates;
+    only the block that carries the commands goes to the generic kernel, the ramping blocks behind it are rendered by the fast kernel
+    (pg_graph_deferred_units() == 0) and match the oracle."""
+    from phonic_amd.graph import Graph
+
+    def build(g):
+        ids = []
+        for i in range(3):
+            m = g.add_mixer()
+            eq = g.add_effect(m, _capi.FX_EQ5, params={"gan2": 3.0})
+            cp = g.add_effect(m, _capi.FX_COMPRESSOR, params={"thrs": -24.0, "rato": 4.0, "gain": 3.0})
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.3), 2, 44100, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+            ids.append((eq, cp))
+        return ids
+
+    def act(g, ids, pos):
+        g.schedule_param(ids[0][0], "gan2", -9.0, pos + 100)
+        g.schedule_param(ids[0][0], "frq3", 900.0, pos + 100)
+        g.schedule_param(ids[1][0], "bw_2", 0.5, pos + 700)
+        g.schedule_param(ids[2][1], "gain", -12.0, pos + 300)
+
+    gg, gc = Graph(SR, 2, 1024, 0), oracle.OracleGraph(SR, 2, 1024)
+    outs, deferred = [], []
+    for g in (gg, gc):
+        ids = build(g)
+        o = np.zeros((12, 2048), np.float32)
+        for b in range(12):
+            if b == 3:
+                act(g, ids, b * 1024)
+            assert g.write(o[b], b * 1024) == 2048
+            if g is gg:
+                deferred.append(g.deferred_units())
+        outs.append(o.reshape(-1))
+    compare(outs[0], outs[1])
+    assert deferred[3] == 3          # the block with the commands: exact generic kernel
+    assert deferred[4] == 0 and deferred[5] == 0, deferred   # still ramping (Eq5 gain: ~0.1 s), yet on the fast kernel
+    assert gg.device_errors() == 0
