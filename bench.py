@@ -199,9 +199,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = None
-    if world > 1:
+    # PHONIC_BENCH_FORCE_DIST=1 (test hook, 1-GPU boxes): a single rank still builds its RCCL group and sends every super-block through
+    # dist.reduce on RCCL's stream — the `nccl` branch (group creation, asynchronous reduce ordered behind the render stream, Work.wait)
+    # runs on the real backend even where only one GPU can be leased.
+    force_dist = world == 1 and os.environ.get("PHONIC_BENCH_FORCE_DIST", "") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if shared_gpu else "nccl"
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
@@ -248,7 +257,7 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.set_stream(render_stream)
     stream = render_stream.cuda_stream
-    ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0)
+    ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0, force_distributed=force_dist)
     if bus_on_root:
         ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
     pos = 0
@@ -345,7 +354,8 @@ def main():
                 "master_frames_per_s": value / total_voices,
                 "x_realtime": value / total_voices / 48000.0,
                 "sharding": f"voices/{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} reduce(sum) of the master bus per {M} block(s)" if world > 1 else ""),
-                "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else (0 if world > 1 else 1),
+                "rccl_ranks": dist.get_world_size() if ((world > 1 or force_dist) and backend == "nccl") else (0 if world > 1 else 1),
+                "rccl_group_forced": bool(force_dist),
                 "backend": backend,
                 "exact_mode": bool(args.exact),
                 "bus_peak": peak,
@@ -373,7 +383,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, block)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

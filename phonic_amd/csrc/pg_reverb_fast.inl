@@ -134,6 +134,60 @@ DEVO double rev_get(const double* buf_generic, uint32_t cnt, uint32_t delay, int
   return (1.0 - blend) * interpol + (val1 * blend);
 }
 
+// sin / asin of the reverb's two shaping points (reverb.rs:256-257,351-352) on the arguments audio actually produces: |x| <= pi/4 resp.
+// |x| <= 1/2 take a short odd polynomial — Taylor to x^15 for sin (truncation < 5e-17 at pi/4), to x^33 for asin (< 3e-13 at 1/2, far
+// less below) — instead of the library routine (argument reduction, two polynomials and a select; a rational with a division for asin);
+// anything larger goes to the library. The parity gate is 1e-5 RMS on f32 output: both are ~8 orders of magnitude inside it.
+#ifndef PG_FAST_SIN
+#define PG_FAST_SIN 1
+#endif
+#ifndef PG_FAST_ASIN
+#define PG_FAST_ASIN 0   // measured (three interleaved repetitions on one box): the short sin −1 % kernel time, the 16-term asin chain +0.7 % (a
+#endif                   // longer dependent chain than the library's rational): sin on, asin off
+
+DEVO double rev_sin(double x) {
+#if PG_FAST_SIN
+  if (fabs(x) <= 0.78539816339744828) {
+    const double z = x * x;
+    double p = -7.6471637318198164759e-13;           // -1/15!
+    p = fma(p, z, 1.6059043836821614599e-10);        //  1/13!
+    p = fma(p, z, -2.5052108385441718775e-08);       // -1/11!
+    p = fma(p, z, 2.7557319223985890653e-06);        //  1/9!
+    p = fma(p, z, -1.9841269841269841270e-04);       // -1/7!
+    p = fma(p, z, 8.3333333333333333333e-03);        //  1/5!
+    p = fma(p, z, -1.6666666666666666667e-01);       // -1/3!
+    return fma(x * z, p, x);
+  }
+#endif
+  return sin(x);
+}
+DEVO double rev_asin(double x) {
+#if PG_FAST_ASIN
+  if (fabs(x) <= 0.5) {
+    // asin x = x + x z (c_1 + z (c_2 + ... + z c_16)),  z = x^2,  c_k = (2k)! / (4^k (k!)^2 (2k+1))
+    const double z = x * x;
+    double p = 0.004240907093679363;         // c_16
+    p = fma(p, z, 0.004660143486915096);     // c_15
+    p = fma(p, z, 0.005153309682319905);     // c_14
+    p = fma(p, z, 0.005740037670841924);     // c_13
+    p = fma(p, z, 0.006447210311889649);     // c_12
+    p = fma(p, z, 0.0073125258735988454);    // c_11
+    p = fma(p, z, 0.008390335809616815);     // c_10
+    p = fma(p, z, 0.009761609529194078);     // c_9
+    p = fma(p, z, 0.011551800896139705);     // c_8
+    p = fma(p, z, 0.01396484375);            // c_7
+    p = fma(p, z, 0.017352764423076924);     // c_6
+    p = fma(p, z, 0.022372159090909092);     // c_5
+    p = fma(p, z, 0.030381944444444444);     // c_4
+    p = fma(p, z, 0.044642857142857144);     // c_3
+    p = fma(p, z, 0.075);                    // c_2
+    p = fma(p, z, 0.16666666666666666);      // c_1
+    return fma(x * z, p, x);
+  }
+#endif
+  return asin(x);
+}
+
 // LDS chunk buffer: [frame][2] f64, skewed by one double per 8-frame segment so that both the linear (per sample)
 // accesses and the per-segment accesses of the blocked biquad are free of bank conflicts.
 #define REV_IDX(n, ch) ((n) * 2 + (ch) + ((n) >> 3))
@@ -457,7 +511,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
         for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
-        double v = sin(bufA[REV_IDX(done + n, ch)] * wet);
+        double v = rev_sin(bufA[REV_IDX(done + n, ch)] * wet);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const double bb = v - (dl[i] * 0.5);
@@ -547,7 +601,7 @@ DEVO void rev_tail_impl(PgReverb& r, float* s0, int T, const RevLds& m, const Re
   rev_biquad_scan(r.cb, r.sb, bufA, T, m.xchg);
   __syncthreads();
   PG_STAMP(diag, 57);
-  for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = asin(clampd(bufA[bi], -1.0, 1.0)); }
+  for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); bufA[bi] = rev_asin(clampd(bufA[bi], -1.0, 1.0)); }
   __syncthreads();
   PG_STAMP(diag, 58);
   rev_biquad_scan(r.cc, r.sc, bufA, T, m.xchg);

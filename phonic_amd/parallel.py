@@ -31,13 +31,14 @@ class MasterBusRing:
     runs on RCCL's own stream, ordered behind the render stream by an event, under the renders of the following super-blocks;
     `Work.wait()` only makes the current stream wait. Without a process group the ring is plain double buffering (world size 1)."""
 
-    def __init__(self, n_samples, blocks_per_reduce, device, n_buffers=4, root=0, group=None):
+    def __init__(self, n_samples, blocks_per_reduce, device, n_buffers=4, root=0, group=None, force_distributed=False):
         self.n_samples, self.m, self.n_buffers, self.root, self.group = int(n_samples), max(1, int(blocks_per_reduce)), int(n_buffers), root, group
         self.buffers = [torch.zeros(self.m * self.n_samples, dtype=torch.float32, device=device) for _ in range(self.n_buffers)]
         self.pending = [None] * self.n_buffers
         self.step = 0  # next block (super-block aligned after drain())
         self._last = None
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (force_distributed: a one-rank group still issues its reduces — exercises the backend where only one GPU can be leased)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_distributed)
 
     def _where(self):
         return (self.step // self.m) % self.n_buffers, self.step % self.m

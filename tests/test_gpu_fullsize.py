@@ -211,6 +211,18 @@ def test_bench_plain_invocation_spawns_its_ranks():
     assert abs(d["value"] - 25 * 1024 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
 
 
+def test_bench_rccl_branch_with_a_one_rank_group():
+    """With 1-GPU leases the `nccl` (= RCCL) branch of bench.py cannot meet a second rank; PHONIC_BENCH_FORCE_DIST=1 makes the single rank
+    build its RCCL process group anyway and push every super-block through an asynchronous dist.reduce on RCCL's stream (ordered behind the
+    render stream, waited for before the buffer is reused): group creation, the collective's launch and the stream ordering run on the real
+    backend. The bus must come back unchanged (sum over one rank)."""
+    d = _run_bench(["--steps", "24", "--warmup", "8", "--repeats", "2", "--voices", "64", "--superblock", "8", "--no-cpu-baseline"], {"PHONIC_BENCH_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["config"]["rccl_group_forced"] is True
+    assert d["value"] > 0 and d["config"]["bus_peak"] > 0.01
+    ref = _run_bench(["--steps", "24", "--warmup", "8", "--repeats", "2", "--voices", "64", "--superblock", "8", "--no-cpu-baseline"], {})
+    assert abs(ref["config"]["bus_peak"] - d["config"]["bus_peak"]) < 1e-7
+
+
 def test_bench_single_gpu_line_shape():
     """The default invocation's JSON contract at a reduced size: roofline (kernel-timed), cpu_baseline with its flags, repeats."""
     d = _run_bench(["--steps", "20", "--warmup", "4", "--repeats", "3", "--voices", "64"], {})
