@@ -153,6 +153,172 @@ DEVO bool delay_fast_eligible(const PgFx& fx) {
   return min_samples >= 66.0f && max_samples < (float)(d.mask - 8);
 }
 
+// ---- DelayEffect while parameters ramp (delay.rs:334-454 with any of its ten smoothers moving) ---------------------------------------------
+// Every per-frame control value of the reference loop is the next() of a smoother (or derived from the LFO, whose rate may ramp): ten
+// lanes of one wave lay out the nine value sequences and the LFO values of a piece — the same sm_next / lfo_run / set_rate calls as the
+// serial loop, each sequence on its own: they do not interact — all lanes turn them into the per-frame delay, cutoff and feedback, and the
+// piece is rendered like the steady state with per-frame values: taps, the time-varying SVF scan (svf_scan_time_varying), rational tanh
+// with the frame's drive, DC scan, line writes and the dry / wet / width law with the frame's values. Chunks are cut for the shortest
+// delay of the piece, so all line reads still hit pre-chunk data.
+constexpr int DELAY_RAMP_SEQS = 10;  // delay_time, d_time, d_filter, cutoff, feedback, d_feedback, drive, wet, width, LFO value
+DEVO PgSmooth& delay_ramp_smoother(PgDelay& d, int j) {
+  switch (j) { case 0: return d.delay_time; case 1: return d.d_time; case 2: return d.d_filter; case 3: return d.cutoff; case 4: return d.feedback;
+               case 5: return d.d_feedback; case 6: return d.drive; case 7: return d.wet; default: return d.width; }
+}
+// Shortest / longest delay (in samples) the coming frames can ask for: the smoothers move between their current value and their target (the
+// critically damped spring of the delay time may travel on by |velocity| / omega when it was redirected in flight), the LFO stays in
+// [-1, 1] up to the parabolic sine's overshoot.
+DEVO bool delay_ramp_eligible(const PgFx& fx) {
+  const PgDelay& d = fx.u.delay;
+  const float srf = (float)fx.sample_rate;
+  const PgSmooth& t = d.delay_time;
+  const float travel = t.kind == SM_SPRING && t.a > 0.0f ? fabsf(t.b) / (t.a * t.comp) : 0.0f;
+  const float lo = fminf(t.current, t.target) - travel, hi = fmaxf(t.current, t.target) + travel;
+  const float dev = fmaxf(fabsf(d.d_time.current), fabsf(d.d_time.target)) * 50.0f * 1.01f + 0.01f;
+  const float min_samples = fmaxf(lo * 0.999f - dev, 1.0f) * 0.001f * srf, max_samples = fmaxf(hi * 1.001f + dev, 1.0f) * 0.001f * srf;
+  return min_samples >= 66.0f && max_samples < (float)(d.mask - 8);
+}
+DEVO bool delay_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  if (!delay_ramp_eligible(fx)) return false;
+  PgDelay& d = fx.u.delay;
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int frames = n_samples / 2;
+  if (frames == 0) return true;
+  const int cap = fc.tmp_floats / DELAY_RAMP_SEQS < 1024 ? fc.tmp_floats / DELAY_RAMP_SEQS : 1024;
+  if (cap < 8) return false;
+  double* buf = (double*)fc.scratch;
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  int* red = (int*)(xchg + 4);  // [2] reductions
+  float* seq = fc.tmp;          // [DELAY_RAMP_SEQS][cap]
+  float* a_dly = seq, *a_dtime = seq + cap, *a_dflt = seq + 2 * cap, *a_cut = seq + 3 * cap, *a_fb = seq + 4 * cap, *a_dfb = seq + 5 * cap;
+  float* a_drive = seq + 6 * cap, *a_wet = seq + 7 * cap, *a_width = seq + 8 * cap, *a_lfo = seq + 9 * cap;
+  const float srf = (float)fx.sample_rate, nyq = srf / 2.0f;
+  const double srd = (double)fx.sample_rate;
+  const double kq = fmax(2.0 * (1.0 - (double)0.302f * 0.97), 0.03);
+  const int svf_type = delay_to_svf(d.filter_type);
+  const uint32_t mask = d.mask;
+  const int mode = d.mode;
+  for (int p0 = 0; p0 < frames; p0 += cap) {
+    const int P = frames - p0 < cap ? frames - p0 : cap;
+    __syncthreads();
+    // 0. the ten sequences of the piece
+    if (tid < DELAY_RAMP_SEQS - 1) {
+      PgSmooth sm = delay_ramp_smoother(d, tid);
+      float* dst = seq + tid * cap;
+      for (int k = 0; k < P; ++k) dst[k] = sm_next(sm);
+      delay_ramp_smoother(d, tid) = sm;
+    } else if (tid == 64) {  // lfo.run(), then the rate update while it ramps (delay.rs:343-347)
+      PgLfo l = d.lfo;
+      PgSmooth rate = d.lfo_rate;
+      for (int k = 0; k < P; ++k) {
+        a_lfo[k] = lfo_run(l);
+        if (sm_need_ramp(rate)) lfo_set_rate(l, fx.sample_rate, (double)sm_next(rate));
+      }
+      d.lfo = l; d.lfo_rate = rate;
+    }
+    if (tid == 0) red[0] = 0x7fffffff;
+    __syncthreads();
+    // per-frame delay in samples, cutoff and feedback (delay.rs:349-372), in place
+    for (int k = tid; k < P; k += nt) {
+      const float lv = a_lfo[k];
+      const float delay_ms = fmaxf(a_dly[k] + lv * a_dtime[k] * 50.0f, 1.0f);
+      a_dly[k] = delay_ms * 0.001f * srf;
+      a_cut[k] = clampf(a_cut[k] * powf(2.0f, lv * a_dflt[k] * 2.0f), 20.0f, nyq);
+      const float bfb = a_fb[k];
+      a_fb[k] = clampf(bfb + lv * a_dfb[k] * (1.0f - fabsf(bfb)), 0.0f, 0.999f);
+    }
+    __syncthreads();
+    int done = 0;
+    while (done < P) {
+      // chunk length: every read of the chunk must hit pre-chunk data -> shorter than the shortest delay of the frames it holds
+      int T = P - done;
+      for (;;) {
+        __syncthreads();
+        if (tid == 0) red[0] = 0x7fffffff;
+        __syncthreads();
+        int m = 0x7fffffff;
+        for (int k = tid; k < T; k += nt) { const int f = (int)floorf(a_dly[done + k]); m = m < f ? m : f; }
+        if (m != 0x7fffffff) atomicMin(&red[0], m);
+        __syncthreads();
+        const int t_max = red[0] - 2;
+        if (T <= t_max) break;
+        T = t_max < 1 ? 1 : t_max;  // (eligibility keeps the delay >= 66 samples: t_max >= 64)
+      }
+      float* s0 = sig + 2 * (p0 + done);
+      const uint32_t wp0[2] = {d.write_pos[0], d.write_pos[1]};
+      const float fb_in[2] = {d.fb[0], d.fb[1]};
+      __syncthreads();
+      // 1. taps + interpolation (dsp/delay.rs:118-134)
+      for (int s = tid; s < 2 * T; s += nt) {
+        const int nn = s >> 1, ch = s & 1;
+        const gdouble* line = (const gdouble*)d.line[ch];
+        const uint32_t wp = (wp0[ch] + (uint32_t)nn) & mask;
+        const double read_pos = (double)wp - (double)a_dly[done + nn];
+        const double read_pos_floor = floor(read_pos);
+        const double fraction = read_pos - read_pos_floor;
+        const long long index1 = (long long)read_pos_floor;
+        const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+        const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+        if (fc.idx_log) fc.idx_log[(p0 + done + nn) * 2 + ch] = (int32_t)i1;
+        const double v1 = line[i1], v2 = line[i2];
+        buf[REV_IDX(nn, ch)] = (double)(float)(v1 + (v2 - v1) * fraction);
+      }
+      __syncthreads();
+      // 2. wet path: SVF with the frame's cutoff -> saturate with the frame's drive -> DC filter
+      {
+        const float* cutp = a_cut + done;
+        auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
+          const double g = tan(F64_PI * (double)cutp[n] / srd);
+          if (svf_type == 0) { m0 = 0.0; m1 = 0.0; m2 = 1.0; } else if (svf_type == 2) { m0 = 0.0; m1 = 1.0; m2 = 0.0; } else { m0 = 1.0; m1 = -kq; m2 = -1.0; }
+          a1 = 1.0 / (1.0 + g * (g + kq));
+          a2 = g * a1;
+          a3 = g * a2;
+        };
+        svf_scan_time_varying<false>(coef, d.flt, buf, T, xchg);
+        if (tid == 0) svf_set(d.coef, svf_type, fx.sample_rate, cutp[T - 1], 0.302f);  // the coefficient cache as the serial loop leaves it
+      }
+      __syncthreads();
+      for (int s = tid; s < 2 * T; s += nt) { const int bi = REV_IDX(s >> 1, s & 1); buf[bi] = delay_saturate(buf[bi], a_drive[done + (s >> 1)]); }
+      __syncthreads();
+      dc_scan(d.dc, buf, T, xchg);
+      __syncthreads();
+      // 3. line writes and output with the frame's feedback, wet and width (delay.rs:374-452)
+      for (int s = tid; s < 2 * T; s += nt) {
+        const int nn = s >> 1, ch = s & 1;
+        const float left_input = s0[2 * nn], right_input = s0[2 * nn + 1];
+        const float clean_l = clampf((float)buf[REV_IDX(nn, 0)], -4.0f, 4.0f), clean_r = clampf((float)buf[REV_IDX(nn, 1)], -4.0f, 4.0f);
+        float prev_l = fb_in[0], prev_r = fb_in[1];
+        if (nn > 0) { prev_l = clampf((float)buf[REV_IDX(nn - 1, 0)], -4.0f, 4.0f); prev_r = clampf((float)buf[REV_IDX(nn - 1, 1)], -4.0f, 4.0f); }
+        const float fb_n = a_fb[done + nn], wet = a_wet[done + nn], width = a_width[done + nn];
+        float line_in;
+        if (mode == 0) line_in = (ch == 0 ? left_input + prev_l * fb_n : right_input + prev_r * fb_n);
+        else line_in = (ch == 0 ? (left_input + right_input) * 0.5f + prev_r * fb_n : prev_l * fb_n);
+        ((gdouble*)d.line[ch])[(wp0[ch] + (uint32_t)nn) & mask] = (double)line_in;
+        const float dry_gain = fminf((1.0f - wet) * 2.0f, 1.0f);
+        const float wet_gain = fminf(wet * 2.0f, 1.0f);
+        const float out_l = left_input * dry_gain + clean_l * wet_gain;
+        const float out_r = right_input * dry_gain + clean_r * wet_gain;
+        const float mid = (out_l + out_r) * 0.5f;
+        const float side = (out_l - out_r) * 0.5f;
+        const float res = ch == 0 ? mid + side * width : mid - side * width;
+        __builtin_amdgcn_wave_barrier();
+        s0[2 * nn + ch] = res;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        d.fb[0] = clampf((float)buf[REV_IDX(T - 1, 0)], -4.0f, 4.0f);
+        d.fb[1] = clampf((float)buf[REV_IDX(T - 1, 1)], -4.0f, 4.0f);
+        d.write_pos[0] = (wp0[0] + (uint32_t)T) & mask;
+        d.write_pos[1] = (wp0[1] + (uint32_t)T) & mask;
+      }
+      __syncthreads();
+      done += T;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (!delay_fast_eligible(fx)) return false;
   PgDelay& d = fx.u.delay;

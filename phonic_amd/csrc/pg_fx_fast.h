@@ -159,7 +159,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
     case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
     case 2: return !staged_unit || !(sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q: time-varying scan (not in the staged kernels)
     case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
-    case 4: return delay_fast_eligible(fx);
+    case 4: return delay_fast_eligible(fx) || (!staged_unit && delay_ramp_eligible(fx));  // ramping: delay_ramp_fast (not in the staged kernels)
     case 5: return reverb_fast_eligible(fx);
     case 6: return chorus_fast_eligible(fx);
     case 7: return comp_fast_eligible(fx);
@@ -252,7 +252,10 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       biquad_chain_fast(sig, n, e.coef, &e.st[0][0], 5, 5, fc);
       return true;
     } else return false;
-    case 4: if constexpr ((KMASK >> 4) & 1) return delay_fast(fx, sig, n, fc); else return false;
+    case 4: if constexpr ((KMASK >> 4) & 1) {
+      if (delay_fast(fx, sig, n, fc)) return true;
+      if constexpr ((KMASK >> 10) & 1) return delay_ramp_fast(fx, sig, n, fc); else return false;
+    } else return false;
     case 5: if constexpr ((KMASK >> 5) & 1) return reverb_fast(fx, sig, n, fc); else return false;
     case 6: if constexpr ((KMASK >> 6) & 1) return chorus_fast(fx, sig, n, fc); else return false;
     case 7: if constexpr ((KMASK >> 7) & 1) return comp_fast(fx, sig, n, fc); else return false;
