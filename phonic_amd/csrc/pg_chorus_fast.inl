@@ -59,6 +59,163 @@ DEVO bool chorus_fast_eligible(const PgFx& fx) {
   return floorf(2.0f + delay_in_samples) >= 66.0f && (2.0f + delay_in_samples + 2.0f * depth_in_samples) < (float)(c.mask - 8);
 }
 
+// ---- ChorusEffect while parameters ramp (chorus.rs:311-394 with any of its eight smoothers moving) ------------------------------------------
+// As for the Delay: single lanes lay out the per-frame value sequences of a piece with the serial loop's own calls — delay (spring), depth,
+// feedback, wet; the two LFO values incl. update_lfos while rate / phase ramp (chorus.rs:223-231: the oscillators are re-seated on
+// `current_phase` every frame for as long as either ramps); the pre-filter's cutoff / resonance while either ramps — then the piece is
+// rendered with per-frame values: time-varying SVF scan of the input, taps at the frame's delay position, line writes with the frame's
+// feedback, dry / wet with the frame's mix. Chunks are cut for the shortest delay of the frames they hold.
+constexpr int CHORUS_RAMP_SEQS = 8;  // delay, depth, feedback, wet, left LFO, right LFO, filter cutoff, filter resonance
+DEVO bool chorus_ramp_eligible(const PgFx& fx) {
+  const PgChorus& c = fx.u.chorus;
+  const float srf = (float)fx.sample_rate;
+  const PgSmooth& t = c.delay;
+  const float travel = t.kind == SM_SPRING && t.a > 0.0f ? fabsf(t.b) / (t.a * t.comp) : 0.0f;
+  const float lo = fmaxf(fminf(t.current, t.target) - travel, 0.0f), hi = fmaxf(t.current, t.target) + travel;
+  const float depth_hi = c.lfo_range * fmaxf(c.depth.current, c.depth.target);
+  if (!(depth_hi >= 0.0f)) return false;
+  return floorf(2.0f + lo * 0.999f * srf * 0.001f) >= 66.0f && (2.0f + hi * 1.001f * srf * 0.001f + 2.0f * depth_hi) < (float)(c.mask - 8);
+}
+DEVO bool chorus_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
+  if (!chorus_ramp_eligible(fx)) return false;
+  PgChorus& c = fx.u.chorus;
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int frames = n_samples / 2;
+  if (frames == 0) return true;
+  int cap = fc.tmp_floats / CHORUS_RAMP_SEQS;
+  if (cap > nt) cap = nt;  // two (frame, channel) items per lane at most: the interpolated outputs wait in two registers across the barrier
+  if (cap < 8 || nt != 256) return false;
+  double* buf = (double*)fc.scratch;
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
+  int* red = (int*)(xchg + 4);
+  float* seq = fc.tmp;
+  float* a_dly = seq, *a_depth = seq + cap, *a_fb = seq + 2 * cap, *a_wet = seq + 3 * cap, *a_ll = seq + 4 * cap, *a_lr = seq + 5 * cap, *a_cut = seq + 6 * cap, *a_res = seq + 7 * cap;
+  const float srf = (float)fx.sample_rate, nyq = srf / 2.0f;
+  const double srd = (double)fx.sample_rate;
+  const uint32_t mask = c.mask;
+  const int svf_type = delay_to_svf(c.filter_type);
+  for (int p0 = 0; p0 < frames; p0 += cap) {
+    const int P = frames - p0 < cap ? frames - p0 : cap;
+    float* sp = sig + 2 * p0;
+    __syncthreads();
+    // 0. the sequences of the piece
+    if (tid < 4) {
+      PgSmooth& g = tid == 0 ? c.delay : (tid == 1 ? c.depth : (tid == 2 ? c.feedback : c.wet));
+      PgSmooth sm = g;
+      float* dst = seq + tid * cap;
+      for (int k = 0; k < P; ++k) { const float v = sm_next(sm); dst[k] = tid == 2 ? clampf(v, -0.999f, 0.999f) : v; }
+      g = sm;
+    } else if (tid == 64) {  // update_lfos while rate / phase ramp, then lfo.run() of both oscillators (chorus.rs:327-329,353-354)
+      PgSmooth rate = c.rate, phase = c.phase;
+      PgLfo o0 = c.osc[0], o1 = c.osc[1];
+      const double current_phase = c.current_phase;
+      for (int k = 0; k < P; ++k) {
+        if (sm_need_ramp(rate) || sm_need_ramp(phase)) {
+          const double r = (double)sm_next(rate);
+          lfo_set_rate(o0, fx.sample_rate, r); lfo_set_rate(o1, fx.sample_rate, r);
+          const double phase_offset = (double)sm_next(phase);
+          lfo_set_phase_degrees(o0, (float)current_phase);
+          lfo_set_phase_degrees(o1, (float)(current_phase + phase_offset));
+        }
+        a_ll[k] = lfo_run(o0);
+        a_lr[k] = lfo_run(o1);
+      }
+      c.rate = rate; c.phase = phase; c.osc[0] = o0; c.osc[1] = o1;
+    } else if (tid == 128) {  // the pre-filter's parameters: next() of both while either ramps (chorus.rs:332-345), else the set in place
+      PgSmooth fr = c.freq, rs = c.res;
+      float cut = c.coef.cutoff, res = c.coef.resonance;
+      for (int k = 0; k < P; ++k) {
+        if (sm_need_ramp(fr) || sm_need_ramp(rs)) { cut = clampf(sm_next(fr), 20.0f, nyq); res = sm_next(rs); }
+        a_cut[k] = cut; a_res[k] = res;
+      }
+      c.freq = fr; c.res = rs;
+    }
+    // 1. pre-filter over the piece with the frame's coefficients (svf.rs:137-168,211-222)
+    for (int s = tid; s < 2 * P; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sp[s];
+    __syncthreads();
+    {
+      auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
+        const double g = tan(F64_PI * (double)a_cut[n] / srd);
+        const double kq = fmax(2.0 * (1.0 - (double)a_res[n] * 0.97), 0.03);
+        if (svf_type == 0) { m0 = 0.0; m1 = 0.0; m2 = 1.0; } else if (svf_type == 2) { m0 = 0.0; m1 = 1.0; m2 = 0.0; } else { m0 = 1.0; m1 = -kq; m2 = -1.0; }
+        a1 = 1.0 / (1.0 + g * (g + kq));
+        a2 = g * a1;
+        a3 = g * a2;
+      };
+      svf_scan_time_varying<false>(coef, c.flt, buf, P, xchg);
+      if (tid == 0) svf_set(c.coef, svf_type, fx.sample_rate, a_cut[P - 1], a_res[P - 1]);
+    }
+    __syncthreads();
+    // 2. chunks
+    int done = 0;
+    while (done < P) {
+      int T = P - done;
+      for (;;) {  // shorter than the shortest delay position of the frames it holds (chorus.rs:356-357: 2 + delay + (1 + lfo) * depth, lfo >= -1 up to the parabola's overshoot)
+        __syncthreads();
+        if (tid == 0) red[0] = 0x7fffffff;
+        __syncthreads();
+        int m = 0x7fffffff;
+        for (int k = tid; k < T; k += nt) { const int f = (int)floorf(2.0f + a_dly[done + k] * srf * 0.001f); m = m < f ? m : f; }
+        if (m != 0x7fffffff) atomicMin(&red[0], m);
+        __syncthreads();
+        const int t_max = red[0] - 4;
+        if (T <= t_max) break;
+        T = t_max < 1 ? 1 : t_max;
+      }
+      const uint32_t wp0[2] = {c.write_pos[0], c.write_pos[1]};
+      float outv[2] = {0.0f, 0.0f};
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int s = tid + it * 256;
+        if (s < 2 * T) {
+          const int nn = done + (s >> 1), ch = s & 1;
+          const float delay_in_samples = a_dly[nn] * srf * 0.001f;
+          const float depth_in_samples = c.lfo_range * a_depth[nn];
+          const float lfo = ch == 0 ? a_ll[nn] : a_lr[nn];
+          const float delay_pos = 2.0f + delay_in_samples + (1.0f + lfo) * depth_in_samples;
+          const gdouble* line = (const gdouble*)c.line[ch];
+          const uint32_t wp = (wp0[ch] + (uint32_t)(s >> 1)) & mask;
+          const double read_pos = (double)wp - (double)delay_pos;
+          const double read_pos_floor = floor(read_pos);
+          const double fraction = read_pos - read_pos_floor;
+          const long long index1 = (long long)read_pos_floor;
+          const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+          const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+          if (fc.idx_log) fc.idx_log[(p0 + nn) * 2 + ch] = (int32_t)i1;
+          const double v1 = line[i1], v2 = line[i2];
+          const float out = (float)(v1 + (v2 - v1) * fraction);
+          outv[it] = out;
+          const int bi = REV_IDX(nn, ch);
+          buf[bi] = (double)(float)buf[bi] + (double)out * (double)a_fb[nn];   // what this frame writes into the line
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int s = tid + it * 256;
+        if (s < 2 * T) {
+          const int nn = done + (s >> 1), ch = s & 1;
+          ((gdouble*)c.line[ch])[(wp0[ch] + (uint32_t)(s >> 1)) & mask] = buf[REV_IDX(nn, ch)];
+          const float wet = a_wet[nn];
+          sp[2 * nn + ch] = sp[2 * nn + ch] * (1.0f - wet) + outv[it] * wet;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { c.write_pos[0] = (wp0[0] + (uint32_t)T) & mask; c.write_pos[1] = (wp0[1] + (uint32_t)T) & mask; }
+      __syncthreads();
+      done += T;
+    }
+  }
+  if (tid == 0) {  // block-end phase bookkeeping (chorus.rs:388-393)
+    const double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;
+    c.current_phase += (double)n_samples / 2.0 * phase_inc;
+    while (c.current_phase >= 2.0 * F64_PI) c.current_phase -= 2.0 * F64_PI;
+  }
+  __syncthreads();
+  return true;
+}
+
 DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   if (!chorus_fast_eligible(fx)) return false;
   PgChorus& c = fx.u.chorus;

@@ -161,7 +161,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
     case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
     case 4: return delay_fast_eligible(fx) || (!staged_unit && delay_ramp_eligible(fx));  // ramping: delay_ramp_fast (not in the staged kernels)
     case 5: return reverb_fast_eligible(fx);
-    case 6: return chorus_fast_eligible(fx);
+    case 6: return chorus_fast_eligible(fx) || (!staged_unit && chorus_ramp_eligible(fx));
     case 7: return comp_fast_eligible(fx);
     case 8: return true;
     case 9: return !sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f);
@@ -257,7 +257,10 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       if constexpr ((KMASK >> 10) & 1) return delay_ramp_fast(fx, sig, n, fc); else return false;
     } else return false;
     case 5: if constexpr ((KMASK >> 5) & 1) return reverb_fast(fx, sig, n, fc); else return false;
-    case 6: if constexpr ((KMASK >> 6) & 1) return chorus_fast(fx, sig, n, fc); else return false;
+    case 6: if constexpr ((KMASK >> 6) & 1) {
+      if (chorus_fast(fx, sig, n, fc)) return true;
+      if constexpr ((KMASK >> 10) & 1) return chorus_ramp_fast(fx, sig, n, fc); else return false;
+    } else return false;
     case 7: if constexpr ((KMASK >> 7) & 1) return comp_fast(fx, sig, n, fc); else return false;
     case 8: if constexpr ((KMASK >> 8) & 1) return gate_fast(fx, sig, n, fc); else return false;
     case 9: if constexpr ((KMASK >> 9) & 1) {  // DistortionEffect, no ramps (distortion.rs:331-341)

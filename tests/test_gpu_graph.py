@@ -1172,7 +1172,7 @@ def test_resampled_source_behind_the_file_source(file_rate, source_rate, channel
     assert gg.device_errors() == 0
 
 
-def test_eq5_compressor_and_delay_ramps_stay_on_the_time_parallel_kernels():
+def test_eq5_compressor_delay_and_chorus_ramps_stay_on_the_time_parallel_kernels():
     """While a smoother moves, FilterEffect (round 1), Eq5Effect and the Compressor's makeup gain (round 2) keep a time-parallel path: the
     smoothers' f32 value sequences are laid out by single lanes, the per-frame coefficients / gains are computed by all lanes, the
     recurrence runs as the time-varying blocked scan. A sub-mixer Eq5 -> Compressor gets gain / frequency / bandwidth / makeup updates;
@@ -1192,9 +1192,18 @@ def test_eq5_compressor_and_delay_ramps_stay_on_the_time_parallel_kernels():
         dl = g.add_effect(m, _capi.FX_DELAY, params={"dlay": 25.0, "fdbk": 0.6, "lfdt": 0.05, "lfdf": 0.3, "lfor": 3.0})
         g.add_voice(m, workloads.tone_buffer(7, 48000, 0.3), 2, 48000, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
         ids.append((dl, dl))
+        m = g.add_mixer()   # ChorusEffect: rate + phase (update_lfos per frame), delay (spring), depth, pre-filter frequency ramp together
+        ch = g.add_effect(m, _capi.FX_CHORUS, params={"rate": 2.0, "dlay": 15.0, "fltf": 8000.0})
+        g.add_voice(m, workloads.tone_buffer(9, 48000, 0.3), 2, 48000, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        ids.append((ch, ch))
         return ids
 
     def act(g, ids, pos):
+        g.schedule_param(ids[4][0], "rate", 6.0, pos + 20)
+        g.schedule_param(ids[4][0], "phas", 0.4, pos + 20)
+        g.schedule_param(ids[4][0], "dlay", 40.0, pos + 500)
+        g.schedule_param(ids[4][0], "dpth", 0.7, pos + 500)
+        g.schedule_param(ids[4][0], "fltf", 1200.0, pos + 800)
         g.schedule_param(ids[3][0], "dlay", 60.0, pos + 50)
         g.schedule_param(ids[3][0], "fdbk", 0.2, pos + 50)
         g.schedule_param(ids[3][0], "wet_", 0.9, pos + 400)
@@ -1218,6 +1227,6 @@ def test_eq5_compressor_and_delay_ramps_stay_on_the_time_parallel_kernels():
                 deferred.append(g.deferred_units())
         outs.append(o.reshape(-1))
     compare(outs[0], outs[1])
-    assert deferred[3] == 4          # the block with the commands: exact generic kernel
+    assert deferred[3] == 5          # the block with the commands: exact generic kernel
     assert deferred[4] == 0 and deferred[5] == 0, deferred   # still ramping (Eq5 gain: ~0.1 s; the delay time's spring: ~0.4 s), yet on the fast kernel
     assert gg.device_errors() == 0
