@@ -267,7 +267,9 @@ def main():
         nonlocal pos
         done = 0
         while done < n_blocks:
-            k = min(sb, n_blocks - done, ring.room())
+            left = n_blocks - done
+            parts = (left + sb - 1) // sb                      # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
+            k = min((left + parts - 1) // parts, ring.room())  # every launch pays about one block time of ramp-up and drain
             bus = ring.slots(k)
             w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
             if w != k * n_samples:
