@@ -282,17 +282,19 @@ def main():
             pos += k * block
             done += k
 
+    dist_on = world > 1 or force_dist  # (a forced one-rank group goes through the same barriers and reductions)
+
     def leg(n_blocks):
         torch.cuda.synchronize()
         g.kernel_ms(reset=True)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         render(n_blocks)
         ring.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -303,7 +305,7 @@ def main():
     ring.drain()
     legs = [leg(args.steps) for _ in range(max(1, args.repeats))]
     dts = [l[0] for l in legs]
-    if world > 1:
+    if dist_on:
         t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dts = [float(x) for x in t.tolist()]

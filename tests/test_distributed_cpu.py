@@ -143,3 +143,59 @@ def test_master_bus_ring_super_block_reduce_two_ranks():
     assert np.all(second[1][: n] == total(8)) and np.all(second[1][n : 2 * n] == total(9)) and np.all(second[1][2 * n :] == total(10))
     assert np.all(second[0][: n] == total(11))                       # reduced alone by drain()
     assert np.all(second[0][n : 2 * n] == total(6)) and np.all(second[0][2 * n :] == total(7))   # left from the reduce of blocks 5-7
+
+
+def _ring_multi_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phonic_amd.parallel import MasterBusRing
+
+    n, m = 4, 6
+    ring = MasterBusRing(n, m, "cpu", n_buffers=2, root=0)
+    step = 0
+
+    def render(k):  # k consecutive blocks in ONE call, as bench.py renders a super-block
+        nonlocal step
+        assert 1 <= k <= ring.room()
+        view = ring.slots(k)
+        assert view.numel() == k * n
+        for j in range(k):
+            view[j * n:(j + 1) * n] = float((step + j + 1) * (1 if rank == 0 else 1000))
+        ring.submit(k)
+        step += k
+
+    for k in (4, 2, 6, 3, 3, 5):   # 4 + 2 fill super-block 0 (reduce), 6 = a whole one, 3 + 3, then 5 left partial
+        render(k)
+    last_before = ring.last_block().clone()
+    ring.drain()
+    if rank == 0:
+        q.put(([b.clone().numpy() for b in ring.buffers], last_before.numpy(), ring.last_block().clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_master_bus_ring_multi_block_slots_two_ranks():
+    """The super-block form of the ring (bench.py renders several blocks per pg_graph_write_device call): slots(k) hands out k consecutive
+    block slots of the buffer being filled, submit(k) advances by k and issues the reduce when the super-block is complete, last_block()
+    is the block submitted last (summed over ranks on the root once drained)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_multi_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bufs, last_before, last_after = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, m = 4, 6
+    total = lambda step: float((step + 1) * 1001)
+    # 23 blocks: super-blocks 0..2 complete (buffers 0, 1, 0), super-block 3 (buffer 1) holds 5 blocks, reduced by drain()
+    for j in range(m):
+        assert np.all(bufs[0][j * n:(j + 1) * n] == total(12 + j))      # super-block 2 overwrote super-block 0 in buffer 0
+    for j in range(5):
+        assert np.all(bufs[1][j * n:(j + 1) * n] == total(18 + j))
+    assert np.all(last_before == 23.0) and np.all(last_after == total(22))
