@@ -269,7 +269,9 @@ def main():
         while done < n_blocks:
             left = n_blocks - done
             parts = (left + sb - 1) // sb                      # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
-            k = min((left + parts - 1) // parts, ring.room())  # every launch pays about one block time of ramp-up and drain
+            k = min((left + parts - 1) // parts, ring.m)       # every launch pays about one block time of ramp-up and drain
+            if k > ring.room():
+                ring.close()                                    # (the ring's super-block ends where the call does)
             bus = ring.slots(k)
             w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
             if w != k * n_samples:

@@ -69,6 +69,15 @@ class MasterBusRing:
             self.pending[k] = dist.reduce(self.buffers[k], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return k, j
 
+    def close(self):
+        """End the super-block being filled early (the caller's next call does not fit into it): its blocks are reduced now, asynchronously,
+        and the next block opens the next buffer. Every rank must close at the same step (the bench's call sizes depend on the step only)."""
+        k, j = self._where()
+        if j != 0:
+            if self.distributed:
+                self.pending[k] = dist.reduce(self.buffers[k][: j * self.n_samples], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.step += self.m - j
+
     def last_block(self):
         """View of the block submitted last (call after drain(): on the root it then holds the reduced sum)."""
         if getattr(self, "_last", None) is None:
@@ -77,11 +86,7 @@ class MasterBusRing:
         return self.buffers[k][j * self.n_samples : (j + 1) * self.n_samples]
 
     def drain(self):
-        k, j = self._where()
-        if j != 0:  # every rank has rendered the same number of blocks: the partly filled super-block still owes its reduce
-            if self.distributed:
-                self.pending[k] = dist.reduce(self.buffers[k][: j * self.n_samples], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.step += self.m - j
+        self.close()  # every rank has rendered the same number of blocks: a partly filled super-block still owes its reduce
         for i in range(self.n_buffers):
             if self.pending[i] is not None:
                 self.pending[i].wait()

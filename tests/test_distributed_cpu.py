@@ -166,8 +166,13 @@ def _ring_multi_worker(rank, world, port, q):
         ring.submit(k)
         step += k
 
-    for k in (4, 2, 6, 3, 3, 5):   # 4 + 2 fill super-block 0 (reduce), 6 = a whole one, 3 + 3, then 5 left partial
+    for k in (4, 2, 6, 3):      # 4 + 2 fill super-block 0 (reduce), 6 = a whole one, 3 open the third
         render(k)
+    ring.close()                # ... which ends early: its 3 blocks are reduced, the next block opens the next buffer
+    render(3)
+    assert ring.room() == 3
+    ring.close()                # (what bench.py does when its next call is larger than the room left)
+    render(5)
     last_before = ring.last_block().clone()
     ring.drain()
     if rank == 0:
@@ -193,9 +198,11 @@ def test_master_bus_ring_multi_block_slots_two_ranks():
         assert p.exitcode == 0
     n, m = 4, 6
     total = lambda step: float((step + 1) * 1001)
-    # 23 blocks: super-blocks 0..2 complete (buffers 0, 1, 0), super-block 3 (buffer 1) holds 5 blocks, reduced by drain()
+    # buffer 0: super-block 0 (blocks 0-5), then the closed one (12-14 over its first three slots), then the last call (18-22);
+    # buffer 1: super-block 1 (blocks 6-11), then blocks 15-17 over its first three slots. Every slot holds a sum over both ranks.
+    expect0 = [18, 19, 20, 21, 22, 5]
+    expect1 = [15, 16, 17, 9, 10, 11]
     for j in range(m):
-        assert np.all(bufs[0][j * n:(j + 1) * n] == total(12 + j))      # super-block 2 overwrote super-block 0 in buffer 0
-    for j in range(5):
-        assert np.all(bufs[1][j * n:(j + 1) * n] == total(18 + j))
+        assert np.all(bufs[0][j * n:(j + 1) * n] == total(expect0[j])), (j, bufs[0])
+        assert np.all(bufs[1][j * n:(j + 1) * n] == total(expect1[j])), (j, bufs[1])
     assert np.all(last_before == 23.0) and np.all(last_after == total(22))
