@@ -20,7 +20,7 @@ struct FastCtx {
                      // of the current process call; nullptr (a compile-time constant in the hot kernels: the stores fold away) = not collected
 };
 
-constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 129 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
+constexpr size_t FAST_SCRATCH_BYTES = (2 * 1024 + 128 + 8) * 8 + 16 * 40 + 16 * 8 + 13 * 16 + 4 * 8 + 9 * 16 * 2 * 8 + 8 * 65 * 2 * 8 + 64;  // reverb: f64 chunk buffer + phase records + epilogue gets
 // What the other time-parallel paths carve from the arena: a launch whose units hold no Reverb gets a smaller arena (pg_fast_scratch_bytes)
 // and with it more resident workgroups per CU.
 constexpr size_t FAST_SCRATCH_SCAN_BYTES = (2 * 1024 + 128 + 8) * 8 + 512;                           // Filter / Eq5 / Delay / Gain's DC filter: chunk buffer + scan hand-over + coefficients

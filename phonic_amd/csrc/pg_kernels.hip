@@ -558,9 +558,12 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
 // LDS, the dry signal is parked in the unit's output row during stage 2); pg_stage1/2/3_kernel are one launch per stage with
 // the chunk buffer handed over through HBM/L2 (kept for profiling the stages in isolation).
 // LDS plan (all stages): [PgFx][ctl 128][red 64][arena ...]; the arena starts with bufA in every stage.
-//   stage 1: arena = union(source scratch, bufA .. xchg), then [sig][tmp][PgVoice]      36.6 KB at 1024 frames
-//   stage 2: arena = full reverb arena (bufA, records, anchors, rotation table)          38.6 KB
-//   stage 3: arena = bufA .. xchg, then [sig]                                            27.9 KB
+//   stage 1: arena = union(source scratch, bufA .. xchg), then [sig][tmp][PgVoice]                        36.6 KB at 1024 frames
+//   stage 2: single launch: bufA .. xchg (inside the union), [sig] where stage 1 left it, then anchors + rotation table   38.9 KB
+//            (round 2: the table holds |j| <= 64 only, which makes room for the dry signal: it no longer travels to the unit's output
+//            row and back — 16 B per voice-frame less HBM traffic and no reload at the top of stage 3);
+//            per-stage launches: the plain reverb arena (bufA, records, anchors, rotation table)           30.4 KB
+//   stage 3: single launch: bufA .. xchg, [sig] in place; per-stage launches: bufA .. xchg, then [sig]     27.9 KB
 __device__ __forceinline__ int stage_image_doubles(int T) { return 2 * T + (T >> 3) + 2; }
 __device__ __forceinline__ void stage_store_image(double* g, const double* lds, int T) {
   const int n2 = (stage_image_doubles(T) + 1) >> 1;
@@ -678,7 +681,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     __syncthreads();
     if (!RESIDENT || !(flags & PG_STAGE_ACTIVE)) for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
   }
-  for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];  // the dry signal waits in the unit's output row
+  if (!RESIDENT) for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];  // per-stage launches: the dry signal waits in the unit's output row
   if (!RESIDENT && tid == 0) unit.stage_flags = flags;  // (the single-launch kernels hand the flags over in registers)
   PG_STAMP(L.diag, 14);
   // schedule cache (ratio < 0.5 only): representatives replay the next block's resampler schedule. A single voice that took the
@@ -701,7 +704,7 @@ __device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flag
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx;
-  const RevLds m = rev_lds(m0.arena);
+  const RevLds m = rev_lds(m0.arena, RESIDENT ? m0.arena + STAGE1_UNION + (((size_t)N * 8 + 15) & ~15ull) : nullptr);  // (single launch: behind the dry signal)
   if (!RESIDENT) {
     PgFx& gfx = stage_reverb(L, unit);
     for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
@@ -733,15 +736,17 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
-  float* sig = (float*)(m0.arena + ((STAGE_ARENA_PREFIX + 15) & ~15ull));
+  float* sig = (float*)(m0.arena + (RESIDENT ? STAGE1_UNION : ((STAGE_ARENA_PREFIX + 15) & ~15ull)));  // single launch: where stage 1 left it
   __syncthreads();
-  // The dry signal (stage 1 left it in the unit's output row) is only needed at the end of the tail. It travels global -> LDS
-  // directly (lds_dma_dword: no registers, no wait here) while the two scans run; a dependent load at this point would cost a
-  // full trip through the loaded memory system. Lane l of wave w, trip k: sample k * 256 + w * 64 + l.
+  // Per-stage launches: the dry signal (stage 1 left it in the unit's output row) is only needed at the end of the tail. It travels
+  // global -> LDS directly (lds_dma_dword: no registers, no wait here) while the two scans run; a dependent load at this point would
+  // cost a full trip through the loaded memory system. Lane l of wave w, trip k: sample k * 256 + w * 64 + l.
+  if (!RESIDENT) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = tid + k * 256;
-    if (i < 2 * N) lds_dma_dword(out + i, sig + k * 256 + (tid & ~63));
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      if (i < 2 * N) lds_dma_dword(out + i, sig + k * 256 + (tid & ~63));
+    }
   }
   if (!(flags & PG_STAGE_SKIPPED)) {
     bool all_bypassed = (flags & PG_STAGE_ALL_BYPASSED) != 0;
@@ -754,7 +759,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       __syncthreads();
       RevBlock b;
       (void)rev_block_params(*lfx, m, ctl, b);
-      rev_tail_impl<true>(lfx->u.reverb, sig, N, m, b, L.diag);
+      rev_tail_impl<!RESIDENT>(lfx->u.reverb, sig, N, m, b, L.diag);
       PG_STAMP(L.diag, 60);
       if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, L.sample_rate, ctl, red);
       PG_STAMP(L.diag, 61);
@@ -765,7 +770,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
     __syncthreads();
     if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
   }
-  lds_dma_wait();  // (bypassed / skipped reverb: the dry signal is the output)
+  if (!RESIDENT) lds_dma_wait();  // (bypassed / skipped reverb: the dry signal is the output)
   __syncthreads();
   PG_STAMP(L.diag, 62);
   // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77) ----
@@ -997,7 +1002,7 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
 }
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0) {
   size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
-  size_t scratch = SRC_SCRATCH_BYTES > FAST_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : FAST_SCRATCH_BYTES;
+  size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }
@@ -1008,7 +1013,8 @@ size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
   if (stage == 1) return s1;
   if (stage == 2) return s2;
   if (stage == 3) return s3;
-  return (s1 > s2 ? (s1 > s3 ? s1 : s3) : (s2 > s3 ? s2 : s3));  // stage 0: the fused single launch
+  const size_t s2r = STAGE_FIXED + STAGE1_UNION + (((size_t)n_frames * 8 + 15) & ~15ull) + REV_TABLES_BYTES;  // stage 0, the single launch: the dry signal stays
+  return s1 > s2r ? s1 : s2r;
 }
 // The staged pipeline of one round (units flagged `staged`): single_launch = pg_stage_fused_kernel, else three launches
 // (L.stage_buf must then hold n_units rows).

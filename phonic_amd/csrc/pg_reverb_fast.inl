@@ -106,7 +106,11 @@ DEVO void ring_advance(RevRing& R, uint32_t T) {  // T in [1, m]
   R.p0 = np; R.pe = np; R.stale = 0;
 }
 // element address of (ring position, channel) in the [pos][2] f64 ring
-DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) { return (gdouble*)R.buf + ((pos << 1) | (uint32_t)ch); }
+// (a 32-bit byte offset on the uniform base: the access is `global_load/store v, v_off, s[base]`, no 64-bit address arithmetic per lane)
+DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) {
+  typedef __attribute__((address_space(1))) char gchar;
+  return (gdouble*)((gchar*)R.buf + (size_t)(uint32_t)((pos << 4) | ((uint32_t)ch << 3)));
+}
 
 DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
   double v = (double)x;
@@ -298,10 +302,15 @@ struct RevLds {   // LDS carve-up of the reverb arena
   RevDesc* desc;  // [13]
   double* xchg;   // biquad scan hand-over
   double* anch;   // [9][16] {sin, cos} anchors: 8 sub-chunks + the epilogue
-  double* vtab;   // vibrato rotation table (LDS copy)
+  double* vtab;   // vibrato rotation table (LDS copy): [8][REV_VTAB_N] {cos, sin}
   char* slack;    // 64 bytes
 };
-DEVO RevLds rev_lds(char* scratch) {
+// The mid stage's tables (anchors, rotation table, slack: REV_TABLES_BYTES) follow the prefix bufA .. xchg, or start at `tables` when the
+// caller keeps something of its own behind the prefix (the staged kernels: the unit's dry signal stays in LDS through the mid stage).
+constexpr int REV_VTAB_HALF = 64;               // sub-chunks are 128 frames around their anchor: |j| <= 64
+constexpr int REV_VTAB_N = REV_VTAB_HALF + 1;   // entries per line held in LDS (the table in HBM has 129 per line)
+constexpr size_t REV_TABLES_BYTES = 9 * 16 * 2 * 8 + 8 * REV_VTAB_N * 2 * 8 + 64;
+DEVO RevLds rev_lds(char* scratch, char* tables = nullptr) {
   RevLds m;
   m.bufA = (double*)scratch;
   char* lp = scratch + REV_BUF_DOUBLES * 8;
@@ -309,8 +318,9 @@ DEVO RevLds rev_lds(char* scratch) {
   m.gl = (double*)lp;     lp += 16 * 8;
   m.desc = (RevDesc*)lp;  lp += 13 * sizeof(RevDesc);
   m.xchg = (double*)lp;   lp += 4 * 8;
+  if (tables) lp = tables;
   m.anch = (double*)lp;   lp += 9 * 16 * 2 * 8;
-  m.vtab = (double*)lp;   lp += 8 * 129 * 2 * 8;
+  m.vtab = (double*)lp;   lp += 8 * REV_VTAB_N * 2 * 8;
   m.slack = lp;
   return m;
 }
@@ -320,15 +330,21 @@ struct RevBlock {  // per-block uniform parameters
   uint32_t predelay, t_mid;
 };
 
-// vibrato rotation table -> LDS: 8*129 {cos, sin} pairs, 16-byte loads all in flight before the first LDS store (caller syncs)
+// vibrato rotation table -> LDS: entries 0 .. REV_VTAB_HALF of each line's {cos, sin} pairs (the rotation by -j is the transpose: cos is even,
+// sin odd), 16-byte loads all in flight before the first LDS store (caller syncs)
 DEVO void rev_load_vtab(const PgReverb& r, const RevLds& m) {
   const int tid = pg_tid();
   const gdouble* tg = (const gdouble*)r.vib_tab;
-  double t0[5], t1[5];
+  constexpr int TRIPS = (8 * REV_VTAB_N + 255) / 256;
+  double t0[TRIPS], t1[TRIPS];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; const int j = i < 8 * 129 ? i : 0; t0[k] = tg[2 * j]; t1[k] = tg[2 * j + 1]; }
+  for (int k = 0; k < TRIPS; ++k) {
+    const int i = tid + k * 256;
+    const int line = i / REV_VTAB_N, j = (i < 8 * REV_VTAB_N) ? line * 129 + (i - line * REV_VTAB_N) : 0;
+    t0[k] = tg[2 * j]; t1[k] = tg[2 * j + 1];
+  }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { const int i = tid + k * 256; if (i < 8 * 129) { m.vtab[2 * i] = t0[k]; m.vtab[2 * i + 1] = t1[k]; } }
+  for (int k = 0; k < TRIPS; ++k) { const int i = tid + k * 256; if (i < 8 * REV_VTAB_N) { m.vtab[2 * i] = t0[k]; m.vtab[2 * i + 1] = t1[k]; } }
 }
 
 // block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets; cached in the effect
@@ -442,12 +458,14 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
     for (int i = 0; i < 12; ++i) D[i] = rev_ring_uniform(desc[i]);
 
     // ---- vibrato anchors for the whole chunk, one lane per (sub-chunk, line, channel): sin/cos (accurate libm) of the exact
-    // phase of the sub-chunk's first item; inside the sub-chunk sin(phase_n) follows by the angle-addition rotation with
-    // the per-line table. Slot 8 = the epilogue's phase (after the chunk's last step).
+    // phase of the sub-chunk's middle item (or the chunk's end, if that comes first); inside the sub-chunk sin(phase_n) follows by
+    // the angle-addition rotation by j = n - anchor steps, |j| <= 64, with the per-line table. Slot 8 = the epilogue's phase (after
+    // the chunk's last step).
     if (tid < 9 * 16) {
       const int sub = tid >> 4, lc = tid & 15;
-      const uint32_t nb = sub == 8 ? (uint32_t)T : (uint32_t)(sub == 0 ? 1 : sub * (nt / 2));
-      if (sub == 8 || nb <= (uint32_t)T) {
+      const int mid_n = sub * (nt / 2) + REV_VTAB_HALF;
+      const uint32_t nb = (sub == 8 || mid_n > T) ? (uint32_t)T : (uint32_t)mid_n;
+      if (sub == 8 || sub * (nt / 2) < T) {
         const RevRec rc = rec[lc];
         const double pb = rev_phase_at(rc, nb);
         anch[tid * 2] = sin(pb);
@@ -479,9 +497,12 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
                           // a spilled tap would put an `s_waitcnt vmcnt(0)` in the middle of the load issue
         if (n >= 1) {
           // sin(phase_n) ~= sin(pb + j*d): pb = the sub-chunk's exact anchor phase, j*d = tabulated rotation. The reference's
-          // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 128 * 2^-52 * |p|
-          // (< 6e-14 in the tap position), far below the 1-ulp spread between libm implementations of sin itself.
-          const int jb = n - (base > 0 ? base : 1);
+          // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 64 * 2^-52 * |p|
+          // (< 3e-14 in the tap position), far below the 1-ulp spread between libm implementations of sin itself.
+          const int n_anchor = base + REV_VTAB_HALF < T ? base + REV_VTAB_HALF : T;
+          const int js = n - n_anchor;                      // in [-64, 63]
+          const int jb = js < 0 ? -js : js;
+          const unsigned long long st_sign = js < 0 ? 0x8000000000000000ull : 0ull;  // sin(-x) = -sin(x)
           const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 2;
           // The rotation operands of line i + 1 are fetched from LDS before line i is evaluated (two register sets): one
           // exposed LDS round trip per sub-chunk instead of one per line.
@@ -492,10 +513,11 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
             const RevRing ld = D[i];
             if (i + 1 < 8) {
               const double* an = anb + ((i + 1) * 2 + ch) * 2;
-              q_ct[(i + 1) & 1] = vtab[((i + 1) * 129 + jb) * 2]; q_st[(i + 1) & 1] = vtab[((i + 1) * 129 + jb) * 2 + 1];
+              q_ct[(i + 1) & 1] = vtab[((i + 1) * REV_VTAB_N + jb) * 2]; q_st[(i + 1) & 1] = vtab[((i + 1) * REV_VTAB_N + jb) * 2 + 1];
               q_a0[(i + 1) & 1] = an[0]; q_a1[(i + 1) & 1] = an[1];
             }
-            const double sn = fma(q_a0[i & 1], q_ct[i & 1], q_a1[i & 1] * q_st[i & 1]);
+            const double st = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_st[i & 1]) ^ st_sign));
+            const double sn = fma(q_a0[i & 1], q_ct[i & 1], q_a1[i & 1] * st);
             const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;
             const double w_floor = floor(working);
             tfr[i] = (uint32_t)((working - w_floor) * 4294967296.0);
