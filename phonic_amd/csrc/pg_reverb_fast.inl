@@ -101,16 +101,46 @@ DEVO uint32_t ring_at(const RevRing& R, uint32_t i) {   // == rev_at(desc, i) fo
   if (R.stale) { if (i == 0) v = R.p0; }  // uniform (scalar) branch, practically never taken
   return v;
 }
+// The same for a ring whose position is inside the ring (p0 <= delay; reverb_fast_eligible checks it for the twelve rings of the mid stage):
+// three scalars per ring instead of five — the mid stage holds twelve of them — and no special case in the address arithmetic.
+struct RevRingN {
+  double* buf;
+  uint32_t pe, m;
+};
+DEVO RevRingN rev_ringn_uniform(const RevDesc& d) {
+  const unsigned long long b = (unsigned long long)d.buf;
+  const uint32_t lo = uni_u32((uint32_t)b), hi = uni_u32((uint32_t)(b >> 32));
+  RevRingN u;
+  u.buf = (double*)(((unsigned long long)hi << 32) | lo);
+  u.pe = uni_u32(d.p0);
+  u.m = uni_u32(d.delay) + 1;
+  return u;
+}
+DEVO uint32_t ring_at(const RevRingN& R, uint32_t i) { return ring_wrap(R.pe + i, R.m); }
 DEVO void ring_advance(RevRing& R, uint32_t T) {  // T in [1, m]
   const uint32_t np = ring_wrap(R.pe + T, R.m);
   R.p0 = np; R.pe = np; R.stale = 0;
 }
 // element address of (ring position, channel) in the [pos][2] f64 ring
+#ifndef REV_TFR_FIXED
+#define REV_TFR_FIXED 0
+#endif
+#if REV_TFR_FIXED
+#define REV_TFR_T uint32_t
+#define REV_TFR_SET(dst, frac) dst = (uint32_t)((frac) * 4294967296.0)
+#define REV_TFR_GET(x) ((double)(x) * 2.3283064365386963e-10)
+#else
+#define REV_TFR_T double
+#define REV_TFR_SET(dst, frac) dst = (frac)
+#define REV_TFR_GET(x) (x)
+#endif
 // (a 32-bit byte offset on the uniform base: the access is `global_load/store v, v_off, s[base]`, no 64-bit address arithmetic per lane)
-DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) {
-  typedef __attribute__((address_space(1))) char gchar;
-  return (gdouble*)((gchar*)R.buf + (size_t)(uint32_t)((pos << 4) | ((uint32_t)ch << 3)));
-}
+typedef __attribute__((address_space(1))) char gchar;
+DEVO uint32_t ring_off(uint32_t pos, int ch) { return (pos << 4) | ((uint32_t)ch << 3); }
+DEVO gdouble* ring_ptr_off(const RevRing& R, uint32_t off) { return (gdouble*)((gchar*)R.buf + (size_t)off); }
+DEVO gdouble* ring_ptr(const RevRing& R, uint32_t pos, int ch) { return ring_ptr_off(R, ring_off(pos, ch)); }
+DEVO gdouble* ring_ptr_off(const RevRingN& R, uint32_t off) { return (gdouble*)((gchar*)R.buf + (size_t)off); }
+DEVO gdouble* ring_ptr(const RevRingN& R, uint32_t pos, int ch) { return ring_ptr_off(R, ring_off(pos, ch)); }
 
 DEVO double rev_guard(float x, uint32_t fpd) {  // reverb.rs:231-236
   double v = (double)x;
@@ -283,7 +313,16 @@ DEVO bool reverb_fast_eligible(const PgFx& fx) {
   if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;
   double rs = (double)r.room.target;
   double size = (rs * rs * 75.0) + 25.0;
-  return d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17;
+  if (!(d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17)) return false;
+  // every ring position inside its ring: after the room shrank a position may sit above the new ring end for one more frame (the next
+  // write lands there, then the walk restarts at 0) — the serial path renders that block
+  // (against the ring lengths the next block will set from the room size it runs with — update_delay_sizes, reverb.rs:196-213 — not the
+  // ones the last block of a ramp left behind)
+  const double k[8] = {79.0, 73.0, 71.0, 67.0, 61.0, 59.0, 53.0, 47.0};
+  for (int i = 0; i < 8; ++i) { const uint32_t dl = (uint32_t)d2u64(k[i] * size), mx = r.line[i].frames - 1; if (r.line[i].count > (dl < mx ? dl : mx)) return false; }
+  const double ka[4] = {43.0, 41.0, 37.0, 31.0};
+  for (int i = 0; i < 4; ++i) { const uint32_t dl = (uint32_t)d2u64(ka[i] * size), mx = r.ap[i].frames - 1; if (r.ap[i].write_pos > (dl < mx ? dl : mx)) return false; }
+  return true;
 }
 
 // ---- the three stages of the time-parallel reverb ------------------------------------------------------------------------
@@ -453,9 +492,9 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
     for (int i = 0; i < 16; ++i) T = T < ctl[8 + i] ? T : ctl[8 + i];
     T = (int)uni_u32((uint32_t)T);
     PG_STAMP(diag, 2);
-    RevRing D[12];  // the ring descriptors as scalars (all uses below index them with compile-time constants)
+    RevRingN D[12];  // the ring descriptors as scalars (all uses below index them with compile-time constants)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) D[i] = rev_ring_uniform(desc[i]);
+    for (int i = 0; i < 12; ++i) D[i] = rev_ringn_uniform(desc[i]);
 
     // ---- vibrato anchors for the whole chunk, one lane per (sub-chunk, line, channel): sin/cos (accurate libm) of the exact
     // phase of the sub-chunk's middle item (or the chunk's end, if that comes first); inside the sub-chunk sin(phase_n) follows by
@@ -493,8 +532,9 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
         // the previous frame's `get` — and the 4 allpass taps go out to HBM; the f64 sin of the front end and the allpass
         // chain then run underneath those loads.
         double tv1[8], tv2[8];
-        uint32_t tfr[8];  // interpolation fraction as 0.32 fixed point (2^-33 error): frees 8 VGPRs, which keeps the loop free of spills —
-                          // a spilled tap would put an `s_waitcnt vmcnt(0)` in the middle of the load issue
+        // interpolation fraction: REV_TFR_FIXED = 1 holds it as 0.32 fixed point (2^-33 error) — 8 VGPRs less, 4 VALU instructions per line
+        // more (a spilled tap would put an `s_waitcnt vmcnt(0)` in the middle of the load issue); 0 = the f64 fraction itself
+        REV_TFR_T tfr[8];
         if (n >= 1) {
           // sin(phase_n) ~= sin(pb + j*d): pb = the sub-chunk's exact anchor phase, j*d = tabulated rotation. The reference's
           // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 64 * 2^-52 * |p|
@@ -510,7 +550,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
           q_ct[0] = vtab[jb * 2]; q_st[0] = vtab[jb * 2 + 1]; q_a0[0] = anb[ch * 2]; q_a1[0] = anb[ch * 2 + 1];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // ReverbDelayLine::get, address part (reverb.rs:563-576); count = position of frame n
-            const RevRing ld = D[i];
+            const RevRingN ld = D[i];
             if (i + 1 < 8) {
               const double* an = anb + ((i + 1) * 2 + ch) * 2;
               q_ct[(i + 1) & 1] = vtab[((i + 1) * REV_VTAB_N + jb) * 2]; q_st[(i + 1) & 1] = vtab[((i + 1) * REV_VTAB_N + jb) * 2 + 1];
@@ -518,19 +558,19 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
             }
             const double st = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_st[i & 1]) ^ st_sign));
             const double sn = fma(q_a0[i & 1], q_ct[i & 1], q_a1[i & 1] * st);
-            const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;
-            const double w_floor = floor(working);
-            tfr[i] = (uint32_t)((working - w_floor) * 4294967296.0);
-            const uint32_t w_int = (uint32_t)w_floor;                 // < count + 15 <= delay + 15 < 2 * (delay + 1)
+            const double working = (double)ring_at(ld, n) + (sn + 1.0) * 7.0;   // > 0: truncation is floor, v_fract_f64 is working - floor(working)
+            REV_TFR_SET(tfr[i], __builtin_amdgcn_fract(working));
+            const uint32_t w_int = (uint32_t)working;                 // < count + 15 <= delay + 15 < 2 * (delay + 1)
             if (idx_log) idx_log[((done + n - 1) * 8 + i) * 2 + ch] = (int32_t)ring_wrap(w_int, ld.m);  // (the get of frame n - 1)
-            tv1[i] = *ring_ptr(ld, ring_wrap(w_int, ld.m), ch);       // `if read > delay { read -= delay + 1 }`
-            tv2[i] = *ring_ptr(ld, ring_wrap(w_int + 1, ld.m), ch);
+            const uint32_t o1 = ring_off(ring_wrap(w_int, ld.m), ch);  // `if read > delay { read -= delay + 1 }`
+            tv1[i] = *ring_ptr_off(ld, o1);
+            tv2[i] = *ring_ptr_off(ld, ring_wrap(o1 + 16u, ld.m << 4));  // the next ring position, same channel: one wrap in the byte domain
           }
         }
         PG_LAP(diag, 50, lap_t);
         double dl[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
+        for (int i = 0; i < 4; ++i) { const RevRingN a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
         double v = rev_sin(bufA[REV_IDX(done + n, ch)] * wet);
@@ -547,7 +587,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
           double g[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // interpolation + blend (reverb.rs:578-583)
-            const double fr = (double)tfr[i] * 2.3283064365386963e-10;
+            const double fr = REV_TFR_GET(tfr[i]);
             const double interpol = tv1[i] * (1.0 - fr) + tv2[i] * fr;
             g[i] = (1.0 - blend) * interpol + (tv1[i] * blend);
           }
@@ -570,9 +610,9 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
       if (active) {
         if (n >= 1) bufA[REV_IDX(done + n - 1, ch)] = o_prev;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const RevRing a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[i]; }
+        for (int i = 0; i < 4; ++i) { const RevRingN a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[i]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const RevRing ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[i]; }
+        for (int i = 0; i < 8; ++i) { const RevRingN ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[i]; }
       }
       PG_LAP(diag, 54, lap_t);
       // no barrier here: the next sub-chunk only reads ring positions that are written by its own or later items, and LDS
