@@ -241,6 +241,7 @@ DEVO Mat2 mat2_mul(const Mat2& x, const Mat2& y) { return Mat2{x.a * y.a + x.b *
 // Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative).
 template <bool ROUND_F32>
 DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
+#pragma clang fp contract(fast)  // mul + add pairs may fuse here (as in the mid stage): the scan reassociates the recurrence anyway, |error| ~ 1e-16 relative
   const int tid = pg_tid();
   const int wave = tid >> 6, lane = tid & 63;
   const int ch = wave & 1, half = wave >> 1;
@@ -248,16 +249,21 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
   const int n0 = seg * 8;
   const int len = n0 >= T ? 0 : (T - n0 < 8 ? T - n0 : 8);
   const double a1 = c.a1, a2 = c.a2, a3 = c.a3, m0 = c.m0, m1 = c.m1, m2 = c.m2;
+  // REV_IDX(n0 + k, ch) = REV_IDX(n0, ch) + 2k inside a segment: both passes are unrolled over constant LDS offsets. (The inputs are read
+  // again in pass 2 rather than held in 16 registers: the tail stage is an out-of-line function that must fit the caller-saved registers.)
+  double* seg_buf = buf + REV_IDX(n0, ch);
   // pass 1
   double s1 = 0.0, s2 = 0.0;
   if (seg == 0) { s1 = st[ch].ic1eq; s2 = st[ch].ic2eq; }
-  for (int k = 0; k < len; ++k) {
-    double v0 = buf[REV_IDX(n0 + k, ch)];
-    double v3 = v0 - s2;
-    double v1 = a1 * s1 + a2 * v3;
-    double v2 = s2 + a2 * s1 + a3 * v3;
-    s1 = 2.0 * v1 - s1;
-    s2 = 2.0 * v2 - s2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < len) {
+      const double v3 = seg_buf[2 * k] - s2;
+      const double v1 = a1 * s1 + a2 * v3;
+      const double v2 = s2 + a2 * s1 + a3 * v3;
+      s1 = 2.0 * v1 - s1;
+      s2 = 2.0 * v2 - s2;
+    }
   }
   // powers of the 8-frame transition matrix
   Mat2 M{2.0 * a1 - 1.0, -2.0 * a2, 2.0 * a2, 1.0 - 2.0 * a3};
@@ -270,7 +276,7 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
     for (int off = 1; off < 64; off <<= 1) {
       double y1 = __shfl_up(z1, off, 64), y2 = __shfl_up(z2, off, 64);
       if (lane >= off) { z1 = z1 + (P.a * y1 + P.b * y2); z2 = z2 + (P.c * y1 + P.d * y2); }
-      P = mat2_mul(P, P);
+      if (off < 32) P = mat2_mul(P, P);
     }
   };
   if (half == 0) {
@@ -291,15 +297,18 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
     else { b1 = xchg[ch * 2]; b2 = xchg[ch * 2 + 1]; }
   }
   // pass 2
-  for (int k = 0; k < len; ++k) {
-    double v0 = buf[REV_IDX(n0 + k, ch)];
-    double v3 = v0 - b2;
-    double v1 = a1 * b1 + a2 * v3;
-    double v2 = b2 + a2 * b1 + a3 * v3;
-    b1 = 2.0 * v1 - b1;
-    b2 = 2.0 * v2 - b2;
-    const double y = m0 * v0 + m1 * v1 + m2 * v2;
-    buf[REV_IDX(n0 + k, ch)] = ROUND_F32 ? (double)(float)y : y;  // `as f32` between cascaded stages (eq5.rs:318-320)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < len) {
+      const double v0 = seg_buf[2 * k];
+      const double v3 = v0 - b2;
+      const double v1 = a1 * b1 + a2 * v3;
+      const double v2 = b2 + a2 * b1 + a3 * v3;
+      b1 = 2.0 * v1 - b1;
+      b2 = 2.0 * v2 - b2;
+      const double y = m0 * v0 + m1 * v1 + m2 * v2;
+      seg_buf[2 * k] = ROUND_F32 ? (double)(float)y : y;  // `as f32` between cascaded stages (eq5.rs:318-320)
+    }
   }
   __syncthreads();  // all lanes have read the carried state
   if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
