@@ -5,8 +5,7 @@ R=${1:-r02}
 O=gpurun_out/profiles_$R
 rm -rf $O; mkdir -p $O
 SB=16   # blocks per launch in the profiled runs (the counter passes need every steady-state dispatch to render the same number of blocks)
-python bench.py > $O/${R}_headline_bench.json 2> $O/bench.err
-python bench.py --steps 20 --warmup 5 > $O/${R}_headline_bench_driver_args.json 2>> $O/bench.err
+: > $O/bench.err
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --superblock $SB --steps 96 --warmup 32 > $O/${R}_headline_bench_under_rocprofv3.json 2>/tmp/kt.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/${R}_headline_rocprofv3_kernel_stats.csv
 # per-dispatch durations of the dominant kernel: steady-state super-block dispatches only (the first rounds of a run are single blocks)
@@ -56,4 +55,8 @@ d = {"workload": "headline", "voices_per_gpu": 1024, "block_frames": 1024, "kern
 json.dump(d, open(os.path.join(O, f"{R}_headline_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(d))
 PY
+# the bench lines last: bench.py quotes roofline.traffic from a profiles/*_pmc_traffic.json whose source hash matches the library it runs
+cp $O/${R}_headline_pmc_traffic.json profiles/${R}_headline_pmc_traffic.json
+python bench.py > $O/${R}_headline_bench.json 2>> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/${R}_headline_bench_driver_args.json 2>> $O/bench.err
 cat $O/${R}_headline_bench.json
