@@ -41,13 +41,13 @@ def random_params(rng, kind, descs):
     return params
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS or 48)))
-def test_random_graph_matches_oracle(seed):
-    from phonic_amd.graph import Graph, effect_parameters
+def make_plan(seed):
+    """The random graph of a seed: sub-mixer chains with voices, bus chain, ragged block sizes, the block that carries the events."""
+    from phonic_amd.graph import effect_parameters
 
     rng = np.random.default_rng(1000 + seed)
     descs = {k: effect_parameters(k) for k in range(10)}
-    plan = {"mixers": [], "bus": []}
+    plan = {"mixers": [], "bus": [], "seed": seed, "descs": descs}
     for m in range(int(rng.integers(1, 5))):
         chain = []
         for _ in range(int(rng.integers(0, 4))):
@@ -61,46 +61,58 @@ def test_random_graph_matches_oracle(seed):
     for _ in range(int(rng.integers(0, 3))):
         k = int(rng.integers(0, 10))
         plan["bus"].append((k, random_params(rng, k, descs[k]), int(rng.integers(0, 1000))))
-    sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000])) for _ in range(10)]
-    ev_block = int(rng.integers(2, 8))
+    plan["sizes"] = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000])) for _ in range(10)]
+    plan["ev_block"] = int(rng.integers(2, 8))
+    return plan
 
-    outs = []
-    for which in ("gpu", "oracle"):
-        g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
-        fx_ids, voice_ids, fx_mixer = [], [], {}
-        for chain, voices in plan["mixers"]:
-            m = g.add_mixer()
-            for (k, p, s) in chain:
-                fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
-                fx_mixer[fx_ids[-1][0]] = m
-            for (ti, rate, vol, pan) in voices:
-                voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
-        for (k, p, s) in plan["bus"]:
-            fx_ids.append((g.add_effect(0, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
-            fx_mixer[fx_ids[-1][0]] = 0
-        chunks, pos = [], 0
-        rng2 = np.random.default_rng(9000 + seed)  # chain mutations (Player::move_effect / remove_effect): the same draws for both sides
-        for b, n in enumerate(sizes):
-            if b == ev_block:
+
+def render_plan(plan, g):
+    """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its blocks, events and chain mutations included."""
+    seed, descs, sizes, ev_block = plan["seed"], plan["descs"], plan["sizes"], plan["ev_block"]
+    fx_ids, voice_ids, fx_mixer = [], [], {}
+    for chain, voices in plan["mixers"]:
+        m = g.add_mixer()
+        for (k, p, s) in chain:
+            fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+            fx_mixer[fx_ids[-1][0]] = m
+        for (ti, rate, vol, pan) in voices:
+            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+    for (k, p, s) in plan["bus"]:
+        fx_ids.append((g.add_effect(0, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+        fx_mixer[fx_ids[-1][0]] = 0
+    chunks, pos = [], 0
+    rng2 = np.random.default_rng(9000 + seed)  # chain mutations (Player::move_effect / remove_effect): the same draws for both sides
+    for b, n in enumerate(sizes):
+        if b == ev_block:
+            if voice_ids:
                 g.set_voice_volume(voice_ids[0], 0.3, pos + 17)
-                if fx_ids:
-                    fid, k = fx_ids[seed % len(fx_ids)]
-                    d = descs[k][0]
-                    if d["type"] == 0:
-                        g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos + n // 2, normalized=True)
-            if b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
-                fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
-                if fid in fx_mixer:
-                    if rng2.random() < 0.6:
-                        g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
-                    else:
-                        g.remove_effect(fid)
-                        del fx_mixer[fid]
-            o = np.zeros(2 * n, np.float32)
-            assert g.write(o, pos) in (0, 2 * n)
-            chunks.append(o)
-            pos += n
-        outs.append(np.concatenate(chunks))
+            if fx_ids:
+                fid, k = fx_ids[seed % len(fx_ids)]
+                d = descs[k][0]
+                if d["type"] == 0:
+                    g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos + n // 2, normalized=True)
+        if b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
+            fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
+            if fid in fx_mixer:
+                if rng2.random() < 0.6:
+                    g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
+                else:
+                    g.remove_effect(fid)
+                    del fx_mixer[fid]
+        o = np.zeros(2 * n, np.float32)
+        assert g.write(o, pos) in (0, 2 * n)
+        chunks.append(o)
+        pos += n
+    return np.concatenate(chunks)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS or 48)))
+def test_random_graph_matches_oracle(seed):
+    from phonic_amd.graph import Graph
+
+    plan = make_plan(seed)
+    sizes = plan["sizes"]
+    outs = [render_plan(plan, Graph(SR, 2, 1024, 0)), render_plan(plan, oracle.OracleGraph(SR, 2, 1024))]
     a, b = outs
     assert np.isfinite(a).all()
     if float(np.abs(b).max()) <= 1e-4:   # e.g. a gate that never opens: both sides silent
