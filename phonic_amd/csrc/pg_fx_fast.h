@@ -30,6 +30,7 @@ constexpr size_t FAST_SCRATCH_GATE_BYTES = 2 * 1024 * 4 + 256;
 
 #include "pg_reverb_fast.inl"
 #include "pg_delay_fast.inl"
+#include "pg_reverb_ramp.inl"
 #include "pg_chorus_fast.inl"
 #include "pg_comp_fast.inl"
 #include "pg_gate_fast.inl"
@@ -153,6 +154,8 @@ DEVO bool eq5_steady(const PgEq5& e) {
 }
 
 // Must mirror the acceptance conditions of fx_fast_process exactly: the fast kernel has no serial code to fall back to.
+// staged_unit: the kernel that renders the unit in steady state carries no ramp paths (the staged kernels; the lean fast kernel of graphs that
+// hold nothing but Gain / Panning / Reverb).
 DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
   switch (fx.kind) {
     case 0: return !sm_need_ramp(fx.u.gain.gain);
@@ -160,7 +163,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
     case 2: return !staged_unit || !(sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q: time-varying scan (not in the staged kernels)
     case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
     case 4: return delay_fast_eligible(fx) || (!staged_unit && delay_ramp_eligible(fx));  // ramping: delay_ramp_fast (not in the staged kernels)
-    case 5: return reverb_fast_eligible(fx);
+    case 5: return reverb_fast_eligible(fx) || (!staged_unit && reverb_wet_ramp_eligible(fx));  // wet ramping: reverb_wet_ramp_fast (not in the staged kernels)
     case 6: return chorus_fast_eligible(fx) || (!staged_unit && chorus_ramp_eligible(fx));
     case 7: return comp_fast_eligible(fx);
     case 8: return true;
@@ -256,7 +259,10 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       if (delay_fast(fx, sig, n, fc)) return true;
       if constexpr ((KMASK >> 10) & 1) return delay_ramp_fast(fx, sig, n, fc); else return false;
     } else return false;
-    case 5: if constexpr ((KMASK >> 5) & 1) return reverb_fast(fx, sig, n, fc); else return false;
+    case 5: if constexpr ((KMASK >> 5) & 1) {
+      if (reverb_fast(fx, sig, n, fc)) return true;
+      if constexpr ((KMASK >> 10) & 1) return reverb_wet_ramp_fast(fx, sig, n, fc); else return false;
+    } else return false;
     case 6: if constexpr ((KMASK >> 6) & 1) {
       if (chorus_fast(fx, sig, n, fc)) return true;
       if constexpr ((KMASK >> 10) & 1) return chorus_ramp_fast(fx, sig, n, fc); else return false;

@@ -468,7 +468,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 
   if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
     int ramping = 0;
-    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]], unit.staged != 0) ? 0 : 1;
+    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]], unit.staged != 0 || L.wide == 0) ? 0 : 1;  // (staged and lean kernels carry no ramp paths)
     for (int vi = 0; vi < unit.n_voices; ++vi) {  // a pitch glide in progress is rendered here as well
       const PgVoice& vv = L.voices[L.voice_index[unit.voice_off + vi]];
       ramping |= (vv.current_speed != vv.target_speed) ? 1 : 0;

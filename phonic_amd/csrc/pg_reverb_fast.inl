@@ -317,9 +317,8 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
 DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg) { rev_biquad_scan_t<false>(c, st, buf, T, xchg); }
 
 // steady state and a geometry whose shortest feedback lag leaves room for a chunk (always true for valid room sizes)
-DEVO bool reverb_fast_eligible(const PgFx& fx) {
+DEVO bool reverb_geometry_ok(const PgFx& fx) {
   const PgReverb& r = fx.u.reverb;
-  if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;
   double rs = (double)r.room.target;
   double size = (rs * rs * 75.0) + 25.0;
   if (!(d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17)) return false;
@@ -332,6 +331,16 @@ DEVO bool reverb_fast_eligible(const PgFx& fx) {
   const double ka[4] = {43.0, 41.0, 37.0, 31.0};
   for (int i = 0; i < 4; ++i) { const uint32_t dl = (uint32_t)d2u64(ka[i] * size), mx = r.ap[i].frames - 1; if (r.ap[i].write_pos > (dl < mx ? dl : mx)) return false; }
   return true;
+}
+DEVO bool reverb_fast_eligible(const PgFx& fx) {
+  const PgReverb& r = fx.u.reverb;
+  return !sm_need_ramp(r.room) && !sm_need_ramp(r.wet) && reverb_geometry_ok(fx);
+}
+// `wet` ramping, room size at rest (reverb_wet_ramp_fast below): the ring geometry stands still, only the wet gain and the three low-pass
+// cutoffs (10000 - room * wet * 3000 Hz, reverb.rs:413-424) move per frame
+DEVO bool reverb_wet_ramp_eligible(const PgFx& fx) {
+  const PgReverb& r = fx.u.reverb;
+  return !sm_need_ramp(r.room) && sm_need_ramp(r.wet) && reverb_geometry_ok(fx);
 }
 
 // ---- the three stages of the time-parallel reverb ------------------------------------------------------------------------
@@ -425,6 +434,7 @@ DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
 }
 
 // ---- front: predelay (DelayLine<2>::process, delay.rs:47-66) in chunks of <= predelay frames, then biquad A ----
+template <bool SCAN_A = true>
 DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {
   const int tid = pg_tid(), nt = blockDim.x;
   double* bufA = m.bufA;
@@ -460,14 +470,16 @@ DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const 
   }
   if (tid == 0) r.pre_write_pos = pd.p0;
   PG_STAMP(diag, 3);
-  rev_biquad_scan(r.ca, r.sa, bufA, T, m.xchg);
+  if (SCAN_A) rev_biquad_scan(r.ca, r.sa, bufA, T, m.xchg);
   __syncthreads();
 }
 
 // ---- mid: allpasses + vibrato lines ----
 // idx_log (test hook, nullptr in the kernels that matter for speed): slot ((frame * 8 + line) * 2 + channel) receives `read_1` of that
 // frame's ReverbDelayLine::get (reverb.rs:563-570) — the index stream SURVEY §8c asks to be compared separately from the samples.
-DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag, int32_t* idx_log = nullptr) {
+// wet_seq (nullptr in the steady-state kernels): the wet gain of every frame of the piece while its smoother moves (reverb_wet_ramp_fast).
+DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag, int32_t* idx_log = nullptr,
+                  const float* wet_seq = nullptr) {
   const int tid = pg_tid(), nt = blockDim.x;
   RevRec* rec = m.rec; double* gl = m.gl; RevDesc* desc = m.desc; double* anch = m.anch; double* vtab = m.vtab;
   const double blend = b.blend, regen = b.regen, wet = b.wet;
@@ -582,7 +594,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
         for (int i = 0; i < 4; ++i) { const RevRingN a = D[8 + i]; dl[i] = *ring_ptr(a, ring_at(a, n + 1), ch); }  // `delayed`
         // front: wet gain, sin, Schroeder allpass chain i -> j -> k -> l (reverb.rs:253-263; delay.rs:314-350)
         double apo[4];
-        double v = rev_sin(bufA[REV_IDX(done + n, ch)] * wet);
+        double v = rev_sin(bufA[REV_IDX(done + n, ch)] * (wet_seq ? (double)wet_seq[done + n] : wet));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const double bb = v - (dl[i] * 0.5);

@@ -1291,3 +1291,49 @@ def test_multi_gpu_sized_run_stays_audible_past_the_silence_gate():
         peaks.append(float(np.abs(o[-2048:]).max()))
     assert peaks[0] > 1e-3 and peaks[-1] > 0.5 * peaks[0], peaks
     assert g.device_errors() == 0
+
+
+def test_reverb_wet_ramp_stays_on_the_time_parallel_kernels():
+    """ReverbEffect while `wet` moves (its exponential smoother needs 2-3 blocks): the ring geometry stands still, the wet gain, the dry share and
+    the three low-pass cutoffs move per frame — reverb_wet_ramp_fast lays the smoother's sequence out on one lane and runs the biquads as
+    time-varying blocked scans. Two sub-mixers Eq5 -> Reverb -> Gain (fused wide kernel: it carries the ramp paths) and one plain Reverb
+    sub-mixer (staged kernel: no ramp paths, the generic kernel takes the unit while it ramps — with the same time-parallel path). Only the
+    block with the commands is rendered serially; a room-size change (ring lengths change per frame) keeps its unit on the serial lane."""
+    from phonic_amd.graph import Graph
+
+    def build(g):
+        ids = []
+        for i in range(2):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_EQ5, params={"gan3": 2.0})
+            rv = g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(40 + i))
+            g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.8})
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+            ids.append(rv)
+        m = g.add_mixer()
+        ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(50)))
+        g.add_voice(m, workloads.tone_buffer(5, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    gg, gc = Graph(SR, 2, 1024, 0), oracle.OracleGraph(SR, 2, 1024)
+    outs, deferred = [], []
+    for g in (gg, gc):
+        ids = build(g)
+        o = np.zeros((14, 2048), np.float32)
+        for b in range(14):
+            if b == 3:
+                g.schedule_param(ids[0], "wet ", 0.9, b * 1024 + 100)
+                g.schedule_param(ids[1], "wet ", 0.05, b * 1024 + 700)
+                g.schedule_param(ids[2], "wet ", 0.8, b * 1024 + 300)
+            if b == 9:
+                g.schedule_param(ids[0], "room", 0.3, b * 1024 + 50)   # shrinking rooms: ring positions may sit above the new ring end
+                g.schedule_param(ids[2], "room", 0.2, b * 1024 + 50)
+            assert g.write(o[b], b * 1024) == 2048
+            if g is gg:
+                deferred.append(g.deferred_units())
+        outs.append(o.reshape(-1))
+    compare(outs[0], outs[1])
+    assert deferred[3] == 3                      # the block with the commands
+    assert deferred[4] == 1 and deferred[5] <= 1, deferred   # wet still ramping: only the staged unit is with the generic kernel
+    assert deferred[8] == 0 and deferred[9] == 2 and deferred[13] == 0, deferred
+    assert gg.device_errors() == 0
