@@ -1,0 +1,504 @@
+#!/usr/bin/env python3
+"""A second, independent restatement of the GRAPH level of the reference path — written from the Rust sources in plain Python scalars,
+separately from the C++ oracle (`oracle/po_sources.hpp`, `phonic_oracle.cpp`) — for the rows of SURVEY.md §8 the reference holds no tests for:
+
+  * PreloadedFileSource::write / write_buffer (loop range, repeat count, EOF)          src/source/file/preloaded.rs:270-332,396-475
+  * VolumeFader (stop with fade-out)                                                   src/utils/fader.rs:60-122; preloaded.rs:194-208
+  * ChannelMappedSource (mono -> stereo), AmplifiedSource, PannedSource                src/source/mapped.rs:61-99, amplified.rs:93-104, panned.rs:93-104,
+                                                                                        src/utils/smoothing.rs:60-122
+  * MixedSource::write: messages, sample-time events splitting the block, start / stop times of sources, removal of exhausted sources,
+    sub-mixers, the effect chain                                                       src/source/mixed.rs:294-499,505-719; src/utils/event.rs:19-59
+  * EffectProcessor (auto-bypass, known tails, silence detection)                      src/source/mixed/effect.rs:56-145
+  * SubMixerProcessor (2 s silence gate)                                               src/source/mixed/submixer.rs:47-77
+
+The effects and the cubic resampler come from the other two restatements of this directory (numpy_restatement.py, numpy_restatement_fx.py).
+Run as a script it writes tests/golden/independent_graph.npz (scenario outputs); tests/test_golden.py renders the same scenarios with the C++
+oracle's graph and compares bit for bit (both sides call the same libm)."""
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import numpy_restatement as R1  # noqa: E402  (CubicInterpolator)
+import numpy_restatement_fx as RF  # noqa: E402  (smoothers, panning_factors, Gain, Filter, Delay)
+
+F = np.float32
+USIZE_MAX = (1 << 64) - 1
+MAX_MIX_BUFFER_SAMPLES = 8 * 1024  # mixed.rs:216
+
+
+# ---- file source ------------------------------------------------------------------------------------------------------------------
+class CubicResampler:  # src/utils/resampler/cubic.rs:144-186 — one interpolator per channel over the same interleaved slices
+    def __init__(self, in_rate, out_rate, nch):
+        ratio = F(float(in_rate) / float(out_rate))
+        self.nch = nch
+        self.chans = [R1.CubicInterpolator(ratio) for _ in range(nch)]
+
+    def process(self, inp, out):
+        res = (0, 0)
+        for ch, it in enumerate(self.chans):
+            res = it.process(inp, out, ch, self.nch)
+        return res
+
+
+class VolumeFader:  # src/utils/fader.rs
+    STOPPED, RUNNING, FINISHED = 0, 1, 2
+
+    def __init__(self, nch, sr):
+        self.state, self.current, self.target, self.inertia, self.nch, self.sr = self.STOPPED, F(1.0), F(1.0), F(1.0), nch, sr
+
+    def start(self, frm, to, seconds):
+        if seconds == 0.0:
+            self.current = self.target = F(to)
+            self.state = self.FINISHED
+        else:
+            self.state, self.current, self.target = self.RUNNING, F(frm), F(to)
+            samples_duration = F(F(F(self.sr) * F(seconds)) / F(4.605))
+            self.inertia = F(F(1.0) - RF.expf(F(F(-1.0) / samples_duration)))
+
+    def start_fade_out(self, seconds):
+        self.start(self.current if self.state == self.RUNNING else F(1.0), F(0.0), seconds)
+
+    def process(self, out):
+        if self.state != self.RUNNING:
+            if self.target != F(1.0):
+                for i in range(len(out)):
+                    out[i] = F(out[i] * self.target)
+        else:
+            for f in range(len(out) // self.nch):
+                self.current = F(self.current + F(F(self.target - self.current) * self.inertia))
+                for c in range(self.nch):
+                    out[f * self.nch + c] = F(out[f * self.nch + c] * self.current)
+            if abs(float(F(self.current - self.target))) < 0.0001:
+                self.state = self.FINISHED
+
+
+class FileSource:  # PreloadedFileSource at the mixer's rate (constant speed 1: no glide)
+    def __init__(self, pcm, nch, file_rate, out_rate, repeat=0, fade_out=0.05):
+        self.buf, self.nch = np.asarray(pcm, F), nch
+        self.resampler = CubicResampler(file_rate, int(float(out_rate) / 1.0), nch)
+        self.fader = VolumeFader(nch, out_rate)
+        self.fade_out = fade_out
+        self.repeat = self.repeat_count = repeat
+        self.pos, self.eof, self.finished, self.pending_stop = 0, False, False, False
+
+    def stop(self):  # preloaded.rs:194-208
+        if not self.finished:
+            if self.fade_out is not None and self.fade_out != 0.0:
+                self.fader.start_fade_out(self.fade_out)
+            else:
+                self.finished = True
+
+    def write_buffer(self, out):  # preloaded.rs:270-332 (no embedded loop range: the loop is the whole file)
+        written = 0
+        start, end = 0, len(self.buf)
+        while written < len(out):
+            remaining_in = max(end - self.pos, 0)
+            consumed, produced = self.resampler.process(self.buf[self.pos:self.pos + remaining_in], out[written:])
+            self.pos += consumed
+            written += produced
+            if self.pos >= end:
+                if self.repeat_count > 0:
+                    if self.repeat_count != USIZE_MAX:
+                        self.repeat_count -= 1
+                    self.pos = start
+                else:
+                    self.eof = True
+            if self.eof and produced == 0:
+                break
+        return written
+
+    def write(self, out):  # preloaded.rs:396-475
+        if self.pending_stop:  # process_messages: the Stop the mixer pushed
+            self.pending_stop = False
+            self.stop()
+        if self.finished:
+            return 0
+        total = self.write_buffer(out)
+        self.fader.process(out[:total])
+        if self.eof or (self.fader.state == VolumeFader.FINISHED and self.fader.target == F(0.0)):
+            self.finished = True
+        return total
+
+    def is_exhausted(self):
+        return self.finished
+
+    channel_count = property(lambda self: self.nch)
+
+
+class Mapped:  # ChannelMappedSource to stereo (mapped.rs:61-99; remap_buffer_channels mono -> stereo, buffer.rs:209-217)
+    def __init__(self, src):
+        self.src, self.inch = src, src.channel_count
+        self.in_buf = np.zeros(MAX_MIX_BUFFER_SAMPLES // 2 * self.inch, F)
+
+    def write(self, out):
+        if len(out) == 0 or self.inch == 2:
+            return self.src.write(out)
+        total = 0
+        while total < len(out):
+            input_max = ((len(out) - total) // 2) * self.inch
+            n = min(input_max, len(self.in_buf))
+            w = self.src.write(self.in_buf[:n])
+            if w == 0:
+                break
+            for i in range(w):
+                out[total + 2 * i] = self.in_buf[i]
+                out[total + 2 * i + 1] = self.in_buf[i]
+            total += 2 * w
+        return total
+
+    def is_exhausted(self):
+        return self.src.is_exhausted()
+
+
+class Amplified:  # amplified.rs:93-104 + apply_smoothed_gain (smoothing.rs:60-71)
+    def __init__(self, src, volume, sr):
+        self.src, self.volume, self.msg = src, RF.ExpSm(volume, sr), None
+
+    def write(self, out):
+        if self.msg is not None:
+            self.volume.set_target(self.msg)
+            self.msg = None
+        w = self.src.write(out)
+        if self.volume.need_ramp():
+            for i in range(w):
+                out[i] = F(out[i] * self.volume.next())
+        else:
+            g = self.volume.target
+            if abs(float(F(F(1.0) - g))) > 0.000001:
+                for i in range(w):
+                    out[i] = F(out[i] * g)
+        return w
+
+    def is_exhausted(self):
+        return self.src.is_exhausted()
+
+
+class Panned:  # panned.rs:93-104 + apply_smoothed_panning (smoothing.rs:74-122), stereo
+    def __init__(self, src, panning, sr):
+        self.src, self.pan, self.msg = src, RF.ExpSm(panning, sr), None
+
+    def write(self, out):
+        if self.msg is not None:
+            self.pan.set_target(self.msg)
+            self.msg = None
+        w = self.src.write(out)
+        if self.pan.need_ramp():
+            for f in range(w // 2):
+                pl, pr = RF.panning_factors(self.pan.next())
+                out[2 * f] = F(out[2 * f] * pl)
+                out[2 * f + 1] = F(out[2 * f + 1] * pr)
+        else:
+            p = self.pan.target
+            if abs(float(p)) > 0.000001:
+                pl, pr = RF.panning_factors(p)
+                for f in range(w // 2):
+                    out[2 * f] = F(out[2 * f] * pl)
+                    out[2 * f + 1] = F(out[2 * f + 1] * pr)
+        return w
+
+    def is_exhausted(self):
+        return self.src.is_exhausted()
+
+
+# ---- mixer ---------------------------------------------------------------------------------------------------------------------------
+def max_abs(buf):
+    m = F(0.0)
+    for v in buf:
+        a = F(abs(v))
+        if a > m:
+            m = a
+    return m
+
+
+class EffectProc:  # src/source/mixed/effect.rs
+    THRESHOLD, SECONDS = F(0.001), 2
+
+    def __init__(self, fx, tail_fn):
+        self.fx, self.tail_fn = fx, tail_fn
+        self.bypassed, self.tail, self.silence = True, 0, USIZE_MAX
+
+    def reset_tail(self):
+        self.tail, self.silence = USIZE_MAX, 0
+
+    def process(self, out, nch, sr, input_bypassed):
+        should = input_bypassed and self.tail == 0 and self.silence == USIZE_MAX
+        if should and not self.bypassed:
+            self.bypassed = True
+        elif not should and self.bypassed:
+            self.bypassed = False
+            self.reset_tail()
+        if self.bypassed:
+            return False
+        self.fx.process(out)
+        if input_bypassed:
+            frames = len(out) // nch
+            tail = self.tail_fn()
+            if tail is not None:
+                if tail == USIZE_MAX:
+                    self.tail = tail
+                elif self.tail == USIZE_MAX:
+                    self.tail = tail
+                else:
+                    self.tail = max(self.tail - frames, 0)
+                self.silence = USIZE_MAX
+            else:
+                if max_abs(out) < self.THRESHOLD:
+                    self.silence = min(self.silence + frames, USIZE_MAX)
+                    if self.silence >= self.SECONDS * sr:
+                        self.tail, self.silence = 0, USIZE_MAX
+                else:
+                    self.silence = 0
+        else:
+            self.reset_tail()
+        return True
+
+
+class Playing:
+    def __init__(self, pid, chain, start):
+        self.pid, self.src, self.start, self.stop, self.active = pid, chain["panned"], start, None, True
+        self.file, self.amp, self.panned = chain["file"], chain["amp"], chain["panned"]
+
+
+class Mixer:  # MixedSource (stereo)
+    def __init__(self, sr):
+        self.sr, self.sources, self.mixers, self.effects, self.events = sr, [], [], [], []
+        self.effects_bypassed = True
+        self.mix = np.zeros(MAX_MIX_BUFFER_SAMPLES, F)
+
+    # Player side (messages are applied at the top of the next write: here directly, the scenarios call these between writes)
+    def add_source(self, playing):
+        i = 0
+        while i < len(self.sources) and self.sources[i].start < playing.start:
+            i += 1
+        self.sources.insert(i, playing)
+
+    def add_effect(self, fid, proc):
+        self.effects.append((fid, proc))
+        self.effects_bypassed = False
+
+    def insert_event(self, ev):  # event.rs:31-38: behind every event with sample_time <= its own
+        i = 0
+        while i < len(self.events) and self.events[i][0] <= ev[0]:
+            i += 1
+        self.events.insert(i, ev)
+
+    def process_event(self, ev):  # mixed.rs:760-925
+        _, kind, target, a, b = ev
+        if kind in ("volume", "panning"):
+            for s in self.sources:
+                if s.pid == target:
+                    if kind == "volume":
+                        s.amp.msg = a
+                    else:
+                        s.panned.msg = a
+                    break
+        else:
+            for fid, proc in self.effects:
+                if fid == target:
+                    proc.fx.set(a, b)
+                    break
+
+    def process_sources(self, out, pos):  # mixed.rs:558-624
+        produced = False
+        frames = len(out) // 2
+        for s in self.sources:
+            total = 0
+            if s.start > pos:
+                until = s.start - pos
+                if until >= frames:
+                    break
+                total += until * 2
+            while total < len(out):
+                t = pos + total // 2
+                until_stop = USIZE_MAX
+                if s.stop is not None:
+                    until_stop = max(s.stop - t, 0) * 2
+                if until_stop == 0:
+                    s.file.pending_stop = True
+                    s.stop = None
+                    until_stop = USIZE_MAX
+                remaining = min(len(out) - total, until_stop)
+                to_write = min(remaining, len(self.mix))
+                w = s.src.write(self.mix[:to_write])
+                for i in range(w):
+                    out[total + i] = F(out[total + i] + self.mix[i])
+                total += w
+                produced = produced or w > 0
+                if s.src.is_exhausted():
+                    s.active = False
+                    break
+                elif w == 0:
+                    break
+        return produced
+
+    def process_effects(self, out, input_bypassed):  # mixed.rs:627-655
+        if self.effects_bypassed and input_bypassed:
+            return
+        all_bypassed = True
+        for _, proc in self.effects:
+            if proc.process(out, 2, self.sr, input_bypassed):
+                input_bypassed = False
+                all_bypassed = False
+        self.effects_bypassed = all_bypassed
+
+    def write(self, out, pos):  # mixed.rs:659-719
+        if not self.sources and not self.effects and not self.mixers and not self.events:
+            return 0
+        out[:] = F(0.0)
+        frames = len(out) // 2
+        done = 0
+        while done < frames:
+            now = pos + done
+            while self.events and self.events[0][0] <= now:
+                self.process_event(self.events.pop(0))
+            until_event = (self.events[0][0] - now) if self.events else USIZE_MAX
+            n = min(frames - done, len(self.mix) // 2, until_event)
+            if n > 0:
+                chunk = out[done * 2:(done + n) * 2]
+                audible = False
+                for sub in self.mixers:
+                    audible = sub.process(chunk, self.mix[:len(chunk)], self.sr, pos + done) or audible
+                audible = self.process_sources(chunk, pos + done) or audible
+                self.process_effects(chunk, not audible)
+                done += n
+        self.sources = [s for s in self.sources if s.active]
+        return len(out)
+
+
+class SubMixer:  # SubMixerProcessor (submixer.rs:47-77)
+    def __init__(self, mixer):
+        self.mixer, self.silence = mixer, 0
+
+    def process(self, out, mix_buffer, sr, pos):
+        w = self.mixer.write(mix_buffer, pos)
+        if max_abs(mix_buffer[:w]) < EffectProc.THRESHOLD:
+            self.silence += len(out) // 2
+            if self.silence < EffectProc.SECONDS * sr:
+                for i in range(w):
+                    out[i] = F(out[i] + mix_buffer[i])
+                return True
+            return False
+        self.silence = 0
+        for i in range(w):
+            out[i] = F(out[i] + mix_buffer[i])
+        return True
+
+
+# ---- tails of the effects used below -------------------------------------------------------------------------------------------------
+def gain_tail(fx, sr):  # gain.rs:168-175 (DC filter off)
+    return lambda: 0
+
+
+def filter_tail(fx, sr):  # filter.rs:203-207
+    return lambda: sr // 10
+
+
+def delay_tail(fx, sr):  # delay.rs:456-476
+    def tail():
+        if fx.sm["driv"].target > F(0.0):
+            return None
+        delay_ms = float(F(fx.sm["dlay"].target + F(50.0)))
+        fb = abs(float(fx.sm["fdbk"].target))
+        if fb >= 0.9999:
+            return USIZE_MAX
+        if fb < 0.001:
+            return int(math.ceil(delay_ms * sr / 1000.0))
+        ds = delay_ms * sr / 1000.0
+        return max(int(math.ceil(ds + ds * math.log10(0.001) / math.log10(fb))), 1)
+    return tail
+
+
+# ---- scenarios (shared with tests/test_golden.py, which builds the same graphs on the C++ oracle) --------------------------------------
+SR = 8000      # mixer rate: the 2 s silence windows are 16 000 frames
+BLOCK = 256
+
+
+def tone(i, rate, seconds, nch):
+    """The workloads' tone family, restated (phonic_amd/workloads.py is product code: not imported here)."""
+    n = int(rate * seconds)
+    t = np.arange(n, dtype=np.float64) / rate
+    f0 = 110.0 * (1.0 + 0.37 * (i % 11))
+    x = 0.6 * np.sin(2 * np.pi * f0 * t) + 0.3 * np.sin(2 * np.pi * 2.01 * f0 * t + 0.5 * i)
+    if nch == 1:
+        return x.astype(F)
+    y = 0.6 * np.sin(2 * np.pi * f0 * t + 0.3) + 0.3 * np.sin(2 * np.pi * 1.5 * f0 * t + 0.2 * i)
+    return np.stack([x, y], axis=1).reshape(-1).astype(F)
+
+
+SCENARIOS = {
+    # main mixer only: start time inside a block, looping stereo voice at another rate, stop with the default 50 ms fade-out, volume / panning
+    # events at sample times, a mono one-shot at the mixer's rate (resampler bypass) that runs into its end of file
+    "sources": {
+        "blocks": [256] * 10 + [100, 412] + [256] * 8,
+        "mixers": [],
+        "voices": [
+            dict(mixer=0, tone=(1, 7350, 0.4, 2), volume=0.5, panning=-0.3, start=300, repeat=USIZE_MAX),
+            dict(mixer=0, tone=(4, 8000, 0.3, 1), volume=0.8, panning=0.5, start=0, repeat=0),
+        ],
+        "actions": {3: [("volume", 0, 0.2, 1000)], 4: [("panning", 0, 0.6, 1500)], 9: [("stop", 0, None, 3000)]},
+    },
+    # a sub-mixer Gain -> Filter -> Delay (drive > 0: no known tail) with a one-shot voice: parameter events inside blocks, then the voice
+    # ends, the Gain bypasses at once, the Filter after its 800-frame tail, the Delay after 2 s below the silence threshold, and the
+    # sub-mixer's own 2 s silence gate closes after that
+    "submixer_bypass": {
+        "blocks": [256] * 170,
+        "mixers": [[("gain", {"gain": 0.7}), ("filter", {"type": 0, "cuto": 1500.0, "fltq": 0.9}), ("delay", {"dlay": 40.0, "fdbk": 0.4, "driv": 0.3})]],
+        "voices": [dict(mixer=1, tone=(2, 7350, 0.25, 2), volume=0.9, panning=0.0, start=0, repeat=0)],
+        "actions": {2: [("param", (1, 1), ("cuto", 900.0), 700)], 4: [("param", (1, 0), ("gain", 0.4), 1200)]},
+    },
+}
+FX = {"gain": (RF.Gain, gain_tail, 0), "filter": (RF.Filter, filter_tail, 2), "delay": (RF.Delay, delay_tail, 4)}  # class, tail, pg_effect_kind
+
+
+def run_scenario(sc):
+    main = Mixer(SR)
+    subs = []
+    fx_of = {}
+    for mi, chain in enumerate(sc["mixers"]):
+        m = Mixer(SR)
+        for fi, (name, params) in enumerate(chain):
+            cls, tail, _ = FX[name]
+            fx = cls(SR, gain=params["gain"]) if cls is RF.Gain else cls(SR, params)
+            m.add_effect((mi + 1, fi), EffectProc(fx, tail(fx, SR)))
+            fx_of[(mi + 1, fi)] = m
+        subs.append(m)
+        main.mixers.append(SubMixer(m))
+    target = [main] + subs
+    voices = []
+    for vi, v in enumerate(sc["voices"]):
+        i, rate, seconds, nch = v["tone"]
+        f = FileSource(tone(i, rate, seconds, nch), nch, rate, SR, repeat=v["repeat"])
+        amp = Amplified(Mapped(f), v["volume"], SR)
+        chain = {"file": f, "amp": amp, "panned": Panned(amp, v["panning"], SR)}
+        target[v["mixer"]].add_source(Playing(vi, chain, v["start"]))
+        voices.append(v["mixer"])
+    outs, pos = [], 0
+    for b, n in enumerate(sc["blocks"]):
+        for kind, who, val, t in sc["actions"].get(b, []):
+            if kind == "stop":  # MixerMessage::StopSource: a message, applied at the top of the write
+                for s in target[voices[who]].sources:
+                    if s.pid == who:
+                        s.stop = t
+            elif kind == "param":
+                fx_of[who].insert_event((t, "param", who, val[0], val[1]))
+            else:
+                target[voices[who]].insert_event((t, kind, who, val, None))
+        o = np.zeros(2 * n, F)
+        main.write(o, pos)
+        outs.append(o)
+        pos += n
+    return np.concatenate(outs)
+
+
+if __name__ == "__main__":
+    vec = {}
+    for name, sc in SCENARIOS.items():
+        y = run_scenario(sc)
+        vec[name] = y
+        print(name, len(y) // 2, "frames, peak", float(np.abs(y).max()), "last non-zero frame", int(np.flatnonzero(y)[-1] // 2) if np.any(y) else -1)
+    np.savez_compressed(os.path.join(HERE, "independent_graph.npz"), **vec)
+    print("independent_graph.npz", os.path.getsize(os.path.join(HERE, "independent_graph.npz")), "bytes")

@@ -131,3 +131,69 @@ def test_independent_restatement_vectors_are_current():
     for case in rfx.CASES[::4]:
         x, y = rfx.run_case(rfx._adapt(case))
         assert np.array_equal(x, IND_FX[case[0] + "_in"]) and np.array_equal(y, IND_FX[case[0] + "_out"]), case[0]
+
+
+# ---- the C++ oracle's GRAPH vs the third part of the independent restatement (numpy_restatement_graph.py) ---------------------------------
+import numpy_restatement_graph as rgr  # noqa: E402
+
+IND_GR = np.load(os.path.join(HERE, "golden", "independent_graph.npz"))
+
+
+def _oracle_scenario(sc):
+    """The scenario of numpy_restatement_graph.py on the C++ oracle's graph, through the API every graph test uses."""
+    import oracle
+    from phonic_amd import _capi
+
+    g = oracle.OracleGraph(rgr.SR, 2, 512)
+    fx_ids = {}
+    mixers = [0]
+    for mi, chain in enumerate(sc["mixers"]):
+        m = g.add_mixer()
+        mixers.append(m)
+        for fi, (name, params) in enumerate(chain):
+            fx_ids[(mi + 1, fi)] = g.add_effect(m, rgr.FX[name][2], params=params)
+    voices = []
+    for v in sc["voices"]:
+        i, rate, seconds, nch = v["tone"]
+        rep = v["repeat"]
+        voices.append(g.add_voice(mixers[v["mixer"]], rgr.tone(i, rate, seconds, nch), nch, rate, volume=v["volume"], panning=v["panning"], start_time=v["start"],
+                                  has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER if rep == rgr.USIZE_MAX else rep))
+    outs, pos = [], 0
+    for b, n in enumerate(sc["blocks"]):
+        for kind, who, val, t in sc["actions"].get(b, []):
+            if kind == "stop":
+                g.stop_voice(voices[who], t)
+            elif kind == "volume":
+                g.set_voice_volume(voices[who], val, t)
+            elif kind == "panning":
+                g.set_voice_panning(voices[who], val, t)
+            else:
+                g.schedule_param(fx_ids[who], val[0], val[1], t)
+        o = np.zeros(2 * n, np.float32)
+        w = g.write(o, pos)
+        assert w in (0, 2 * n)
+        outs.append(o)
+        pos += n
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("name", sorted(rgr.SCENARIOS))
+def test_oracle_graph_equals_independent_restatement(name):
+    """The graph level — PreloadedFileSource (repeat, end of file, stop with fade-out), mono -> stereo mapping, smoothed source volume and
+    panning, MixedSource::write (sample-time events splitting blocks, start / stop times, removal of exhausted sources, sub-mixers, the effect
+    chain), EffectProcessor's auto-bypass with known tails and with silence detection, SubMixerProcessor's 2 s silence gate — restated a
+    second time in Python from the Rust sources: the C++ oracle's graph must agree bit for bit over the whole run (the sub-mixer scenario
+    runs 43 520 frames at 8 kHz: the voice ends, the Gain bypasses at once, the Filter after its tail, the Delay after 2 s of silence, the
+    sub-mixer's gate 2 s after its output fell silent)."""
+    want = IND_GR[name]
+    got = _oracle_scenario(rgr.SCENARIOS[name])
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        raise AssertionError(f"{name}: {bad.size} samples differ, first at frame {bad[0] // 2} (oracle {got[bad[0]]!r}, restatement {want[bad[0]]!r}), "
+                             f"max |d| {float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())}")
+
+
+def test_independent_graph_vectors_are_current():
+    """The committed vectors are what the restatement script produces (the short scenario; the long one takes a few seconds)."""
+    assert np.array_equal(rgr.run_scenario(rgr.SCENARIOS["sources"]), IND_GR["sources"])
