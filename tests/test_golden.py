@@ -139,12 +139,13 @@ import numpy_restatement_graph as rgr  # noqa: E402
 IND_GR = np.load(os.path.join(HERE, "golden", "independent_graph.npz"))
 
 
-def _oracle_scenario(sc):
-    """The scenario of numpy_restatement_graph.py on the C++ oracle's graph, through the API every graph test uses."""
-    import oracle
+def _oracle_scenario(sc, g=None):
+    """The scenario of numpy_restatement_graph.py on the C++ oracle's graph (or the graph given), through the API every graph test uses."""
     from phonic_amd import _capi
 
-    g = oracle.OracleGraph(rgr.SR, 2, 512)
+    if g is None:
+        import oracle
+        g = oracle.OracleGraph(rgr.SR, 2, 512)
     fx_ids = {}
     mixers = [0]
     for mi, chain in enumerate(sc["mixers"]):
@@ -197,3 +198,17 @@ def test_oracle_graph_equals_independent_restatement(name):
 def test_independent_graph_vectors_are_current():
     """The committed vectors are what the restatement script produces (the short scenario; the long one takes a few seconds)."""
     assert np.array_equal(rgr.run_scenario(rgr.SCENARIOS["sources"]), IND_GR["sources"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(rgr.SCENARIOS))
+def test_gpu_graph_matches_independent_restatement(name):
+    """The HIP graph against the restatement's vectors directly (no oracle in between), at the scenarios' 8 kHz mixer rate: sources with start /
+    stop / fade-out / volume and panning events, and the 43 520-frame bypass scenario (known tails, silence detection, the sub-mixer's gate)."""
+    from phonic_amd.graph import Graph
+
+    want = IND_GR[name]
+    got = _oracle_scenario(rgr.SCENARIOS[name], Graph(rgr.SR, 2, 512, 0))
+    close(got, want)
+    if name == "submixer_bypass":   # behind every gate of the long scenario both sides are exactly silent
+        assert not np.any(got[2 * 23000:]) and not np.any(want[2 * 23000:])
