@@ -76,14 +76,62 @@ class VolumeFader:  # src/utils/fader.rs
                 self.state = self.FINISHED
 
 
-class FileSource:  # PreloadedFileSource at the mixer's rate (constant speed 1: no glide)
-    def __init__(self, pcm, nch, file_rate, out_rate, repeat=0, fade_out=0.05):
-        self.buf, self.nch = np.asarray(pcm, F), nch
+class FileSource:  # PreloadedFileSource created at the mixer's rate
+    SPEED_UPDATE_CHUNK_SIZE = 64  # common.rs:57
+
+    def __init__(self, pcm, nch, file_rate, out_rate, repeat=0, fade_out=0.05, loop_range=None):
+        self.buf, self.nch, self.file_rate, self.out_rate = np.asarray(pcm, F), nch, file_rate, out_rate
         self.resampler = CubicResampler(file_rate, int(float(out_rate) / 1.0), nch)
         self.fader = VolumeFader(nch, out_rate)
         self.fade_out = fade_out
         self.repeat = self.repeat_count = repeat
-        self.pos, self.eof, self.finished, self.pending_stop = 0, False, False, False
+        frames = len(self.buf) // nch
+        self.loop_range = None if loop_range is None else (min(loop_range[0], max(frames - 1, 0)), min(loop_range[1], frames))  # preloaded.rs:100-103
+        self.pos, self.eof, self.finished = 0, False, False
+        self.msgs = []  # FilePlaybackMessage queue, drained at the top of write
+        self.current_speed = self.target_speed = 1.0
+        self.glide_rate = F(0.0)
+        self.to_next_speed_update = 0
+
+    def seek(self, seconds):  # preloaded.rs:137-145
+        if not self.finished:
+            buffer_pos = float(seconds) * float(self.file_rate) * float(self.nch)
+            self.pos = min(max(int(buffer_pos), 0), len(self.buf))
+            for it in self.resampler.chans:
+                it.input = [F(0.0)] * 4
+                it.sub_pos = F(0.0)
+                it.initialized = False
+
+    def update_speed(self):  # common.rs:141-169
+        diff = self.target_speed - self.current_speed
+        if self.glide_rate > F(0.0) and abs(diff) > 0.0001:
+            semitone_diff = abs(12.0 * math.log2(self.target_speed / self.current_speed))
+            duration_secs = F(F(semitone_diff) / self.glide_rate)
+            if duration_secs > F(0.0):
+                duration_frames = F(duration_secs * F(self.out_rate))
+                step = (self.target_speed - self.current_speed) / float(duration_frames)
+                change = step * float(self.SPEED_UPDATE_CHUNK_SIZE)
+                if abs(self.target_speed - self.current_speed) < abs(change):
+                    self.current_speed = self.target_speed
+                else:
+                    self.current_speed += change
+            else:
+                self.current_speed = self.target_speed
+        else:
+            self.current_speed = self.target_speed
+        new_rate = int(float(self.out_rate) / self.current_speed)
+        ratio = F(float(self.file_rate) / float(new_rate))
+        for it in self.resampler.chans:
+            it.ratio = ratio
+
+    def set_speed(self, speed, glide):  # preloaded.rs:180-191
+        if not self.finished:
+            self.to_next_speed_update = 0
+            self.target_speed = float(speed)
+            self.glide_rate = F(glide) if glide else F(0.0)
+            if self.glide_rate == F(0.0):
+                self.current_speed = float(speed)
+                self.update_speed()
 
     def stop(self):  # preloaded.rs:194-208
         if not self.finished:
@@ -92,9 +140,11 @@ class FileSource:  # PreloadedFileSource at the mixer's rate (constant speed 1: 
             else:
                 self.finished = True
 
-    def write_buffer(self, out):  # preloaded.rs:270-332 (no embedded loop range: the loop is the whole file)
+    def write_buffer(self, out):  # preloaded.rs:270-332
         written = 0
         start, end = 0, len(self.buf)
+        if self.repeat > 0 and self.loop_range is not None:
+            start, end = self.loop_range[0] * self.nch, self.loop_range[1] * self.nch
         while written < len(out):
             remaining_in = max(end - self.pos, 0)
             consumed, produced = self.resampler.process(self.buf[self.pos:self.pos + remaining_in], out[written:])
@@ -112,12 +162,32 @@ class FileSource:  # PreloadedFileSource at the mixer's rate (constant speed 1: 
         return written
 
     def write(self, out):  # preloaded.rs:396-475
-        if self.pending_stop:  # process_messages: the Stop the mixer pushed
-            self.pending_stop = False
-            self.stop()
+        while self.msgs:  # process_messages
+            m = self.msgs.pop(0)
+            if m[0] == "stop":
+                self.stop()
+            elif m[0] == "seek":
+                self.seek(m[1])
+            else:
+                self.set_speed(m[1], m[2])
         if self.finished:
             return 0
-        total = self.write_buffer(out)
+        total = 0
+        if self.current_speed != self.target_speed:  # pitch glide: speed updates every 64 frames
+            while total < len(out):
+                if self.to_next_speed_update == 0:
+                    if self.current_speed != self.target_speed:
+                        self.update_speed()
+                    self.to_next_speed_update = self.SPEED_UPDATE_CHUNK_SIZE * self.nch
+                n = min(len(out) - total, self.to_next_speed_update)
+                w = self.write_buffer(out[total:total + n])
+                self.to_next_speed_update -= w
+                total += w
+                if w < n:
+                    break
+        else:
+            self.to_next_speed_update = 0
+            total = self.write_buffer(out)
         self.fader.process(out[:total])
         if self.eof or (self.fader.state == VolumeFader.FINISHED and self.fader.target == F(0.0)):
             self.finished = True
@@ -288,13 +358,17 @@ class Mixer:  # MixedSource (stereo)
 
     def process_event(self, ev):  # mixed.rs:760-925
         _, kind, target, a, b = ev
-        if kind in ("volume", "panning"):
+        if kind in ("volume", "panning", "speed", "seek"):
             for s in self.sources:
                 if s.pid == target:
                     if kind == "volume":
                         s.amp.msg = a
-                    else:
+                    elif kind == "panning":
                         s.panned.msg = a
+                    elif kind == "speed":
+                        s.file.msgs.append(("speed", a, b))
+                    else:
+                        s.file.msgs.append(("seek", a))
                     break
         else:
             for fid, proc in self.effects:
@@ -318,7 +392,7 @@ class Mixer:  # MixedSource (stereo)
                 if s.stop is not None:
                     until_stop = max(s.stop - t, 0) * 2
                 if until_stop == 0:
-                    s.file.pending_stop = True
+                    s.file.msgs.append(("stop",))
                     s.stop = None
                     until_stop = USIZE_MAX
                 remaining = min(len(out) - total, until_stop)
@@ -451,6 +525,14 @@ SCENARIOS = {
         "actions": {2: [("param", (1, 1), ("cuto", 900.0), 700)], 4: [("param", (1, 0), ("gain", 0.4), 1200)]},
     },
 }
+SCENARIOS["file_features"] = {
+    # loop range with a finite repeat count (the source ends at the loop's end once the repeats are used up), a pitch glide in 64-frame steps,
+    # a seek (resampler reset) and an immediate speed change, each at a sample time inside a block
+    "blocks": [256] * 56,
+    "mixers": [],
+    "voices": [dict(mixer=0, tone=(3, 7350, 0.5, 2), volume=0.7, panning=0.2, start=0, repeat=3, loop=(600, 2400))],
+    "actions": {2: [("speed", 0, (1.5, 24.0), 700)], 9: [("seek", 0, (0.1, None), 2500)], 12: [("speed", 0, (0.8, None), 3200)]},
+}
 FX = {"gain": (RF.Gain, gain_tail, 0), "filter": (RF.Filter, filter_tail, 2), "delay": (RF.Delay, delay_tail, 4)}  # class, tail, pg_effect_kind
 
 
@@ -471,7 +553,7 @@ def run_scenario(sc):
     voices = []
     for vi, v in enumerate(sc["voices"]):
         i, rate, seconds, nch = v["tone"]
-        f = FileSource(tone(i, rate, seconds, nch), nch, rate, SR, repeat=v["repeat"])
+        f = FileSource(tone(i, rate, seconds, nch), nch, rate, SR, repeat=v["repeat"], loop_range=v.get("loop"))
         amp = Amplified(Mapped(f), v["volume"], SR)
         chain = {"file": f, "amp": amp, "panned": Panned(amp, v["panning"], SR)}
         target[v["mixer"]].add_source(Playing(vi, chain, v["start"]))
@@ -485,6 +567,8 @@ def run_scenario(sc):
                         s.stop = t
             elif kind == "param":
                 fx_of[who].insert_event((t, "param", who, val[0], val[1]))
+            elif kind in ("speed", "seek"):
+                target[voices[who]].insert_event((t, kind, who, val[0], val[1]))
             else:
                 target[voices[who]].insert_event((t, kind, who, val, None))
         o = np.zeros(2 * n, F)

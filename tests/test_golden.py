@@ -157,8 +157,9 @@ def _oracle_scenario(sc, g=None):
     for v in sc["voices"]:
         i, rate, seconds, nch = v["tone"]
         rep = v["repeat"]
+        loop = dict(has_loop_range=1, loop_start=v["loop"][0], loop_end=v["loop"][1]) if v.get("loop") else {}
         voices.append(g.add_voice(mixers[v["mixer"]], rgr.tone(i, rate, seconds, nch), nch, rate, volume=v["volume"], panning=v["panning"], start_time=v["start"],
-                                  has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER if rep == rgr.USIZE_MAX else rep))
+                                  has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER if rep == rgr.USIZE_MAX else rep, **loop))
     outs, pos = [], 0
     for b, n in enumerate(sc["blocks"]):
         for kind, who, val, t in sc["actions"].get(b, []):
@@ -168,6 +169,10 @@ def _oracle_scenario(sc, g=None):
                 g.set_voice_volume(voices[who], val, t)
             elif kind == "panning":
                 g.set_voice_panning(voices[who], val, t)
+            elif kind == "speed":
+                g.set_voice_speed(voices[who], val[0], t, glide=val[1])
+            elif kind == "seek":
+                g.seek_voice(voices[who], val[0], t)
             else:
                 g.schedule_param(fx_ids[who], val[0], val[1], t)
         o = np.zeros(2 * n, np.float32)
@@ -182,7 +187,8 @@ def _oracle_scenario(sc, g=None):
 def test_oracle_graph_equals_independent_restatement(name):
     """The graph level — PreloadedFileSource (repeat, end of file, stop with fade-out), mono -> stereo mapping, smoothed source volume and
     panning, MixedSource::write (sample-time events splitting blocks, start / stop times, removal of exhausted sources, sub-mixers, the effect
-    chain), EffectProcessor's auto-bypass with known tails and with silence detection, SubMixerProcessor's 2 s silence gate — restated a
+    chain; loop range with a finite repeat count, pitch glide in 64-frame steps, seek, immediate speed change), EffectProcessor's auto-bypass with
+    known tails and with silence detection, SubMixerProcessor's 2 s silence gate — restated a
     second time in Python from the Rust sources: the C++ oracle's graph must agree bit for bit over the whole run (the sub-mixer scenario
     runs 43 520 frames at 8 kHz: the voice ends, the Gain bypasses at once, the Filter after its tail, the Delay after 2 s of silence, the
     sub-mixer's gate 2 s after its output fell silent)."""
