@@ -533,6 +533,16 @@ SCENARIOS["file_features"] = {
     "voices": [dict(mixer=0, tone=(3, 7350, 0.5, 2), volume=0.7, panning=0.2, start=0, repeat=3, loop=(600, 2400))],
     "actions": {2: [("speed", 0, (1.5, 24.0), 700)], 9: [("seek", 0, (0.1, None), 2500)], 12: [("speed", 0, (0.8, None), 3200)]},
 }
+SCENARIOS["nested"] = {
+    # Player::add_mixer(parent): a sub-mixer inside a sub-mixer. The parent's events split ITS block, and with it the calls into the child
+    # (whose silence gate and effect tails count per call); the child's own event splits only the child's part
+    "blocks": [256] * 12 + [300, 212] + [256] * 10,
+    "mixers": [[("gain", {"gain": 0.8})], [("filter", {"type": 0, "cuto": 1200.0, "fltq": 1.1})]],
+    "parents": [0, 1],
+    "voices": [dict(mixer=2, tone=(5, 7350, 0.3, 2), volume=0.8, panning=-0.4, start=100, repeat=0),
+               dict(mixer=1, tone=(6, 8000, 0.2, 1), volume=0.5, panning=0.3, start=900, repeat=0)],
+    "actions": {1: [("param", (1, 0), ("gain", 0.3), 500)], 2: [("param", (2, 0), ("cuto", 600.0), 777)], 5: [("param", (1, 0), ("gain", 0.9), 1400), ("volume", 0, 0.4, 1500)]},
+}
 FX = {"gain": (RF.Gain, gain_tail, 0), "filter": (RF.Filter, filter_tail, 2), "delay": (RF.Delay, delay_tail, 4)}  # class, tail, pg_effect_kind
 
 
@@ -548,7 +558,9 @@ def run_scenario(sc):
             m.add_effect((mi + 1, fi), EffectProc(fx, tail(fx, SR)))
             fx_of[(mi + 1, fi)] = m
         subs.append(m)
-        main.mixers.append(SubMixer(m))
+    parents = sc.get("parents", [0] * len(subs))
+    for mi, m in enumerate(subs):
+        ([main] + subs)[parents[mi]].mixers.append(SubMixer(m))
     target = [main] + subs
     voices = []
     for vi, v in enumerate(sc["voices"]):

@@ -149,7 +149,8 @@ def _oracle_scenario(sc, g=None):
     fx_ids = {}
     mixers = [0]
     for mi, chain in enumerate(sc["mixers"]):
-        m = g.add_mixer()
+        parent = sc.get("parents", [0] * len(sc["mixers"]))[mi]
+        m = g.add_mixer() if parent == 0 else g.add_mixer(mixers[parent])
         mixers.append(m)
         for fi, (name, params) in enumerate(chain):
             fx_ids[(mi + 1, fi)] = g.add_effect(m, rgr.FX[name][2], params=params)
