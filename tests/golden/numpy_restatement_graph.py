@@ -4,6 +4,7 @@ separately from the C++ oracle (`oracle/po_sources.hpp`, `phonic_oracle.cpp`) â€
 
   * PreloadedFileSource::write / write_buffer (loop range, repeat count, EOF)          src/source/file/preloaded.rs:270-332,396-475
   * VolumeFader (stop with fade-out)                                                   src/utils/fader.rs:60-122; preloaded.rs:194-208
+  * ResampledSource + TempBuffer (a file source created at another rate than the mixer's)   src/source/resampled.rs:101-152; src/utils/buffer.rs:499-610
   * ChannelMappedSource (mono -> stereo), AmplifiedSource, PannedSource                src/source/mapped.rs:61-99, amplified.rs:93-104, panned.rs:93-104,
                                                                                         src/utils/smoothing.rs:60-122
   * MixedSource::write: messages, sample-time events splitting the block, start / stop times of sources, removal of exhausted sources,
@@ -195,6 +196,64 @@ class FileSource:  # PreloadedFileSource created at the mixer's rate
 
     def is_exhausted(self):
         return self.finished
+
+    channel_count = property(lambda self: self.nch)
+
+
+class TempBuffer:  # src/utils/buffer.rs:499-610
+    def __init__(self, capacity):
+        self.buf, self.start, self.end = np.zeros(capacity, F), 0, 0
+
+    def is_empty(self):
+        return self.start >= self.end
+
+    def get(self):
+        return self.buf[self.start:self.end]
+
+    def reset_range(self):
+        self.start, self.end = 0, len(self.buf)
+
+    def set_range(self, a, b):
+        self.start, self.end = a, b
+
+    def consume(self, n):
+        assert self.start + n <= self.end
+        self.start += n
+
+    def copy_to(self, other):
+        n = min(len(other), self.end - self.start)
+        other[:n] = self.get()[:n]
+        return n
+
+
+class Resampled:  # ResampledSource with the cubic resampler (src/source/resampled.rs:101-152): 512-frame input / output staging
+    def __init__(self, src, in_rate, out_rate):
+        self.src, self.nch = src, src.channel_count
+        self.resampler = CubicResampler(in_rate, out_rate, self.nch)
+        self.inp, self.outb = TempBuffer(512 * self.nch), TempBuffer(512 * self.nch)
+
+    def write(self, out):
+        if len(out) == 0:
+            return self.src.write(out)
+        total = 0
+        while total < len(out):
+            if self.outb.is_empty():
+                self.outb.reset_range()
+                if self.inp.is_empty():
+                    self.inp.reset_range()
+                    self.src.write(self.inp.get())  # what the source did not fill keeps its old content and is resampled all the same
+                consumed, produced = self.resampler.process(self.inp.get(), self.outb.get())
+                self.inp.consume(consumed)
+                self.outb.set_range(0, produced)
+                if self.src.is_exhausted() and produced == 0:
+                    break
+            n = self.outb.copy_to(out[total:])
+            self.outb.consume(n)
+            total += n
+        return total
+
+    def is_exhausted(self):
+        return self.src.is_exhausted() and self.inp.is_empty() and self.outb.is_empty()
 
     channel_count = property(lambda self: self.nch)
 
@@ -543,6 +602,18 @@ SCENARIOS["nested"] = {
                dict(mixer=1, tone=(6, 8000, 0.2, 1), volume=0.5, panning=0.3, start=900, repeat=0)],
     "actions": {1: [("param", (1, 0), ("gain", 0.3), 500)], 2: [("param", (2, 0), ("cuto", 600.0), 777)], 5: [("param", (1, 0), ("gain", 0.9), 1400), ("volume", 0, 0.4, 1500)]},
 }
+SCENARIOS["resampled_source"] = {
+    # file sources created at a rate other than the mixer's: ConvertedSource puts a ResampledSource (and, for the mono one, the channel mapping
+    # behind it) between the file and the mixer â€” 512-frame staging on both sides, ranges carried across calls. As written in the reference, a
+    # source that has ended leaves the input staging buffer's range at its full length, so the last 512-frame input block is resampled again
+    # and again and the wrapper never reports exhaustion (the cubic resampler states no required input size, resampled.rs:121-128): both
+    # restatements read it that way, and the one-shot voices below keep sounding to the end of the run
+    "blocks": [256, 100, 412, 64, 333, 700 - 256 - 64 - 333 + 256] + [256] * 14,
+    "mixers": [],
+    "voices": [dict(mixer=0, tone=(7, 7350, 0.3, 2), volume=0.6, panning=0.1, start=50, repeat=0, source_rate=6000),
+               dict(mixer=0, tone=(8, 5000, 0.25, 1), volume=0.5, panning=-0.5, start=1000, repeat=0, source_rate=11025)],
+    "actions": {},
+}
 FX = {"gain": (RF.Gain, gain_tail, 0), "filter": (RF.Filter, filter_tail, 2), "delay": (RF.Delay, delay_tail, 4)}  # class, tail, pg_effect_kind
 
 
@@ -565,8 +636,10 @@ def run_scenario(sc):
     voices = []
     for vi, v in enumerate(sc["voices"]):
         i, rate, seconds, nch = v["tone"]
-        f = FileSource(tone(i, rate, seconds, nch), nch, rate, SR, repeat=v["repeat"], loop_range=v.get("loop"))
-        amp = Amplified(Mapped(f), v["volume"], SR)
+        src_rate = v.get("source_rate") or SR
+        f = FileSource(tone(i, rate, seconds, nch), nch, rate, src_rate, repeat=v["repeat"], loop_range=v.get("loop"))
+        conv = Resampled(f, src_rate, SR) if src_rate != SR else f   # ConvertedSource (converted.rs:24-42): resample first, then map the channels
+        amp = Amplified(Mapped(conv), v["volume"], SR)
         chain = {"file": f, "amp": amp, "panned": Panned(amp, v["panning"], SR)}
         target[v["mixer"]].add_source(Playing(vi, chain, v["start"]))
         voices.append(v["mixer"])

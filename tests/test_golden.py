@@ -159,6 +159,8 @@ def _oracle_scenario(sc, g=None):
         i, rate, seconds, nch = v["tone"]
         rep = v["repeat"]
         loop = dict(has_loop_range=1, loop_start=v["loop"][0], loop_end=v["loop"][1]) if v.get("loop") else {}
+        if v.get("source_rate"):
+            loop["source_rate"] = v["source_rate"]
         voices.append(g.add_voice(mixers[v["mixer"]], rgr.tone(i, rate, seconds, nch), nch, rate, volume=v["volume"], panning=v["panning"], start_time=v["start"],
                                   has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER if rep == rgr.USIZE_MAX else rep, **loop))
     outs, pos = [], 0
