@@ -1337,3 +1337,39 @@ def test_reverb_wet_ramp_stays_on_the_time_parallel_kernels():
     assert deferred[4] == 1 and deferred[5] <= 1, deferred   # wet still ramping: only the staged unit is with the generic kernel
     assert deferred[8] == 0 and deferred[9] == 2 and deferred[13] == 0, deferred
     assert gg.device_errors() == 0
+
+
+def test_reverb_wet_ramp_in_a_graph_of_lean_kernels():
+    """The same ramp in a graph that holds nothing but Gain / Panning / Reverb: its fused fast kernel (`pg_unit_kernel_fast`, lean) carries no
+    ramp paths, so a ramping unit must stay with the generic kernel (which takes the time-parallel ramp path itself) until the smoother rests —
+    no kernel may meet a state it declines (pg_graph_device_errors() == 0), and the output matches the oracle."""
+    from phonic_amd.graph import Graph
+
+    def build(g):
+        ids = []
+        m = g.add_mixer()
+        ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(70)))
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.7})     # reverb not last: a fused (lean) unit, not a staged one
+        g.add_voice(m, workloads.tone_buffer(2, 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m = g.add_mixer()
+        ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(71)))
+        g.add_voice(m, workloads.tone_buffer(3, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    gg, gc = Graph(SR, 2, 1024, 0), oracle.OracleGraph(SR, 2, 1024)
+    outs, deferred = [], []
+    for g in (gg, gc):
+        ids = build(g)
+        o = np.zeros((10, 2048), np.float32)
+        for b in range(10):
+            if b == 3:
+                g.schedule_param(ids[0], "wet ", 0.85, b * 1024 + 200)
+                g.schedule_param(ids[1], "wet ", 0.1, b * 1024 + 600)
+            assert g.write(o[b], b * 1024) == 2048
+            if g is gg:
+                deferred.append(g.deferred_units())
+        outs.append(o.reshape(-1))
+    compare(outs[0], outs[1])
+    assert gg.dominant_kernel().startswith("pg_stage_fused_kernel") or "pg_unit_kernel_fast" in gg.dominant_kernel()
+    assert deferred[3] == 2 and deferred[4] == 2 and deferred[9] == 0, deferred   # both units wait out the ramp on the generic kernel
+    assert gg.device_errors() == 0
