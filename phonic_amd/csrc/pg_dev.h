@@ -245,6 +245,8 @@ enum PgCmdType {
   CMD_VOICE_SPEED = 5,  // value64 = f64 bits of the speed, value = glide (semitones/s, <= 0: none)
   CMD_VOICE_SEEK = 6,   // value64 = f64 bits of the position in seconds
   CMD_CALL_SPLIT = 7,   // nested sub-mixers: an ancestor splits its block at `frame` -> this unit's write() call ends there and a new one begins
+  CMD_NOP = 8,          // an event whose effect was removed before it came due: nothing to apply, but the mixer's block still ends a segment at its
+                        // time (the reference pops the event, logs "not found" and carries on, mixed.rs:862-924 — per-call logic counts calls)
 };
 #define PG_MAX_CALLS 64  // calls of one sub-mixer per launch round (bits of PgUnit::call_audible); the host bounds the round accordingly
 struct PgCmd {

@@ -242,6 +242,7 @@ struct HostFx {
   double vib[16] = {0};
   void* d_mem = nullptr;         // delay-line memory owned by this effect
   size_t d_mem_bytes = 0;
+  int last_mixer = -1;           // graph effects: the mixer the effect belonged to when it was removed (its late events stay that mixer's events)
 };
 
 static int host_fx_from_init(int kind, const pg_effect_init* init, HostFx& h) {
@@ -952,9 +953,13 @@ int pg_graph_remove_effect(pg_graph* g, int effect_id) {
   drain_control_messages(g);
   HostMixer& mx = g->mixers[g->fx_mixer[effect_id]];
   mx.fx.erase(std::remove(mx.fx.begin(), mx.fx.end(), effect_id), mx.fx.end());
-  auto addressed = [effect_id](const Event& e) { return (e.cmd.type == CMD_FX_PARAM || e.cmd.type == CMD_FX_RESET) && e.cmd.target == effect_id; };
-  mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), addressed), mx.events.end());
-  mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), addressed), mx.bus_events.end());
+  // Events already scheduled for the effect stay in the mixer's queue (RemoveEffect only takes the effect out of the chain, mixed.rs:433-440):
+  // when they come due they find no effect and do nothing — but they still split the block there, and the per-call logic of the effect
+  // processors and sub-mixers (tail counters start on one call and count down from the next, effect.rs:113-127) sees the extra call.
+  auto disarm = [effect_id](Event& e) { if ((e.cmd.type == CMD_FX_PARAM || e.cmd.type == CMD_FX_RESET) && e.cmd.target == effect_id) { e.cmd.type = CMD_NOP; e.cmd.target = 0; } };
+  for (Event& e : mx.events) disarm(e);
+  for (Event& e : mx.bus_events) disarm(e);
+  g->fx[effect_id]->last_mixer = g->fx_mixer[effect_id];
   g->fx_mixer[effect_id] = -1;
   g->fx_kind_tab.set((size_t)effect_id, -1);
   g->topo_dirty = true;
@@ -1154,7 +1159,12 @@ static void drain_control_messages(pg_graph* g) {
     memset(&c, 0, sizeof c);
     switch (m.type) {
       case pgc::CT_FX_PARAM: {
-        if (m.id < 0 || m.id >= (int)g->fx.size() || g->fx_mixer[m.id] < 0) break;  // removed in the meantime: dropped, as an event for a missing effect is (mixed.rs:880-924)
+        if (m.id < 0 || m.id >= (int)g->fx.size()) break;
+        if (g->fx_mixer[m.id] < 0) {  // removed in the meantime: the event will find no effect (mixed.rs:880-924), but it is an event of that mixer all the same
+          const int lm = g->fx[m.id]->last_mixer;
+          if (lm >= 0 && lm < (int)g->mixers.size() && !g->mixers[lm].removed) { c.type = CMD_NOP; push_event(g, lm, m.sample_time, c); }
+          break;
+        }
         HostFx& h = *g->fx[m.id];
         h.target[m.param] = m.value;
         // a Gain whose DC filter gets switched on later needs the kernel variants that carry the DC scan: classify the chain again
@@ -1163,7 +1173,12 @@ static void drain_control_messages(pg_graph* g) {
         push_event(g, g->fx_mixer[m.id], m.sample_time, c);
       } break;
       case pgc::CT_FX_RESET: {
-        if (m.id < 0 || m.id >= (int)g->fx.size() || g->fx_mixer[m.id] < 0) break;
+        if (m.id < 0 || m.id >= (int)g->fx.size()) break;
+        if (g->fx_mixer[m.id] < 0) {
+          const int lm = g->fx[m.id]->last_mixer;
+          if (lm >= 0 && lm < (int)g->mixers.size() && !g->mixers[lm].removed) { c.type = CMD_NOP; push_event(g, lm, m.sample_time, c); }
+          break;
+        }
         c.type = CMD_FX_RESET; c.target = m.id;
         push_event(g, g->fx_mixer[m.id], m.sample_time, c);
       } break;
@@ -1456,14 +1471,14 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
     HostMixer& main = g->mixers[0];
     while (!main.events.empty() && main.events.front().sample_time <= now) {
       PgCmd c = main.events.front().cmd;
-      if (g->defer_bus && (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET)) {  // the bus chain runs in pg_graph_process_bus_device
+      if (g->defer_bus && (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET || c.type == CMD_NOP)) {  // the bus chain runs in pg_graph_process_bus_device
         if (main.bus_events.size() >= 65536) main.bus_events.erase(main.bus_events.begin(), main.bus_events.begin() + 32768);  // a shard that never runs the bus
         main.bus_events.push_back(main.events.front());
         main.events.erase(main.events.begin());
         continue;
       }
       c.frame = 0;
-      c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET) ? main.unit_slot : g->source_unit_of_voice[c.param];  // voice commands carry the voice id in `param`
+      c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET || c.type == CMD_NOP) ? main.unit_slot : g->source_unit_of_voice[c.param];  // voice commands carry the voice id in `param`
       cmds.push_back(c);
       main.events.erase(main.events.begin());
     }

@@ -703,7 +703,9 @@ DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBloc
 
 DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgReverb& r = fx.u.reverb;
-  if (sm_need_ramp(r.room) || sm_need_ramp(r.wet)) return false;  // per-frame delay sizes / coefficients: exact serial path
+  // per-frame delay sizes / coefficients while a smoother moves, or a ring position still above a ring end the room left behind when it
+  // shrank (the mid stage's ring arithmetic has no case for it): exact serial path
+  if (!reverb_fast_eligible(fx)) return false;
   const int frames = n_samples / 2;
   if (frames == 0) return true;
   const RevLds m = rev_lds(fc.scratch);

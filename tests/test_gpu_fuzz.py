@@ -126,11 +126,9 @@ def test_random_graph_matches_oracle(seed):
     assert float(np.abs(d).max()) <= 1e-4 * scale, what
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24)))
-def test_random_nested_graph_matches_oracle(seed):
-    """Player::add_mixer(parent): random mixer trees up to depth 4. Events on a mixer with sub-mixers (effect parameters, voice
-    volume) split its block, and with it the write() calls its sub-mixers see (per-call silence gate and bypass logic)."""
-    from phonic_amd.graph import Graph, effect_parameters
+def make_nested_plan(seed):
+    """Random mixer trees up to depth 4 with events on mixers that have sub-mixers of their own."""
+    from phonic_amd.graph import effect_parameters
 
     rng = np.random.default_rng(5000 + seed)
     descs = {k: effect_parameters(k) for k in range(10)}
@@ -151,52 +149,71 @@ def test_random_nested_graph_matches_oracle(seed):
     sizes = [int(rng.choice([1024, 1024, 512, 700, 333])) for _ in range(8)]
     n_events = int(rng.integers(2, 9))
     ev_plan = [(int(rng.integers(1, len(sizes))), float(rng.random()), int(rng.integers(0, 1 << 30)), float(rng.uniform(0.1, 0.9))) for _ in range(n_events)]
+    return {"seed": seed, "descs": descs, "mixers": mixers, "sizes": sizes, "ev_plan": ev_plan}
 
-    outs = []
-    for which in ("gpu", "oracle"):
-        g = oracle.OracleGraph(SR, 2, 1024) if which == "oracle" else Graph(SR, 2, 1024, 0)
-        ids, fx_ids, voice_ids, fx_mixer = [], [], [], {}
-        rng2 = np.random.default_rng(7000 + seed)  # chain mutations: the same draws for both sides
-        for parent, chain, voices in mixers:
-            m = g.add_mixer(None if parent < 0 else ids[parent])
-            ids.append(m)
-            for (k, p, s) in chain:
-                fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
-                fx_mixer[fx_ids[-1][0]] = m
-            for (ti, rate, vol, pan) in voices:
-                voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
-        chunks, pos = [], 0
-        for b, n in enumerate(sizes):
-            for (eb, frac, pick, val) in ev_plan:
-                if eb != b:
+
+def render_nested_plan(plan, g, mutations=True, events=True):
+    seed, descs, mixers, sizes, ev_plan = plan["seed"], plan["descs"], plan["mixers"], plan["sizes"], plan["ev_plan"]
+    ids, fx_ids, voice_ids, fx_mixer = [], [], [], {}
+    rng2 = np.random.default_rng(7000 + seed)  # chain mutations: the same draws for both sides
+    for parent, chain, voices in mixers:
+        m = g.add_mixer(None if parent < 0 else ids[parent])
+        ids.append(m)
+        for (k, p, s) in chain:
+            fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
+            fx_mixer[fx_ids[-1][0]] = m
+        for (ti, rate, vol, pan) in voices:
+            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+    chunks, pos = [], 0
+    for b, n in enumerate(sizes):
+        for (eb, frac, pick, val) in ev_plan:
+            if eb != b or not events:
+                continue
+            t = pos + int(frac * n)
+            if fx_ids and pick % 2 == 0:
+                fid, k = fx_ids[(pick >> 1) % len(fx_ids)]
+                d = descs[k][0]
+                if d["type"] == 0 and fid in fx_mixer:
+                    g.schedule_param(fid, fourcc_str(d["fourcc"]), val, t, normalized=True)
                     continue
-                t = pos + int(frac * n)
-                if fx_ids and pick % 2 == 0:
-                    fid, k = fx_ids[(pick >> 1) % len(fx_ids)]
-                    d = descs[k][0]
-                    if d["type"] == 0 and fid in fx_mixer:
-                        g.schedule_param(fid, fourcc_str(d["fourcc"]), val, t, normalized=True)
-                        continue
-                g.set_voice_volume(voice_ids[(pick >> 1) % len(voice_ids)], val, t)
-            if b in (3, 5) and fx_ids and seed % 2 == 1:  # Player::move_effect / remove_effect between blocks
-                fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
-                if fid in fx_mixer:
-                    if rng2.random() < 0.6:
-                        g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
-                    else:
-                        g.remove_effect(fid)
-                        del fx_mixer[fid]
-            o = np.zeros(2 * n, np.float32)
-            assert g.write(o, pos) in (0, 2 * n)
-            chunks.append(o)
-            pos += n
-        outs.append(np.concatenate(chunks))
-    a, b = outs
+            g.set_voice_volume(voice_ids[(pick >> 1) % len(voice_ids)], val, t)
+        if mutations and b in (3, 5) and fx_ids and seed % 2 == 1:  # Player::move_effect / remove_effect between blocks
+            fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
+            if fid in fx_mixer:
+                if rng2.random() < 0.6:
+                    g.move_effect(fid, fx_mixer[fid], _capi.MOVE_DIRECTION, int(rng2.integers(-3, 4)))
+                else:
+                    g.remove_effect(fid)
+                    del fx_mixer[fid]
+        o = np.zeros(2 * n, np.float32)
+        assert g.write(o, pos) in (0, 2 * n)
+        chunks.append(o)
+        pos += n
+    return np.concatenate(chunks)
+
+
+# seeds a wide campaign found: 2141 — a parameter event scheduled for an effect that is removed before the event comes due (the event must still
+# split the block: the effect processors' tail counters count calls); 3442 — a room that shrinks leaves a ring position above the new ring end,
+# and the generic kernel must not hand that block to the time-parallel reverb
+NESTED_REGRESSION_SEEDS = [] if FUZZ_SEEDS else [2141, 3442]
+
+
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24))) + NESTED_REGRESSION_SEEDS)
+def test_random_nested_graph_matches_oracle(seed):
+    """Player::add_mixer(parent): random mixer trees up to depth 4. Events on a mixer with sub-mixers (effect parameters, voice
+    volume) split its block, and with it the write() calls its sub-mixers see (per-call silence gate and bypass logic)."""
+    from phonic_amd.graph import Graph
+
+    plan = make_nested_plan(seed)
+    a = render_nested_plan(plan, Graph(SR, 2, 1024, 0))
+    b = render_nested_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all()
     if float(np.abs(b).max()) <= 1e-4:
         assert float(np.abs(a).max()) <= 1e-4
         pytest.skip("silent case")
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
-    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
-    assert float(np.abs(d).max()) <= 1e-4 * scale
+    what = {"mixers": [(parent, [(_capi.FX_NAMES[k], p) for (k, p, _) in chain], len(voices)) for parent, chain, voices in plan["mixers"]],
+            "rms_per_block": [float(np.sqrt(np.mean(x * x))) for x in np.array_split(d, len(plan["sizes"]))], "peak": float(np.abs(b).max())}
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) {what}"
+    assert float(np.abs(d).max()) <= 1e-4 * scale, what

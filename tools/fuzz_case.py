@@ -1,6 +1,8 @@
-"""usage (GPU box): python tools/fuzz_case.py SEED — where does a fuzz graph's GPU-vs-oracle difference come from? Renders the seed's plan
-(tests/test_gpu_fuzz.py: make_plan / render_plan) whole, on the exact serial kernels, one sub-mixer at a time and with that sub-mixer's chain cut
-after each effect, and prints the RMS difference against the oracle per block."""
+"""usage (GPU box): python tools/fuzz_case.py SEED [nested] — where does a fuzz graph's GPU-vs-oracle difference come from?
+
+Flat graphs (tests/test_gpu_fuzz.py: make_plan / render_plan): the seed's plan whole, on the exact serial kernels, one sub-mixer at a time and with
+that sub-mixer's chain cut after each effect. Nested graphs (make_nested_plan / render_nested_plan): whole, on the exact serial kernels, without the
+chain mutations, without the events, and with one mixer's chain emptied at a time. Prints the RMS difference against the oracle per block."""
 import copy
 import os
 import sys
@@ -15,14 +17,10 @@ from phonic_amd import _capi  # noqa: E402
 from phonic_amd.graph import Graph  # noqa: E402
 
 
-def run(plan, exact=False):
-    g = Graph(F.SR, 2, 1024, 0)
-    if exact:
-        g.set_fast_math(0)
-    a = F.render_plan(plan, g)
-    b = F.render_plan(plan, oracle.OracleGraph(F.SR, 2, 1024))
+def diff(a, b, sizes):
     d = a.astype(np.float64) - b.astype(np.float64)
-    per = [float(np.sqrt(np.mean(x * x))) for x in np.array_split(d, len(plan["sizes"]))]
+    edges = np.cumsum([0] + [2 * n for n in sizes])
+    per = [float(np.sqrt(np.mean(d[edges[i]:edges[i + 1]] ** 2))) for i in range(len(sizes))]
     return float(np.sqrt(np.mean(d * d))), float(np.abs(b).max()), per
 
 
@@ -30,21 +28,60 @@ def names(chain):
     return [_capi.FX_NAMES[k] for (k, _, _) in chain]
 
 
+def fmt(per):
+    return [f"{x:.1e}" for x in per]
+
+
+def run(plan, exact=False):
+    g = Graph(F.SR, 2, 1024, 0)
+    if exact:
+        g.set_fast_math(0)
+    a = F.render_plan(plan, g)
+    b = F.render_plan(plan, oracle.OracleGraph(F.SR, 2, 1024))
+    return diff(a, b, plan["sizes"])
+
+
+def run_nested(plan, exact=False, mutations=True, events=True):
+    g = Graph(F.SR, 2, 1024, 0)
+    if exact:
+        g.set_fast_math(0)
+    a = F.render_nested_plan(plan, g, mutations, events)
+    b = F.render_nested_plan(plan, oracle.OracleGraph(F.SR, 2, 1024), mutations, events)
+    return diff(a, b, plan["sizes"]) + (g.device_errors(),)
+
+
 seed = int(sys.argv[1])
-plan = F.make_plan(seed)
-print("seed", seed, "sizes", plan["sizes"], "event block", plan["ev_block"])
-for i, (chain, voices) in enumerate(plan["mixers"]):
-    print(" mixer", i, names(chain), "voices", [(v[1], round(v[2], 2)) for v in voices])
-print(" bus", names(plan["bus"]))
-for label, exact in (("time-parallel kernels", False), ("exact serial kernels", True)):
-    rms, peak, per = run(plan, exact)
-    print(f"whole graph, {label}: rms {rms:.3e} peak {peak:.3f} per block {[f'{x:.1e}' for x in per]}")
-for i, (chain, voices) in enumerate(plan["mixers"]):
-    for cut in range(len(chain) + 1):
+if len(sys.argv) > 2 and sys.argv[2] == "nested":
+    plan = F.make_nested_plan(seed)
+    print("seed", seed, "sizes", plan["sizes"], "events (block, frac, pick, value)", [(e[0], round(e[1], 3), e[2], round(e[3], 3)) for e in plan["ev_plan"]])
+    for i, (parent, chain, voices) in enumerate(plan["mixers"]):
+        print(" mixer", i, "parent", parent, [(n, p) for n, (_, p, _) in zip(names(chain), chain)], "voices", [(v[1], round(v[2], 2)) for v in voices])
+    for label, kw in (("time-parallel kernels", {}), ("exact serial kernels", {"exact": True}), ("no chain mutations", {"mutations": False}),
+                      ("no events, no mutations", {"mutations": False, "events": False})):
+        rms, peak, per, err = run_nested(plan, **kw)
+        print(f"whole graph, {label}: rms {rms:.3e} peak {peak:.3f} device errors {err} per block {fmt(per)}")
+    for i, (parent, chain, voices) in enumerate(plan["mixers"]):
+        if not chain:
+            continue
         p = copy.copy(plan)
-        p["mixers"] = [(chain[:cut], voices)]
-        p["bus"] = []
-        p["ev_block"] = 99  # no events, no chain mutations: the chain as built
-        rms, peak, per = run(p)
-        rms_x, _, _ = run(p, True)
-        print(f"mixer {i} alone, chain {names(chain[:cut])}: rms {rms:.3e} (exact kernels {rms_x:.3e}) peak {peak:.3f} worst block {max(per):.1e}")
+        p["mixers"] = [(pa, [] if j == i else ch, vo) for j, (pa, ch, vo) in enumerate(plan["mixers"])]
+        rms, peak, per, err = run_nested(p, mutations=False, events=False)
+        print(f"without the chain of mixer {i} {names(chain)} (no events, no mutations): rms {rms:.3e} per block {fmt(per)}")
+else:
+    plan = F.make_plan(seed)
+    print("seed", seed, "sizes", plan["sizes"], "event block", plan["ev_block"])
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        print(" mixer", i, names(chain), "voices", [(v[1], round(v[2], 2)) for v in voices])
+    print(" bus", names(plan["bus"]))
+    for label, exact in (("time-parallel kernels", False), ("exact serial kernels", True)):
+        rms, peak, per = run(plan, exact)
+        print(f"whole graph, {label}: rms {rms:.3e} peak {peak:.3f} per block {fmt(per)}")
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        for cut in range(len(chain) + 1):
+            p = copy.copy(plan)
+            p["mixers"] = [(chain[:cut], voices)]
+            p["bus"] = []
+            p["ev_block"] = 99  # no events, no chain mutations: the chain as built
+            rms, peak, per = run(p)
+            rms_x, _, _ = run(p, True)
+            print(f"mixer {i} alone, chain {names(chain[:cut])}: rms {rms:.3e} (exact kernels {rms_x:.3e}) peak {peak:.3f} worst block {max(per):.1e}")
