@@ -1144,6 +1144,17 @@ int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // M
 }
 
 // insert_event (src/utils/event.rs:31-38): sorted by sample time, after the events of the same time
+// PgCmd::value64 of a parameter update: the coefficients that follow from a new attack / release time of the Compressor's and the Gate's envelope
+// follower (EnvelopeFollower::set_attack_time / set_release_time, envelope.rs:27-42) and of the Gate's gain smoothing (gate.rs:80-90), computed here
+// with the host's expf — the same call the effect's initial state was built with, and the one the reference makes.
+static uint64_t fx_param_aux(int kind, int param, float raw, uint32_t sr) {
+  float lo = 0.0f, hi = 0.0f;
+  if (kind == PG_FX_COMPRESSOR && (param == P_COMP_ATTACK || param == P_COMP_RELEASE)) lo = env_coeff(raw, sr);
+  else if (kind == PG_FX_GATE && (param == P_GATE_ATTACK || param == P_GATE_RELEASE)) { lo = env_coeff(raw, sr); hi = std::exp(-1.0f / (raw * (float)sr)); }
+  uint32_t l, h;
+  memcpy(&l, &lo, 4); memcpy(&h, &hi, 4);
+  return (uint64_t)l | ((uint64_t)h << 32);
+}
 static void push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
   HostMixer& mx = g->mixers[mixer];
   Event e{sample_time, g->event_seq++, cmd, mixer};
@@ -1169,7 +1180,7 @@ static void drain_control_messages(pg_graph* g) {
         h.target[m.param] = m.value;
         // a Gain whose DC filter gets switched on later needs the kernel variants that carry the DC scan: classify the chain again
         if (h.kind == PG_FX_GAIN && m.param != P_GAIN_GAIN && (int)m.value != 0 && (int)h.init_raw[1] == 0) { h.init_raw[1] = m.value; g->topo_dirty = true; }
-        c.type = CMD_FX_PARAM; c.target = m.id; c.param = m.param; c.value = m.value;
+        c.type = CMD_FX_PARAM; c.target = m.id; c.param = m.param; c.value = m.value; c.value64 = fx_param_aux(h.kind, m.param, m.value, g->sample_rate);
         push_event(g, g->fx_mixer[m.id], m.sample_time, c);
       } break;
       case pgc::CT_FX_RESET: {
@@ -1994,7 +2005,7 @@ int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_n
   if (!e->initialized) { e->host.init_raw[pi] = raw; return PG_OK; }  // before initialize: plain value update
   PgCmd c;
   memset(&c, 0, sizeof c);
-  c.type = CMD_FX_PARAM; c.unit = 0; c.target = 0; c.param = pi; c.value = raw; c.frame = 0;
+  c.type = CMD_FX_PARAM; c.unit = 0; c.target = 0; c.param = pi; c.value = raw; c.frame = 0; c.value64 = fx_param_aux(e->kind, pi, raw, e->sample_rate);
   if (e->pending.size() >= 64) { int rc = effect_run(e, nullptr, 0, 0); if (rc) return rc; }
   e->pending.push_back(c);
   return PG_OK;

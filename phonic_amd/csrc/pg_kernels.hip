@@ -25,7 +25,10 @@ using namespace pgd;
 
 // ---- parameter updates (Effect::process_parameter_update of each effect), lane 0 --------------------
 // Returns 1 when the whole workgroup must flush state afterwards (compressor look-ahead line re-created).
-__device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value) {
+// aux: time-constant coefficients the HOST computed for this update (pg_host.hip: fx_param_aux) — exp(-1 / (t * fs)) sits within 1e-5 of one, where a
+// one-ulp difference between two libm implementations of expf is half a percent of the time constant; the reference's value is the host libm's.
+__device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value, unsigned long long aux) {
+  const float aux_lo = __uint_as_float((uint32_t)aux), aux_hi = __uint_as_float((uint32_t)(aux >> 32));
   uint32_t sr = fx.sample_rate;
   switch (fx.kind) {
     case 0: {  // gain.rs:177-205
@@ -108,13 +111,11 @@ __device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value) {
         case P_COMP_THRESHOLD: c.threshold = value; break;
         case P_COMP_RATIO: c.ratio = value; break;
         case P_COMP_KNEE: c.knee = value; break;
-        case P_COMP_ATTACK: c.attack = value; break;
-        case P_COMP_RELEASE: c.release = value; break;
+        case P_COMP_ATTACK: c.attack = value; c.env_attack = aux_lo; break;    // (update_coefficients recomputes both from the stored times:
+        case P_COMP_RELEASE: c.release = value; c.env_release = aux_lo; break;  //  only the one whose time changed can change)
         case P_COMP_MAKEUP: sm_set_target(c.makeup, value); break;
         default: c.lookahead = value; break;
       }
-      c.env_attack = env_coeff(c.attack, sr);
-      c.env_release = env_coeff(c.release, sr);
       if (c.lookahead != old_lookahead) {  // LookupDelayLine::new  delay.rs:182-203
         uint32_t df = (uint32_t)f2u64(ceilf(c.lookahead * (float)sr));
         c.delay_frames = df;
@@ -128,15 +129,11 @@ __device__ __noinline__ int fx_apply_param(PgFx& fx, int param, float value) {
       PgGate& g = fx.u.gate;
       switch (param) {
         case P_GATE_THRESHOLD: g.threshold = value; break;
-        case P_GATE_ATTACK: g.attack = value; break;
+        case P_GATE_ATTACK: g.attack = value; g.env_attack = aux_lo; g.attack_coeff = aux_hi; break;
         case P_GATE_HOLD: g.hold = value; break;
-        case P_GATE_RELEASE: g.release = value; break;
+        case P_GATE_RELEASE: g.release = value; g.env_release = aux_lo; g.release_coeff = aux_hi; break;
         default: g.range = value; break;
       }
-      g.env_attack = env_coeff(g.attack, sr);
-      g.env_release = env_coeff(g.release, sr);
-      g.attack_coeff = expf(-1.0f / (g.attack * (float)sr));
-      g.release_coeff = expf(-1.0f / (g.release * (float)sr));
     } break;
     default: {  // distortion.rs:368-385
       PgDist& d = fx.u.dist;
@@ -393,7 +390,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       int flush = 0;
       __syncthreads();
       if (tid == 0) {
-        if (cmd.type == CMD_FX_PARAM) flush = fx_apply_param(L.fx[cmd.target], cmd.param, cmd.value);
+        if (cmd.type == CMD_FX_PARAM) flush = fx_apply_param(L.fx[cmd.target], cmd.param, cmd.value, cmd.value64);
         else if (cmd.type == CMD_VOICE_VOLUME) sm_set_target(L.voices[cmd.target].volume, cmd.value);
         else if (cmd.type == CMD_VOICE_PAN) sm_set_target(L.voices[cmd.target].panning, cmd.value);
         else if (cmd.type == CMD_VOICE_STOP) { L.voices[cmd.target].has_stop = 1; L.voices[cmd.target].stop_time = cmd.value64; }
