@@ -66,8 +66,10 @@ def make_plan(seed):
     return plan
 
 
-def render_plan(plan, g):
-    """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its blocks, events and chain mutations included."""
+def render_plan(plan, g, split=0, events_at_call_start=False):
+    """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its blocks, events and chain mutations included. split: pull
+    every block in pieces of that many frames (the oracle walks a long write in chunks of its 4096-frame mix buffer, a HIP graph in chunks of
+    its max_frames: per-call logic — tails, ramps — sees different calls unless the caller pulls both in the same pieces)."""
     seed, descs, sizes, ev_block = plan["seed"], plan["descs"], plan["sizes"], plan["ev_block"]
     fx_ids, voice_ids, fx_mixer = [], [], {}
     for chain, voices in plan["mixers"]:
@@ -85,12 +87,12 @@ def render_plan(plan, g):
     for b, n in enumerate(sizes):
         if b == ev_block:
             if voice_ids:
-                g.set_voice_volume(voice_ids[0], 0.3, pos + 17)
+                g.set_voice_volume(voice_ids[0], 0.3, pos if events_at_call_start else pos + 17)
             if fx_ids:
                 fid, k = fx_ids[seed % len(fx_ids)]
                 d = descs[k][0]
                 if d["type"] == 0:
-                    g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos + n // 2, normalized=True)
+                    g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos if events_at_call_start else pos + n // 2, normalized=True)
         if b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
             fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
             if fid in fx_mixer:
@@ -100,7 +102,9 @@ def render_plan(plan, g):
                     g.remove_effect(fid)
                     del fx_mixer[fid]
         o = np.zeros(2 * n, np.float32)
-        assert g.write(o, pos) in (0, 2 * n)
+        for off in range(0, n, split or n):
+            m = min(split or n, n - off)
+            assert g.write(o[2 * off:2 * (off + m)], pos + off) in (0, 2 * m)
         chunks.append(o)
         pos += n
     return np.concatenate(chunks)
@@ -124,6 +128,34 @@ def test_random_graph_matches_oracle(seed):
             "rms_per_block": [float(np.sqrt(np.mean(x * x))) for x in np.array_split(d, len(sizes))], "peak": float(np.abs(b).max())}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) {what}"
     assert float(np.abs(d).max()) <= 1e-4 * scale, what
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16)))
+def test_random_graph_superblock_writes(seed):
+    """The same random graphs pulled in calls of one to four whole blocks with super-block launches enabled (pg_graph_set_max_blocks_per_launch):
+    units enter and leave the steady state (events, chain mutations, voices that end, tails, gates), and the host must fall back to single
+    blocks exactly where it has to — the render equals the block-by-block pull BIT FOR BIT. Events sit at the start of a call here: behind an
+    event inside a call the chunks are counted from the event (as MixedSource::write counts them, mixed.rs:679-712), not from the caller's
+    block grid, and per-call logic (ramps, tails) then legitimately sees other calls than a block-by-block pull would give it."""
+    from phonic_amd.graph import Graph
+
+    plan = make_plan(seed)
+    rng = np.random.default_rng(11000 + seed)
+    plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+    g = Graph(SR, 2, 1024, 0)
+    g.set_max_blocks_per_launch(4)
+    a = render_plan(plan, g, events_at_call_start=True)
+    a1 = render_plan(plan, Graph(SR, 2, 1024, 0), split=1024, events_at_call_start=True)           # the same pull, block by block
+    assert np.array_equal(a, a1), f"super-block render differs from the block-by-block one in {int(np.count_nonzero(a != a1))} samples, sizes {plan['sizes']}"
+    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024), split=1024, events_at_call_start=True)
+    assert np.isfinite(a).all() and g.device_errors() == 0
+    if float(np.abs(b).max()) <= 1e-4:
+        assert float(np.abs(a).max()) <= 1e-4
+        pytest.skip("silent case")
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) sizes {plan['sizes']}"
+    assert float(np.abs(d).max()) <= 1e-4 * scale
 
 
 def make_nested_plan(seed):

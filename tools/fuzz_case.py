@@ -51,7 +51,29 @@ def run_nested(plan, exact=False, mutations=True, events=True):
 
 
 seed = int(sys.argv[1])
-if len(sys.argv) > 2 and sys.argv[2] == "nested":
+if len(sys.argv) > 2 and sys.argv[2] == "super":   # a seed of test_random_graph_superblock_writes
+    plan = F.make_plan(seed)
+    rng = np.random.default_rng(11000 + seed)
+    plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+    print("seed", seed, "call sizes in blocks", [n // 1024 for n in plan["sizes"]], "event block", plan["ev_block"])
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        print(" mixer", i, [(n, p) for n, (_, p, _) in zip(names(chain), chain)], "voices", [(v[1], round(v[2], 2)) for v in voices])
+    print(" bus", [(n, p) for n, (_, p, _) in zip(names(plan["bus"]), plan["bus"])])
+    g = Graph(F.SR, 2, 1024, 0)
+    g.set_max_blocks_per_launch(4)
+    a = F.render_plan(plan, g, events_at_call_start=True)
+    a1 = F.render_plan(plan, Graph(F.SR, 2, 1024, 0), split=1024, events_at_call_start=True)
+    gx = Graph(F.SR, 2, 1024, 0)
+    gx.set_fast_math(0)
+    ax = F.render_plan(plan, gx, split=1024, events_at_call_start=True)
+    b = F.render_plan(plan, oracle.OracleGraph(F.SR, 2, 1024), split=1024, events_at_call_start=True)
+    blocks = [1024] * (len(a) // 2048)
+    print("super vs block-by-block, samples differing per block:", [int(np.count_nonzero(a[i * 2048:(i + 1) * 2048] != a1[i * 2048:(i + 1) * 2048])) for i in range(len(blocks))])
+    print("super vs block-by-block rms per block:", fmt(diff(a, a1, blocks)[2]))
+    print("block-by-block vs oracle rms per block:", fmt(diff(a1, b, blocks)[2]))
+    print("exact kernels  vs oracle rms per block:", fmt(diff(ax, b, blocks)[2]))
+    print("device errors", g.device_errors())
+elif len(sys.argv) > 2 and sys.argv[2] == "nested":
     plan = F.make_nested_plan(seed)
     print("seed", seed, "sizes", plan["sizes"], "events (block, frac, pick, value)", [(e[0], round(e[1], 3), e[2], round(e[3], 3)) for e in plan["ev_plan"]])
     for i, (parent, chain, voices) in enumerate(plan["mixers"]):
