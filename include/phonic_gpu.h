@@ -235,7 +235,11 @@ size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64
  * spans several blocks of max_frames may render up to `n_blocks` of them in ONE launch sequence when nothing is scheduled inside them and
  * every unit is in steady state (MixedSource::write walks its chunks inside one call the same way, src/source/mixed.rs:679-712). All
  * per-block semantics (bypass counters, tails, silence gates) stay per block. Default 1; sizes the per-unit output table
- * (n_blocks x units x max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph. */
+ * (n_blocks x units x max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph.
+ * max_frames plays the part of the reference's mix buffer (4096 frames there, mixed.rs:216): inside one write*() call the chunks run from the
+ * call's start — and from every main-mixer event that falls inside the call — in steps of max_frames, exactly as MixedSource::write counts
+ * them; a caller that wants the chunk grid of a block-by-block pull puts its events on call boundaries or pulls block by block.
+ * (pg_graph_write with a host buffer hands the graph at most n_blocks x max_frames frames per call and loops over longer buffers.) */
 int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks);
 /* Process-wide counters of the library's own HIP calls: out[0] = allocations (hipMalloc / hipHostMalloc), out[1] = releases, out[2] = host
  * waits for a stream (hipStreamSynchronize), out[3] = blocking copies / fills. The reference runs its audio callback under
