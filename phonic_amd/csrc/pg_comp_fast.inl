@@ -84,11 +84,11 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       for (int n = tid; n < N; n += nt) {   // window [i - W + 1, i] = [i - span + 1, i] U [i - W + 1, i - W + span]
         const int i = n + H;
         const float m = fmaxf(src[i], src[i - W + span]);
-        env[n] = (m > 1e-6f) ? 20.0f * log10f(m) : -120.0f;
+        env[n] = (m > 1e-6f) ? 20.0f * pg_log10f(m) : -120.0f;
       }
     } else {
       __syncthreads();
-      for (int n = tid; n < N; n += nt) { const float fp = a0[n + H]; env[n] = (fp > 1e-6f) ? 20.0f * log10f(fp) : -120.0f; }
+      for (int n = tid; n < N; n += nt) { const float fp = a0[n + H]; env[n] = (fp > 1e-6f) ? 20.0f * pg_log10f(fp) : -120.0f; }
     }
     __syncthreads();
     // 4. envelope follower: the one serial recurrence; meanwhile the other lanes stage the input (the output pass overwrites it)

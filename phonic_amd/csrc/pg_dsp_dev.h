@@ -283,6 +283,54 @@ DEV float env_run(float& current, float attack_coeff, float release_coeff, float
   else current = input + release_coeff * (current - input);
   return current;
 }
+// log10f as the HOST's libm computes it. The level detectors of the Compressor and the Gate feed `20 * log10f(peak)` into decisions — the
+// envelope follower's attack / release switch, the gate's `envelope >= threshold`, the edges of the compressor's knee (the reference's gain
+// computer even has a hole exactly on the upper edge, compressor.rs:272-283) — so one ulp between two libm implementations can move a gate's
+// opening by a frame or put a one-frame click into one side only (found by the fuzz campaigns). The reference calls the platform's
+// log10f; on the Linux boxes this library runs on that is glibc's: __ieee754_log10f (fdlibm's scaling around logf, sysdeps/ieee754/flt-32/
+// e_log10f.c) over the table-driven logf of ARM's optimized-routines (sysdeps/ieee754/flt-32/e_logf.c, MIT), restated here operation by operation
+// for finite normal x > 0 (the callers pass peaks > 1e-6) — bit-identical to glibc 2.35 on 2e8 random arguments (tests/host/log10f_check.c).
+DEV float pg_logf_glibc(float x) {
+  const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,
+                           0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                           0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+  const double logc[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3, -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,
+                           -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4, -0x1.252f438e10c1ep-5, 0x0p+0, 0x1.aa5aa5df25984p-5, 0x1.c5e53aa362eb4p-4,
+                           0x1.526e57720db08p-3, 0x1.bc2860d22477p-3, 0x1.1058bc8a07ee1p-2, 0x1.4043057b6ee09p-2};
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  if (ix == 0x3f800000u) return 0.0f;
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const int k = (int)((int32_t)tmp >> 23);
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  float zf;
+  memcpy(&zf, &iz, 4);
+  const double z = (double)zf;
+  const double r = z * invc[i] - 1.0;
+  const double y0 = logc[i] + (double)k * 0x1.62e42fefa39efp-1;
+  const double r2 = r * r;
+  double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+  y = -0x1.00ea348b88334p-2 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+DEV float pg_log10f(float x) {
+  uint32_t ux;
+  memcpy(&ux, &x, 4);
+  if (ux < 0x00800000u || ux >= 0x7f800000u) return log10f(x);  // zero, subnormal, negative, inf, nan: not reached by the level detectors
+  const float ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+  int32_t hx = (int32_t)ux;
+  const int32_t k = (hx >> 23) - 127;
+  const int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+  const float y = (float)(k + i);
+  float xr;
+  const uint32_t uh = (uint32_t)hx;
+  memcpy(&xr, &uh, 4);
+  const float z = y * log10_2lo + ivln10 * pg_logf_glibc(xr);
+  return z + y * log10_2hi;
+}
 DEV float env_coeff(float t, uint32_t sr) { return (t > 0.0f) ? expf(-1.0f / (t * (float)sr)) : 0.0f; }  // :27-42
 
 // workgroup max-reduction of |x| over an LDS buffer (max_abs_sample, src/utils/buffer.rs:150-173; order free)

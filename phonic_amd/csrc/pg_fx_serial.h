@@ -434,10 +434,10 @@ DEVN void comp_serial(PgFx& fx, float* sig, int n) {
     float input_db;
     if (c.ratio >= 20.0f) {
       float lookahead_peak = (float)c.peak_value;
-      input_db = (lookahead_peak > 1e-6f) ? 20.0f * log10f(lookahead_peak) : -120.0f;
+      input_db = (lookahead_peak > 1e-6f) ? 20.0f * pg_log10f(lookahead_peak) : -120.0f;
     } else {
       float frame_peak = fmaxf(fabsf(in_frame[0]), fabsf(in_frame[1]));
-      input_db = (frame_peak > 1e-6f) ? 20.0f * log10f(frame_peak) : -120.0f;
+      input_db = (frame_peak > 1e-6f) ? 20.0f * pg_log10f(frame_peak) : -120.0f;
     }
     float envelope = env_run(c.env_current, c.env_attack, c.env_release, input_db);
     float t = c.threshold, w = c.knee;
@@ -468,7 +468,7 @@ DEVN void gate_serial(PgFx& fx, float* sig, int n) {
   uint32_t hold_counter = g.hold_counter;
   for (int f = 0; f + 2 <= n; f += 2) {
     float frame_peak = fmaxf(fabsf(sig[f]), fabsf(sig[f + 1]));
-    float input_db = (frame_peak > 1e-6f) ? 20.0f * log10f(frame_peak) : -120.0f;
+    float input_db = (frame_peak > 1e-6f) ? 20.0f * pg_log10f(frame_peak) : -120.0f;
     float envelope = env_run(env, g.env_attack, g.env_release, input_db);
     float target_gain_db;
     if (envelope >= threshold) { hold_counter = hold_samples; target_gain_db = 0.0f; }

@@ -15,7 +15,7 @@ DEVO bool gate_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     __syncthreads();
     for (int n = tid; n < N; n += nt) {
       const float frame_peak = fmaxf(fabsf(sp[2 * n]), fabsf(sp[2 * n + 1]));
-      db[n] = (frame_peak > 1e-6f) ? 20.0f * log10f(frame_peak) : -120.0f;
+      db[n] = (frame_peak > 1e-6f) ? 20.0f * pg_log10f(frame_peak) : -120.0f;
     }
     __syncthreads();
     if (tid == 0) {

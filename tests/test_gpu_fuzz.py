@@ -66,7 +66,7 @@ def make_plan(seed):
     return plan
 
 
-def render_plan(plan, g, split=0, events_at_call_start=False):
+def render_plan(plan, g, split=0, events_at_call_start=False, mutations=True):
     """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its blocks, events and chain mutations included. split: pull
     every block in pieces of that many frames (the oracle walks a long write in chunks of its 4096-frame mix buffer, a HIP graph in chunks of
     its max_frames: per-call logic — tails, ramps — sees different calls unless the caller pulls both in the same pieces)."""
@@ -93,7 +93,7 @@ def render_plan(plan, g, split=0, events_at_call_start=False):
                 d = descs[k][0]
                 if d["type"] == 0:
                     g.schedule_param(fid, fourcc_str(d["fourcc"]), 0.35, pos if events_at_call_start else pos + n // 2, normalized=True)
-        if b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
+        if mutations and b in (ev_block + 1, ev_block + 2) and fx_ids and seed % 3 != 0:
             fid, k = fx_ids[int(rng2.integers(0, len(fx_ids)))]
             if fid in fx_mixer:
                 if rng2.random() < 0.6:
@@ -110,7 +110,13 @@ def render_plan(plan, g, split=0, events_at_call_start=False):
     return np.concatenate(chunks)
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS or 48)))
+# 888: a Gate whose envelope crosses the threshold where the device's own log10f and the host's differ in the last bit used to open a frame late;
+# 734 (super-block test below): a Compressor whose envelope landed exactly on the upper knee edge — where the reference's gain computer has no
+# branch — on the device only. The level detectors now use the host libm's log10f restated (pg_log10f).
+FLAT_REGRESSION_SEEDS = [] if FUZZ_SEEDS else [888]
+
+
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS or 48))) + FLAT_REGRESSION_SEEDS)
 def test_random_graph_matches_oracle(seed):
     from phonic_amd.graph import Graph
 
@@ -130,7 +136,7 @@ def test_random_graph_matches_oracle(seed):
     assert float(np.abs(d).max()) <= 1e-4 * scale, what
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16)))
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16))) + ([] if FUZZ_SEEDS else [734]))
 def test_random_graph_superblock_writes(seed):
     """The same random graphs pulled in calls of one to four whole blocks with super-block launches enabled (pg_graph_set_max_blocks_per_launch):
     units enter and leave the steady state (events, chain mutations, voices that end, tails, gates), and the host must fall back to single
@@ -155,6 +161,27 @@ def test_random_graph_superblock_writes(seed):
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) sizes {plan['sizes']}"
+    assert float(np.abs(d).max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 12)))
+def test_random_graph_on_three_shards(seed):
+    """The same random graphs behind ONE pg_sharded_* handle with three shards (on one device here): sub-mixers and main-mixer sources are placed
+    on the least loaded shard, events travel to the shard that owns their target, the partial buses meet on the root in shard order in front of
+    the bus chain. Against the oracle (the sum over shards reassociates the f32 master-bus sum: tolerance, not bit-equality)."""
+    from phonic_amd.graph import ShardedGraph
+
+    plan = make_plan(seed)
+    g = ShardedGraph([0, 0, 0], SR, 2, 1024)
+    a = render_plan(plan, g, mutations=False)
+    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024), mutations=False)
+    assert np.isfinite(a).all() and g.device_errors() == 0
+    if float(np.abs(b).max()) <= 1e-4:
+        assert float(np.abs(a).max()) <= 1e-4
+        pytest.skip("silent case")
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
     assert float(np.abs(d).max()) <= 1e-4 * scale
 
 

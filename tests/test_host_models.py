@@ -29,6 +29,20 @@ def test_f32_phase_advance_equals_serial_loop(tmp_path):
     assert "bad 0" in r.stdout
 
 
+def test_device_log10f_restatement_equals_the_host_libm(tmp_path):
+    """pg_log10f (the level detectors of the Compressor and the Gate): glibc's log10f restated operation by operation, so that threshold and knee
+    decisions fall on the same frame on the device as in the reference on this platform — 4.2e7 arguments, bit for bit."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "log10f_check"
+    subprocess.run([hipcc, "-O2", "-ffp-contract=off", "-fno-builtin", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "phonic_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(HOST, "log10f_check.hip"), "-o", str(exe)], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout
+
+
 def test_resampler_schedule_integer_model_equals_serial_recurrence():
     sys.path.insert(0, HOST)
     import resampler_schedule_model as m
