@@ -277,3 +277,88 @@ def test_random_nested_graph_matches_oracle(seed):
             "rms_per_block": [float(np.sqrt(np.mean(x * x))) for x in np.array_split(d, len(plan["sizes"]))], "peak": float(np.abs(b).max())}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) {what}"
     assert float(np.abs(d).max()) <= 1e-4 * scale, what
+
+
+def make_voice_plan(seed):
+    """Random file sources on the main mixer and on one plain sub-mixer: rates on both sides of the mixer's (resampler ratios from 0.17 to 2),
+    mono / stereo, one-shots, finite and endless repeats, loop ranges, start times inside blocks, fade-out lengths, and a schedule of stop /
+    volume / panning / speed (immediate and glide) / seek calls at sample times."""
+    rng = np.random.default_rng(21000 + seed)
+    voices = []
+    for _ in range(int(rng.integers(1, 6))):
+        rate = int(rng.choice([8000, 11025, 22050, 32000, 44100, 48000, 64000, 96000]))
+        nch = int(rng.choice([1, 2]))
+        seconds = float(rng.uniform(0.02, 0.25))
+        frames = int(rate * seconds)
+        opt = dict(volume=float(rng.uniform(0.1, 0.9)), panning=float(rng.uniform(-1, 1)), start_time=int(rng.choice([0, 0, int(rng.integers(1, 3000))])),
+                   fade_out_seconds=float(rng.choice([0.05, 0.0, 0.01, 0.2])))
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            opt.update(has_repeat=1, repeat=int(rng.integers(1, 4)))
+        elif mode == 2:
+            opt.update(has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        elif mode == 3 and frames > 64:
+            a = int(rng.integers(0, frames // 2))
+            opt.update(has_repeat=1, repeat=(2 if rng.random() < 0.5 else _capi.PG_REPEAT_FOREVER), has_loop_range=1, loop_start=a, loop_end=int(rng.integers(a + 16, frames + 1)))
+        if rng.random() < 0.3:
+            opt["speed"] = float(rng.choice([0.5, 0.75, 1.25, 1.5, 2.0]))
+        voices.append(dict(mixer=int(rng.integers(0, 2)), tone=(int(rng.integers(0, 60)), rate, seconds, nch), opt=opt))
+    sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000, 1])) for _ in range(12)]
+    total = sum(sizes)
+    actions = []
+    for _ in range(int(rng.integers(0, 9))):
+        kind = str(rng.choice(["stop", "volume", "panning", "speed", "glide", "seek"]))
+        actions.append((int(rng.integers(0, len(sizes))), kind, int(rng.integers(0, len(voices))), float(rng.random()), int(rng.integers(0, total))))
+    return {"voices": voices, "sizes": sizes, "actions": actions}
+
+
+def render_voice_plan(plan, g):
+    m1 = g.add_mixer()
+    ids = []
+    for v in plan["voices"]:
+        i, rate, seconds, nch = v["tone"]
+        ids.append(g.add_voice(m1 if v["mixer"] else 0, workloads.tone_buffer(i, rate, seconds, channels=nch), nch, rate, **v["opt"]))
+    chunks, pos = [], 0
+    for b, n in enumerate(plan["sizes"]):
+        for (ab, kind, vi, x, t) in plan["actions"]:
+            if ab != b:
+                continue
+            t = max(t, pos)   # handles schedule from "now" on
+            if kind == "stop":
+                g.stop_voice(ids[vi], t)
+            elif kind == "volume":
+                g.set_voice_volume(ids[vi], x, t)
+            elif kind == "panning":
+                g.set_voice_panning(ids[vi], 2.0 * x - 1.0, t)
+            elif kind == "speed":
+                g.set_voice_speed(ids[vi], 0.5 + 1.5 * x, t)
+            elif kind == "glide":
+                g.set_voice_speed(ids[vi], 0.5 + 1.5 * x, t, glide=6.0 + 60.0 * x)
+            else:
+                # Seek positions on a frame boundary: PreloadedFileSource::seek turns seconds into a SAMPLE index (seconds * rate * channels,
+                # truncated, preloaded.rs:137-145); an odd index in a stereo file leaves half a frame in front of the loop end that no
+                # resampler call can consume — write_buffer then spins forever in the reference (and in the oracle; the device breaks out).
+                rate = plan["voices"][vi]["tone"][1]
+                g.seek_voice(ids[vi], (int(0.2 * x * rate) + 0.25) / rate, t)
+        o = np.zeros(2 * n, np.float32)
+        assert g.write(o, pos) in (0, 2 * n)
+        chunks.append(o)
+        pos += n
+    return np.concatenate(chunks)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24)))
+def test_random_voice_features_match_oracle(seed):
+    """PreloadedFileSource / FileSourceImpl / VolumeFader / ChannelMapped / Amplified / Panned through MixedSource's source loop, no effects:
+    the arithmetic is f32 and identical on both sides (resampler schedule, Hermite taps, fades, smoothed gain and panning), only the order of
+    the f32 sum over sources differs — 1e-6 RMS."""
+    from phonic_amd.graph import Graph
+
+    plan = make_voice_plan(seed)
+    a = render_voice_plan(plan, Graph(SR, 2, 1024, 0))
+    b = render_voice_plan(plan, oracle.OracleGraph(SR, 2, 1024))
+    assert np.isfinite(a).all()
+    d = a.astype(np.float64) - b.astype(np.float64)
+    what = {"voices": [(v["mixer"], v["tone"][1:], v["opt"]) for v in plan["voices"]], "actions": plan["actions"], "sizes": plan["sizes"],
+            "rms_per_block": [float(np.sqrt(np.mean(x * x))) if x.size else 0.0 for x in np.split(d, np.cumsum([2 * n for n in plan["sizes"]])[:-1])]}
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-6 and float(np.abs(d).max()) <= 1e-5, what
