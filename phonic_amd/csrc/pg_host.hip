@@ -1550,6 +1550,15 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
     }
     // bus commands run in the bus launch; everything is sorted by (unit, frame), stable
     std::stable_sort(cmds.begin(), cmds.end(), [](const PgCmd& a, const PgCmd& b) { return a.unit != b.unit ? a.unit < b.unit : a.frame < b.frame; });
+    // SetSourceVolume / SetSourcePanning events reach the source through a ONE-slot queue that the mixer force_pushes into (mixed.rs:810-845,
+    // amplified.rs:33-35): of several such events that come due in front of the same chunk only the last one is still there when the source runs —
+    // and that matters, an exponential smoother snaps to a target that is close enough (smoothing.rs:221-226), so applying the earlier ones too
+    // can leave another `current` behind. (Speed and seek messages travel through the file's 128-slot queue and all arrive.)
+    for (size_t i = 0; i < cmds.size(); ++i) {
+      if (cmds[i].type != CMD_VOICE_VOLUME && cmds[i].type != CMD_VOICE_PAN) continue;
+      for (size_t j = i + 1; j < cmds.size() && cmds[j].unit == cmds[i].unit && cmds[j].frame == cmds[i].frame; ++j)
+        if (cmds[j].type == cmds[i].type && cmds[j].target == cmds[i].target) { cmds[i].type = CMD_NOP; break; }
+    }
     // Super-block: when the call still spans several whole blocks of max_frames, nothing is scheduled inside them and the graph is in
     // steady state, ONE launch sequence renders them all (the reference's MixedSource::write walks its <= 4096-frame chunks in one call
     // the same way, mixed.rs:679-712); every per-block decision is still taken per block, on the device.

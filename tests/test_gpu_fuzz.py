@@ -347,7 +347,9 @@ def render_voice_plan(plan, g):
     return np.concatenate(chunks)
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24)))
+# 9028: two panning events for one source come due in front of the same chunk — the reference's one-slot message queue keeps the last one only,
+# and the first one would have snapped the nearly settled smoother onto its target
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24))) + ([] if FUZZ_SEEDS else [9028]))
 def test_random_voice_features_match_oracle(seed):
     """PreloadedFileSource / FileSourceImpl / VolumeFader / ChannelMapped / Amplified / Panned through MixedSource's source loop, no effects:
     the arithmetic is f32 and identical on both sides (resampler schedule, Hermite taps, fades, smoothed gain and panning), only the order of

@@ -51,7 +51,26 @@ def run_nested(plan, exact=False, mutations=True, events=True):
 
 
 seed = int(sys.argv[1])
-if len(sys.argv) > 2 and sys.argv[2] == "super":   # a seed of test_random_graph_superblock_writes
+if len(sys.argv) > 2 and sys.argv[2] == "voices":   # a seed of test_random_voice_features_match_oracle
+    plan = F.make_voice_plan(seed)
+    print("seed", seed, "sizes", plan["sizes"])
+    for v in plan["voices"]:
+        print(" voice on mixer", v["mixer"], v["tone"], v["opt"])
+    pos = np.cumsum([0] + plan["sizes"])
+    for a_ in sorted(plan["actions"]):
+        print(" action in front of block", a_[0], "(frame", int(pos[a_[0]]), ")", a_[1:])
+    a = F.render_voice_plan(plan, Graph(F.SR, 2, 1024, 0))
+    b = F.render_voice_plan(plan, oracle.OracleGraph(F.SR, 2, 1024))
+    print("rms per block", fmt(diff(a, b, plan["sizes"])[2]))
+    bad = np.flatnonzero(a != b)
+    print("samples differing:", bad.size, "first frame", bad[0] // 2 if bad.size else None, "last frame", bad[-1] // 2 if bad.size else None)
+    big = np.flatnonzero(np.abs(a.astype(np.float64) - b) > 1e-6)
+    print("samples with |d| > 1e-6:", big.size, "first frame", big[0] // 2 if big.size else None, "last", big[-1] // 2 if big.size else None)
+    if big.size:
+        f = big[0] // 2
+        for k in range(max(f - 2, 0), f + 6):
+            print("  ", k, "gpu", a[2 * k], a[2 * k + 1], "oracle", b[2 * k], b[2 * k + 1])
+elif len(sys.argv) > 2 and sys.argv[2] == "super":   # a seed of test_random_graph_superblock_writes
     plan = F.make_plan(seed)
     rng = np.random.default_rng(11000 + seed)
     plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
