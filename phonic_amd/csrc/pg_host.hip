@@ -1912,6 +1912,7 @@ struct pg_effect {
   int32_t* d_idx_log = nullptr;  // test hook (pg_effect_debug_index_log)
   size_t idx_log_words = 0;
   std::vector<PgCmd> pending;
+  size_t cmd_cap = 64;           // commands d_cmds holds
 };
 
 pg_effect* pg_effect_create(int kind, const pg_effect_init* init, int device) {
@@ -1949,6 +1950,7 @@ int pg_effect_initialize(pg_effect* e, uint32_t sample_rate, size_t channel_coun
   HIP_TRY(pg_malloc((void**)&e->d_fx, sizeof fx));
   HIP_TRY(pg_malloc((void**)&e->d_fx_index, 4));
   HIP_TRY(pg_malloc((void**)&e->d_cmds, sizeof(PgCmd) * 64));
+  e->cmd_cap = 64;
   HIP_TRY(pg_malloc((void**)&e->d_buf, max_frames * 2 * sizeof(float)));
   HIP_TRY(pg_memcpy(e->d_unit, &u, sizeof u, hipMemcpyHostToDevice));
   HIP_TRY(pg_memcpy(e->d_fx, &fx, sizeof fx, hipMemcpyHostToDevice));
@@ -1980,6 +1982,19 @@ int pg_effect_debug_index_log(pg_effect* e, int32_t* out, size_t words) {
 int pg_effect_process_started(pg_effect*) { return PG_OK; }  // no-ops for all stock effects (src/effect.rs:127-139)
 int pg_effect_process_stopped(pg_effect*) { return PG_OK; }
 
+// room for one more queued command (a launch applies commands at the head of the frames it renders, so a launch of no frames cannot flush them:
+// the queue grows instead)
+static int effect_reserve_cmd(pg_effect* e) {
+  if (e->pending.size() < e->cmd_cap) return PG_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  PgCmd* bigger = nullptr;
+  HIP_TRY(pg_malloc((void**)&bigger, sizeof(PgCmd) * e->cmd_cap * 2));
+  HIP_TRY(pg_stream_sync(e->stream));
+  (void)pg_free(e->d_cmds);
+  e->d_cmds = bigger;
+  e->cmd_cap *= 2;
+  return PG_OK;
+}
 static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t pos) {
   HIP_TRY(hipSetDevice(e->device));
   if (n_samples) HIP_TRY(hipMemcpyAsync(e->d_buf, host_buf, n_samples * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -2000,7 +2015,7 @@ static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t 
 int pg_effect_process(pg_effect* e, float* interleaved, size_t n_samples, uint64_t pos_in_frames) {
   if (!e->initialized) return set_error(PG_ERR_STATE, "effect is not initialized");
   if (n_samples % 2 != 0 || n_samples / 2 > e->max_frames) return set_error(PG_ERR_PARAMETER, "buffer must hold <= max_frames stereo frames");
-  if (n_samples == 0 && e->pending.empty()) return PG_OK;
+  if (n_samples == 0) return PG_OK;  // nothing to render: parameter updates and messages received so far stay queued, in order, for the next call that does
   return effect_run(e, interleaved, n_samples, pos_in_frames);
 }
 int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_normalized) {
@@ -2015,7 +2030,8 @@ int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_n
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = CMD_FX_PARAM; c.unit = 0; c.target = 0; c.param = pi; c.value = raw; c.frame = 0; c.value64 = fx_param_aux(e->kind, pi, raw, e->sample_rate);
-  if (e->pending.size() >= 64) { int rc = effect_run(e, nullptr, 0, 0); if (rc) return rc; }
+  int rc = effect_reserve_cmd(e);
+  if (rc) return rc;
   e->pending.push_back(c);
   return PG_OK;
 }
@@ -2026,7 +2042,8 @@ int pg_effect_message_reset(pg_effect* e) {
   PgCmd c;
   memset(&c, 0, sizeof c);
   c.type = CMD_FX_RESET; c.unit = 0; c.target = 0;
-  if (e->pending.size() >= 64) { int rc = effect_run(e, nullptr, 0, 0); if (rc) return rc; }
+  int rc = effect_reserve_cmd(e);
+  if (rc) return rc;
   e->pending.push_back(c);
   return PG_OK;
 }

@@ -300,3 +300,29 @@ def test_delay_line_read_index_streams(name, kind, params, seeds, per_frame):
     print(f"{name}: {flips} index flips in {total} reads (rate {rate:.2e}, largest distance {worst})")
     assert rate <= INDEX_FLIP_RATE_MAX, f"{flips} flips in {total} reads"
     check(a, b)
+
+
+def test_parameter_updates_survive_empty_process_calls_and_long_queues():
+    """pg_effect_set_parameter queues commands that the next launch applies at the head of the frames it renders. A process call of zero frames
+    renders nothing — the queue must stay (it used to be cleared: the updates were lost), and more updates than the queue's first allocation
+    holds must all arrive, in order (the queue grows; a flush launch of zero frames cannot apply them)."""
+    for kind, pid, lo, hi in ((_capi.FX_FILTER, "cuto", 200.0, 9000.0), (_capi.FX_GAIN, "gain", 0.1, 2.0), (_capi.FX_COMPRESSOR, "thrs", -50.0, -5.0)):
+        e_gpu, e_cpu = gpu_effect(kind), oracle.OracleEffect(kind, None, None)
+        for e in (e_gpu, e_cpu):
+            e.initialize(SR, 2, 1024)
+        x = workloads.test_signal(4 * 512, seed=3)
+        a, b = x.copy(), x.copy()
+        empty = np.zeros(0, np.float32)
+        for blk in range(4):
+            for e in (e_gpu, e_cpu):
+                if blk == 1:
+                    e.set_parameter(pid, lo, False)
+                    e.process(empty)                      # zero frames: the update above must still apply to block 1
+                if blk == 2:
+                    for k in range(150):                   # far more than the 64 commands the queue starts with; the last one wins
+                        e.set_parameter(pid, lo + (hi - lo) * ((k * 37) % 150) / 149.0, False)
+            sl = slice(blk * 1024, (blk + 1) * 1024)
+            e_gpu.process(a[sl])
+            e_cpu.process(b[sl])
+        check(a, b)
+        assert not np.array_equal(a[1024:2048], x[1024:2048])

@@ -364,3 +364,56 @@ def test_random_voice_features_match_oracle(seed):
     what = {"voices": [(v["mixer"], v["tone"][1:], v["opt"]) for v in plan["voices"]], "actions": plan["actions"], "sizes": plan["sizes"],
             "rms_per_block": [float(np.sqrt(np.mean(x * x))) if x.size else 0.0 for x in np.split(d, np.cumsum([2 * n for n in plan["sizes"]])[:-1])]}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-6 and float(np.abs(d).max()) <= 1e-5, what
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS or 40)))
+def test_random_standalone_effect_sequences(seed):
+    """The `trait Effect` surface (pg_effect_*): one effect of a random kind with random construction parameters, then a random sequence of
+    process calls of ragged sizes with parameter updates (raw and normalized, any parameter, several between two calls) and reset messages in
+    between, on a signal that alternates noise, bursts and silence."""
+    import phonic_amd
+    from phonic_amd.graph import effect_parameters
+
+    rng = np.random.default_rng(31000 + seed)
+    kind = int(rng.integers(0, 10))
+    descs = effect_parameters(kind)
+    params = random_params(rng, kind, descs) if rng.random() < 0.7 else None
+    seeds = workloads.reverb_seeds(int(rng.integers(0, 1000))) if kind == _capi.FX_REVERB else None
+    e_gpu, e_cpu = phonic_amd.Effect(kind, params, seeds), oracle.OracleEffect(kind, params, seeds)
+    for e in (e_gpu, e_cpu):
+        e.initialize(SR, 2, 1024)
+    sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000, 1, 0])) for _ in range(14)]
+    x = workloads.test_signal(sum(sizes) + 1, seed=seed, kind=str(rng.choice(["noise", "burst"])))[: 2 * sum(sizes)].copy()
+    quiet = int(rng.integers(0, len(sizes)))
+    a, b = x.copy(), x.copy()
+    pos = 0
+    log = []
+    for i, n in enumerate(sizes):
+        if i == quiet:
+            a[2 * pos:] *= 0.0
+            b[2 * pos:] *= 0.0
+        for _ in range(int(rng.choice([0, 0, 1, 1, 2, 4]))):
+            d = descs[int(rng.integers(0, len(descs)))]
+            name = fourcc_str(d["fourcc"])
+            if kind == _capi.FX_DELAY and name == "lfos":
+                continue
+            norm = bool(rng.random() < 0.5)
+            if d["type"] == 0:
+                v = float(rng.random()) if norm else float(np.float32(d["min"] + (d["max"] - d["min"]) * rng.random()))
+            else:
+                v = float(rng.random()) if norm else float(int(rng.integers(int(d["min"]), int(d["max"]) + 1)))
+            log.append((i, name, v, norm))
+            e_gpu.set_parameter(name, v, norm)
+            e_cpu.set_parameter(name, v, norm)
+        if kind in (_capi.FX_DELAY, _capi.FX_REVERB, _capi.FX_CHORUS) and rng.random() < 0.1:
+            log.append((i, "reset"))
+            e_gpu.reset()
+            e_cpu.reset()
+        e_gpu.process(a[2 * pos:2 * (pos + n)])
+        e_cpu.process(b[2 * pos:2 * (pos + n)])
+        pos += n
+    assert np.isfinite(a).all()
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    what = {"kind": _capi.FX_NAMES[kind], "params": params, "sizes": sizes, "quiet from call": quiet, "log": log}
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), float(np.abs(d).max()), what)
