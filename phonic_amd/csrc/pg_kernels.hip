@@ -303,6 +303,7 @@ __device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* 
   return audible;
 }
 
+#define PG_MIN_ROW_FRAMES 64
 template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, const int chunk = 0) {
   if (slot >= L.n_units) return;
@@ -310,9 +311,13 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   PgUnit& unit = L.units[u];
   const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
+  // The two signal rows hold at least PG_MIN_ROW_FRAMES frames: the ramp paths lay their per-frame parameter sequences out in `tmp`, eight to ten
+  // sequences of at least eight frames (delay_ramp_fast, chorus_ramp_fast) — with rows sized by a launch of a handful of frames they would
+  // decline, and the fast kernels have no serial code to fall back to (found by the fuzz over block sizes: 1-frame blocks behind a ramp).
+  const int NA = N < PG_MIN_ROW_FRAMES ? PG_MIN_ROW_FRAMES : N;
   float* sig = (float*)pg_smem;
-  float* tmp = sig + 2 * N;
-  char* scratch = (char*)(tmp + 2 * N);
+  float* tmp = sig + 2 * NA;
+  char* scratch = (char*)(tmp + 2 * NA);
   // fixed small areas at the start of scratch
   PgVoice* lv = (PgVoice*)scratch;                 scratch += (sizeof(PgVoice) + 15) & ~15ull;
   PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
@@ -323,7 +328,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   S.diag = L.diag;
   S.sched_rd = nullptr;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * N; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
+  fc.tmp = tmp; fc.tmp_floats = 2 * NA; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word;
   fc.idx_log = FAST_ONLY ? nullptr : L.index_log;  // (a constant in the fast kernels: the logging stores are compiled out)
   if (L.mode != 2) PG_STAMP(L.diag, 0);
 
@@ -998,6 +1003,7 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
   return need;
 }
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0) {
+  if (n_frames < PG_MIN_ROW_FRAMES) n_frames = PG_MIN_ROW_FRAMES;
   size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
   size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;

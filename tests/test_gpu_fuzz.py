@@ -122,9 +122,10 @@ def test_random_graph_matches_oracle(seed):
 
     plan = make_plan(seed)
     sizes = plan["sizes"]
-    outs = [render_plan(plan, Graph(SR, 2, 1024, 0)), render_plan(plan, oracle.OracleGraph(SR, 2, 1024))]
+    g = Graph(SR, 2, 1024, 0)
+    outs = [render_plan(plan, g), render_plan(plan, oracle.OracleGraph(SR, 2, 1024))]
     a, b = outs
-    assert np.isfinite(a).all()
+    assert np.isfinite(a).all() and g.device_errors() == 0   # (no kernel met an effect state its time-parallel paths decline)
     if float(np.abs(b).max()) <= 1e-4:   # e.g. a gate that never opens: both sides silent
         assert float(np.abs(a).max()) <= 1e-4
         pytest.skip("silent case")
@@ -265,9 +266,10 @@ def test_random_nested_graph_matches_oracle(seed):
     from phonic_amd.graph import Graph
 
     plan = make_nested_plan(seed)
-    a = render_nested_plan(plan, Graph(SR, 2, 1024, 0))
+    g = Graph(SR, 2, 1024, 0)
+    a = render_nested_plan(plan, g)
     b = render_nested_plan(plan, oracle.OracleGraph(SR, 2, 1024))
-    assert np.isfinite(a).all()
+    assert np.isfinite(a).all() and g.device_errors() == 0
     if float(np.abs(b).max()) <= 1e-4:
         assert float(np.abs(a).max()) <= 1e-4
         pytest.skip("silent case")
@@ -417,3 +419,28 @@ def test_random_standalone_effect_sequences(seed):
     scale = max(1.0, float(np.abs(b).max()))
     what = {"kind": _capi.FX_NAMES[kind], "params": params, "sizes": sizes, "quiet from call": quiet, "log": log}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), float(np.abs(d).max()), what)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16)))
+def test_random_graph_other_rates_and_block_sizes(seed):
+    """The flat random graphs at other mixer rates (22.05 / 44.1 / 96 kHz: delay-line lengths, filter coefficients, smoother and tail constants,
+    resampler ratios on the other side of one all move) and other max_frames (256 ... 4096: chunking of the time-parallel paths, the staged
+    kernels' 1024-frame limit, LDS plans)."""
+    from phonic_amd.graph import Graph
+
+    rng = np.random.default_rng(41000 + seed)
+    sr = int(rng.choice([22050, 44100, 96000]))
+    mf = int(rng.choice([256, 512, 2048, 4096]))
+    plan = make_plan(seed)
+    plan["sizes"] = [int(rng.choice([mf, mf, mf // 2, max(1, mf // 3), 64, 1])) for _ in range(9)]
+    g = Graph(sr, 2, mf, 0)
+    a = render_plan(plan, g)
+    b = render_plan(plan, oracle.OracleGraph(sr, 2, mf))
+    assert np.isfinite(a).all() and g.device_errors() == 0
+    if float(np.abs(b).max()) <= 1e-4:
+        assert float(np.abs(a).max()) <= 1e-4
+        pytest.skip("silent case")
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    what = {"sr": sr, "max_frames": mf, "sizes": plan["sizes"], "chains": [[_capi.FX_NAMES[k] for (k, _, _) in chain] for chain, _ in plan["mixers"]], "bus": [_capi.FX_NAMES[k] for (k, _, _) in plan["bus"]]}
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), what)

@@ -51,7 +51,46 @@ def run_nested(plan, exact=False, mutations=True, events=True):
 
 
 seed = int(sys.argv[1])
-if len(sys.argv) > 2 and sys.argv[2] == "voices":   # a seed of test_random_voice_features_match_oracle
+if len(sys.argv) > 2 and sys.argv[2] == "rates":   # a seed of test_random_graph_other_rates_and_block_sizes
+    rng = np.random.default_rng(41000 + seed)
+    sr = int(rng.choice([22050, 44100, 96000]))
+    mf = int(rng.choice([256, 512, 2048, 4096]))
+    plan = F.make_plan(seed)
+    plan["sizes"] = [int(rng.choice([mf, mf, mf // 2, max(1, mf // 3), 64, 1])) for _ in range(9)]
+    print("seed", seed, "sample rate", sr, "max_frames", mf, "sizes", plan["sizes"], "event block", plan["ev_block"])
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        print(" mixer", i, [(n, p) for n, (_, p, _) in zip(names(chain), chain)], "voices", [(v[1], round(v[2], 2)) for v in voices])
+    print(" bus", [(n, p) for n, (_, p, _) in zip(names(plan["bus"]), plan["bus"])])
+
+    def run_r(p, exact=False, mutations=True):
+        g = Graph(sr, 2, mf, 0)
+        if exact:
+            g.set_fast_math(0)
+        a = F.render_plan(p, g, mutations=mutations)
+        b = F.render_plan(p, oracle.OracleGraph(sr, 2, mf), mutations=mutations)
+        return diff(a, b, p["sizes"])
+    for label, kw in (("time-parallel kernels", {}), ("exact serial kernels", {"exact": True}), ("no mutations", {"mutations": False})):
+        rms, peak, per = run_r(plan, **kw)
+        print(f"whole graph, {label}: rms {rms:.3e} peak {peak:.3f} per block {fmt(per)}")
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        for cut in range(len(chain) + 1):
+            p = copy.copy(plan)
+            p["mixers"] = [(chain[:cut], voices)]
+            p["bus"] = []
+            p["ev_block"] = 99
+            rms, peak, per = run_r(p)
+            rms_x, _, _ = run_r(p, True)
+            print(f"mixer {i} alone, chain {names(chain[:cut])}: rms {rms:.3e} (exact kernels {rms_x:.3e}) peak {peak:.3f} per block {fmt(per)}")
+    if plan["bus"]:
+        for cut in range(1, len(plan["bus"]) + 1):
+            p = copy.copy(plan)
+            p["bus"] = plan["bus"][:cut]
+            p["mixers"] = [([], v) for _, v in plan["mixers"]]
+            p["ev_block"] = 99
+            rms, peak, per = run_r(p)
+            rms_x, _, _ = run_r(p, True)
+            print(f"sources + bus {names(p['bus'])}: rms {rms:.3e} (exact kernels {rms_x:.3e}) per block {fmt(per)}")
+elif len(sys.argv) > 2 and sys.argv[2] == "voices":   # a seed of test_random_voice_features_match_oracle
     plan = F.make_voice_plan(seed)
     print("seed", seed, "sizes", plan["sizes"])
     for v in plan["voices"]:
