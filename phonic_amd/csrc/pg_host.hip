@@ -466,6 +466,8 @@ struct HostMixer {
   std::vector<int> children;       // nested sub-mixers, in the order they were added
   bool removed = false;            // Player::remove_mixer: gone from its parent (with everything under it)
   bool remove_pending = false;     // MixerMessage::RemoveAllPendingEvents waiting for the next write (it needs that write's position)
+  uint64_t remove_event_seq = 0;   // ... it covers the events queued before it (Event::seq below this) and the sources added before it
+  size_t remove_voice_limit = 0;   //     (voice ids below this): messages are processed in order (mixed.rs:294-313), what arrives later stays
 };
 // Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
 // deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
@@ -888,7 +890,7 @@ static void stop_all_voices_now(pg_graph* g) {
     c.type = CMD_VOICE_STOP; c.target = g->voices[v].dev_index; c.value64 = 0; c.param = (int)v;
     g->mixers[g->voices[v].mixer].messages.push_back(c);
   }
-  for (HostMixer& mx : g->mixers) if (!mx.removed) mx.remove_pending = true;
+  for (HostMixer& mx : g->mixers) if (!mx.removed) { mx.remove_pending = true; mx.remove_event_seq = g->event_seq; mx.remove_voice_limit = g->voices.size(); }
 }
 static int ctrl_push(pg_graph* g, const pgc::CtrlMsg& m) {
   if (!g->ctrl.push(m)) return set_error(PG_ERR_QUEUE_FULL, "mixer's message queue is full");  // Error::SendError
@@ -906,7 +908,7 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
     mx.remove_pending = false;
     for (size_t i = 0; i < mx.voices.size();) {
       const int v = mx.voices[i];
-      if (g->voices[v].start_time > pos) {
+      if ((size_t)v < mx.remove_voice_limit && g->voices[v].start_time > pos) {
         mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [v](const PgCmd& c) { return c.param == v; }), mx.messages.end());
         g->voices[v].mixer = -1;
         g->voice_alive_tab.set((size_t)v, 0);
@@ -915,8 +917,9 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
         g->topo_dirty = true;
       } else ++i;
     }
-    mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), [pos](const Event& e) { return e.sample_time > pos; }), mx.events.end());
-    mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), [pos](const Event& e) { return e.sample_time > pos; }), mx.bus_events.end());
+    const uint64_t lim = mx.remove_event_seq;
+    mx.events.erase(std::remove_if(mx.events.begin(), mx.events.end(), [pos, lim](const Event& e) { return e.seq < lim && e.sample_time > pos; }), mx.events.end());
+    mx.bus_events.erase(std::remove_if(mx.bus_events.begin(), mx.bus_events.end(), [pos, lim](const Event& e) { return e.seq < lim && e.sample_time > pos; }), mx.bus_events.end());
   }
 }
 
@@ -992,6 +995,7 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   if (src_rate == 0) return -set_error(PG_ERR_PARAMETER, "file buffer sample rate must be > 0");
   if (src_channels != 1 && src_channels != 2) return -set_error(PG_ERR_PARAMETER, "only mono and stereo file buffers are supported");
   if (n_frames == 0 || !pcm) return -set_error(PG_ERR_PARAMETER, "file buffer must not be empty");
+  drain_control_messages(g);  // control calls made before this one come first (a stop_all_voices must not take this source with it)
   pg_voice_options def;
   if (!opt) { pg_voice_options_default(&def); opt = &def; }
   if (!(opt->speed > 0.0)) return -set_error(PG_ERR_PARAMETER, "speed must be > 0");

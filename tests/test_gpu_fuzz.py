@@ -444,3 +444,114 @@ def test_random_graph_other_rates_and_block_sizes(seed):
     scale = max(1.0, float(np.abs(b).max()))
     what = {"sr": sr, "max_frames": mf, "sizes": plan["sizes"], "chains": [[_capi.FX_NAMES[k] for (k, _, _) in chain] for chain, _ in plan["mixers"]], "bus": [_capi.FX_NAMES[k] for (k, _, _) in plan["bus"]]}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), what)
+
+
+def make_topology_plan(seed):
+    """A graph that keeps changing while it plays: between blocks, sub-mixers (also nested ones) are added and removed with everything on them,
+    effects are added, moved and removed, one-shot and looping voices start on any live mixer, single voices and all voices are stopped, and
+    parameter / volume events are scheduled — also for things that are gone by the time the event comes due."""
+    from phonic_amd.graph import effect_parameters
+
+    rng = np.random.default_rng(51000 + seed)
+    descs = {k: effect_parameters(k) for k in range(10)}
+    steps = []
+    for b in range(12):
+        acts = []
+        for _ in range(int(rng.choice([0, 1, 1, 2, 3]))):
+            what = str(rng.choice(["add_mixer", "add_nested", "remove_mixer", "add_effect", "remove_effect", "move_effect", "add_voice", "add_voice", "stop_voice", "stop_all",
+                                   "param", "volume"]))
+            k = int(rng.integers(0, 10))
+            acts.append(dict(what=what, pick=int(rng.integers(0, 1 << 30)), kind=k, params=random_params(rng, k, descs[k]), rseed=int(rng.integers(0, 1000)),
+                             tone=int(rng.integers(0, 60)), rate=int(rng.choice([44100, 48000, 32000, 22050])), vol=float(rng.uniform(0.2, 0.7)), pan=float(rng.uniform(-1, 1)),
+                             loop=bool(rng.random() < 0.5), frac=float(rng.random()), val=float(rng.uniform(0.1, 0.9)), off=int(rng.integers(-2, 3))))
+        steps.append((int(rng.choice([1024, 1024, 512, 700, 333])), acts))
+    return {"steps": steps, "descs": descs}
+
+
+def render_topology_plan(plan, g):
+    descs = plan["descs"]
+    mixers, parent_of, fx, voices = [0], {0: None}, [], []      # live mixers (0 = main), effects [(id, kind, mixer)], voices [(id, mixer)]
+
+    def dead_branch(m):
+        out, grew = {m}, True
+        while grew:
+            grew = False
+            for c, p in parent_of.items():
+                if p in out and c not in out:
+                    out.add(c)
+                    grew = True
+        return out
+
+    chunks, pos = [], 0
+    for n, acts in plan["steps"]:
+        for a in acts:
+            w, pick = a["what"], a["pick"]
+            t = pos + int(a["frac"] * n)
+            if w == "add_mixer" and len(mixers) < 7:
+                m = g.add_mixer()
+                mixers.append(m); parent_of[m] = 0
+            elif w == "add_nested" and len(mixers) > 1 and len(mixers) < 7:
+                p = mixers[1 + pick % (len(mixers) - 1)]
+                m = g.add_mixer(p)
+                mixers.append(m); parent_of[m] = p
+            elif w == "remove_mixer" and len(mixers) > 1:
+                m = mixers[1 + pick % (len(mixers) - 1)]
+                gone = dead_branch(m)
+                g.remove_mixer(m)
+                mixers[:] = [x for x in mixers if x not in gone]
+                fx[:] = [e for e in fx if e[2] not in gone]
+                voices[:] = [v for v in voices if v[1] not in gone]
+                for x in gone:
+                    parent_of.pop(x, None)
+            elif w == "add_effect":
+                m = mixers[pick % len(mixers)]
+                if sum(1 for e in fx if e[2] == m) < 3:
+                    fx.append((g.add_effect(m, a["kind"], params=a["params"], reverb_seeds=workloads.reverb_seeds(a["rseed"]) if a["kind"] == _capi.FX_REVERB else None), a["kind"], m))
+            elif w == "remove_effect" and fx:
+                e = fx.pop(pick % len(fx))
+                g.remove_effect(e[0])
+            elif w == "move_effect" and fx:
+                e = fx[pick % len(fx)]
+                g.move_effect(e[0], e[2], _capi.MOVE_DIRECTION, a["off"])
+            elif w == "add_voice" and len(voices) < 10:
+                m = mixers[pick % len(mixers)]
+                opt = dict(volume=a["vol"], panning=a["pan"], start_time=t)
+                if a["loop"]:
+                    opt.update(has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+                v = g.add_voice(m, workloads.tone_buffer(a["tone"], a["rate"], 0.1), 2, a["rate"], **opt)
+                if a["loop"]:   # only voices that cannot end by themselves are addressed later: a handle of a source that has ended refuses calls
+                    voices.append((v, m))   # (FilePlaybackHandle: Error::SourceNotPlaying), and when it notices is a matter of thread timing in the reference
+            elif w == "stop_voice" and voices:
+                g.stop_voice(voices.pop(pick % len(voices))[0], t)
+            elif w == "stop_all":
+                g.stop_all_voices()
+                voices.clear()
+            elif w == "param" and fx:
+                e = fx[pick % len(fx)]
+                d = descs[e[1]][(pick >> 8) % len(descs[e[1]])]
+                if d["type"] == 0 and not (e[1] == _capi.FX_DELAY and fourcc_str(d["fourcc"]) in ("lfdt", "lfdf", "ldfb")):
+                    g.schedule_param(e[0], fourcc_str(d["fourcc"]), a["val"], t + (n if pick & 1 else 0), normalized=True)   # some come due a block later
+            elif w == "volume" and voices:
+                g.set_voice_volume(voices[pick % len(voices)][0], a["val"], t)
+        o = np.zeros(2 * n, np.float32)
+        assert g.write(o, pos) in (0, 2 * n)
+        chunks.append(o)
+        pos += n
+    return np.concatenate(chunks)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 32)))
+def test_random_topology_changes_while_playing(seed):
+    from phonic_amd.graph import Graph
+
+    plan = make_topology_plan(seed)
+    g = Graph(SR, 2, 1024, 0)
+    a = render_topology_plan(plan, g)
+    b = render_topology_plan(plan, oracle.OracleGraph(SR, 2, 1024))
+    assert np.isfinite(a).all() and g.device_errors() == 0
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    edges = np.cumsum([0] + [2 * n for n, _ in plan["steps"]])
+    what = {"rms_per_block": [float(np.sqrt(np.mean(d[edges[i]:edges[i + 1]] ** 2))) for i in range(len(plan["steps"]))],
+            "steps": [(n, [(x["what"], x["pick"] % 97, _capi.FX_NAMES[x["kind"]]) for x in acts]) for n, acts in plan["steps"]]}
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), what)

@@ -51,7 +51,46 @@ def run_nested(plan, exact=False, mutations=True, events=True):
 
 
 seed = int(sys.argv[1])
-if len(sys.argv) > 2 and sys.argv[2] == "rates":   # a seed of test_random_graph_other_rates_and_block_sizes
+if len(sys.argv) > 2 and sys.argv[2] == "topology":   # a seed of test_random_topology_changes_while_playing: shrink it to a minimal failing sequence
+    plan = F.make_topology_plan(seed)
+
+    def rms_of(p, exact=False):
+        g = Graph(F.SR, 2, 1024, 0)
+        if exact:
+            g.set_fast_math(0)
+        try:
+            a = F.render_topology_plan(p, g)
+            b = F.render_topology_plan(p, oracle.OracleGraph(F.SR, 2, 1024))
+        except Exception as e:   # a shrunk sequence may address something that no longer exists
+            return -1.0, None
+        d = a.astype(np.float64) - b.astype(np.float64)
+        edges = np.cumsum([0] + [2 * n for n, _ in p["steps"]])
+        return float(np.sqrt(np.mean(d * d))), [float(np.sqrt(np.mean(d[edges[i]:edges[i + 1]] ** 2))) for i in range(len(p["steps"]))]
+
+    base, per = rms_of(plan)
+    print("seed", seed, "rms", base, "exact kernels", rms_of(plan, True)[0])
+    steps = [(n, list(acts)) for n, acts in plan["steps"]]
+    changed = True
+    while changed:
+        changed = False
+        for bi in range(len(steps)):
+            for ai in range(len(steps[bi][1]) - 1, -1, -1):
+                trial = [(n, [x for j, x in enumerate(acts) if not (i == bi and j == ai)]) for i, (n, acts) in enumerate(steps)]
+                r, _ = rms_of({"steps": trial, "descs": plan["descs"]})
+                if r > 1e-5:
+                    steps = trial
+                    changed = True
+    while len(steps) > 1 and rms_of({"steps": steps[:-1], "descs": plan["descs"]})[0] > 1e-5:
+        steps = steps[:-1]
+    r, per = rms_of({"steps": steps, "descs": plan["descs"]})
+    print("minimal failing sequence: rms", r, "exact kernels", rms_of({"steps": steps, "descs": plan["descs"]}, True)[0], "per block", fmt(per))
+    for bi, (n, acts) in enumerate(steps):
+        print(" block", bi, n, "frames")
+        for x in acts:
+            extra = {"add_effect": (_capi.FX_NAMES[x["kind"]], x["params"]), "add_voice": (x["rate"], "loop" if x["loop"] else "one-shot", round(x["frac"], 3)),
+                     "param": (round(x["val"], 3), round(x["frac"], 3), "next block" if x["pick"] & 1 else ""), "move_effect": x["off"]}.get(x["what"], "")
+            print("    ", x["what"], "pick", x["pick"], extra)
+elif len(sys.argv) > 2 and sys.argv[2] == "rates":   # a seed of test_random_graph_other_rates_and_block_sizes
     rng = np.random.default_rng(41000 + seed)
     sr = int(rng.choice([22050, 44100, 96000]))
     mf = int(rng.choice([256, 512, 2048, 4096]))
