@@ -555,3 +555,52 @@ def test_random_topology_changes_while_playing(seed):
     what = {"rms_per_block": [float(np.sqrt(np.mean(d[edges[i]:edges[i + 1]] ** 2))) for i in range(len(plan["steps"]))],
             "steps": [(n, [(x["what"], x["pick"] % 97, _capi.FX_NAMES[x["kind"]]) for x in acts]) for n, acts in plan["steps"]]}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), what)
+
+
+class _AsyncWriter:
+    """A Graph whose write() enqueues the render on a caller's stream into one device buffer and returns at once (pg_graph_write_device): the
+    host never waits between blocks, so every graph mutation and control call of a plan meets rounds that are still in flight."""
+
+    def __init__(self, g, total_frames):
+        import torch
+
+        self._g, self._torch = g, torch
+        self._stream = torch.cuda.Stream()
+        self._buf = torch.zeros(2 * total_frames, dtype=torch.float32, device="cuda")
+        self._views = []
+
+    def __getattr__(self, name):
+        return getattr(self._g, name)
+
+    def write(self, out, pos):
+        off = 2 * pos
+        w = self._g.write_device(self._buf.data_ptr() + 4 * off, out.size, pos, self._stream.cuda_stream)
+        self._views.append((out, off, w))
+        return w if w else out.size   # (0 = nothing to do: the slice stays zero, as a host write leaves its buffer)
+
+    def finish(self):
+        self._torch.cuda.synchronize()
+        host = self._buf.cpu().numpy()
+        for out, off, w in self._views:
+            if w:
+                out[:] = host[off:off + out.size]
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24)))
+def test_random_topology_changes_on_an_asynchronous_stream(seed):
+    """The same changing graphs rendered without a single host wait between blocks: pg_graph_write_device on a caller's stream returns while the
+    round is in flight, and the add / remove / move / stop calls that follow must order themselves against it (they drain the stream the last
+    write used before they touch tables a running round reads)."""
+    from phonic_amd.graph import Graph
+
+    plan = make_topology_plan(seed)
+    g = Graph(SR, 2, 1024, 0)
+    w = _AsyncWriter(g, sum(n for n, _ in plan["steps"]))
+    render_topology_plan(plan, w)
+    w.finish()
+    a = np.concatenate([out for out, _, _ in w._views])   # (the blocks' host arrays are filled when the stream has drained)
+    b = render_topology_plan(plan, oracle.OracleGraph(SR, 2, 1024))
+    assert np.isfinite(a).all() and g.device_errors() == 0
+    d = a.astype(np.float64) - b.astype(np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, float(np.sqrt(np.mean(d * d)))
