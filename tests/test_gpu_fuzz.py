@@ -604,3 +604,21 @@ def test_random_topology_changes_on_an_asynchronous_stream(seed):
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, float(np.sqrt(np.mean(d * d)))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 12)))
+def test_random_graph_on_the_exact_serial_kernels(seed):
+    """pg_graph_set_fast_math(0): every unit on the generic kernel's exact serial code (the path that otherwise only renders command blocks and the
+    few states without a time-parallel form) — flat and changing graphs alike, same bar."""
+    from phonic_amd.graph import Graph
+
+    for make, render in ((make_plan, render_plan), (make_topology_plan, render_topology_plan)):
+        plan = make(seed)
+        g = Graph(SR, 2, 1024, 0)
+        g.set_fast_math(0)
+        a = render(plan, g)
+        b = render(plan, oracle.OracleGraph(SR, 2, 1024))
+        assert np.isfinite(a).all() and g.device_errors() == 0
+        d = a.astype(np.float64) - b.astype(np.float64)
+        scale = max(1.0, float(np.abs(b).max()))
+        assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (make.__name__, float(np.sqrt(np.mean(d * d))))
