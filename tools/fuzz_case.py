@@ -1,8 +1,9 @@
-"""usage (GPU box): python tools/fuzz_case.py SEED [nested] — where does a fuzz graph's GPU-vs-oracle difference come from?
+"""usage (GPU box): python tools/fuzz_case.py SEED [nested|super|voices|rates|topology] — where does a fuzz case's GPU-vs-oracle difference come from?
 
-Flat graphs (tests/test_gpu_fuzz.py: make_plan / render_plan): the seed's plan whole, on the exact serial kernels, one sub-mixer at a time and with
-that sub-mixer's chain cut after each effect. Nested graphs (make_nested_plan / render_nested_plan): whole, on the exact serial kernels, without the
-chain mutations, without the events, and with one mixer's chain emptied at a time. Prints the RMS difference against the oracle per block."""
+One mode per family of tests/test_gpu_fuzz.py. Flat graphs (default): the seed's plan whole, on the exact serial kernels, one sub-mixer at a time and
+with that sub-mixer's chain cut after each effect. nested: whole, exact kernels, without chain mutations, without events, one mixer's chain emptied at
+a time. super: super-block pull vs block-by-block pull vs oracle, per block. voices: the file-source plan with its actions, first differing frame.
+rates: the flat bisection at the seed's mixer rate and max_frames. topology: shrinks a changing-graph seed to a minimal failing call sequence."""
 import copy
 import os
 import sys
