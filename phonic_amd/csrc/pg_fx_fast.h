@@ -158,8 +158,8 @@ DEVO bool eq5_steady(const PgEq5& e) {
 // hold nothing but Gain / Panning / Reverb).
 DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
   switch (fx.kind) {
-    case 0: return !sm_need_ramp(fx.u.gain.gain);
-    case 1: return !sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width);
+    case 0: return !staged_unit || !sm_need_ramp(fx.u.gain.gain);   // ramping: the sequence paths of fx_fast_process (kernel variants with the ramp paths)
+    case 1: return !staged_unit || (!sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width));
     case 2: return !staged_unit || !(sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q: time-varying scan (not in the staged kernels)
     case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
     case 4: return delay_fast_eligible(fx) || (!staged_unit && delay_ramp_eligible(fx));  // ramping: delay_ramp_fast (not in the staged kernels)
@@ -167,7 +167,7 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
     case 6: return chorus_fast_eligible(fx) || (!staged_unit && chorus_ramp_eligible(fx));
     case 7: return comp_fast_eligible(fx);
     case 8: return true;
-    case 9: return !sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f);
+    case 9: return !staged_unit || (!sm_need_ramp(fx.u.dist.mix) && !sm_need_ramp(fx.u.dist.drive) && (fx.u.dist.mix.target == 0.0f || fx.u.dist.mix.target >= 1.0f));
     default: return false;
   }
 }
@@ -181,7 +181,15 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
   switch (fx.kind) {
     case 0: {  // GainEffect without ramp: optional DC filter per channel (gain.rs:147-153), then scale_buffer (gain.rs:162-165)
       PgGain& g = fx.u.gain;
-      if (sm_need_ramp(g.gain)) return false;
+      // A moving gain (gain.rs:154-161: one smoother step per frame): one lane lays the value sequence of a piece out in the temporary row,
+      // all lanes scale. Only in the kernel variants that carry the ramp paths (bit 10).
+      const bool ramp = sm_need_ramp(g.gain);
+      if (ramp && !((KMASK >> 10) & 1)) return false;
+      float* gseq = fc.tmp;
+      const int gcap = fc.tmp_floats < 1024 ? fc.tmp_floats : 1024;
+      auto lay_out = [&](int T) {  // the gains of the next T frames -> gseq (caller syncs)
+        if (tid == 0) { PgSmooth sg = g.gain; for (int k = 0; k < T; ++k) gseq[k] = sm_next(sg); g.gain = sg; }
+      };
       float v = g.gain.target;
       if (g.dc_mode != 0) {
         // DcFilter::process_sample per channel as a blocked scan over the block (dc_scan, shared with the DelayEffect's wet path),
@@ -191,18 +199,32 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
           double* buf = (double*)fc.scratch;
           double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
           const int frames = n / 2;
-          for (int done = 0; done < frames; done += 1024) {
-            const int T = frames - done < 1024 ? frames - done : 1024;
+          const int piece = ramp ? gcap : 1024;
+          for (int done = 0; done < frames; done += piece) {
+            const int T = frames - done < piece ? frames - done : piece;
             __syncthreads();
+            if (ramp) lay_out(T);
             for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
             __syncthreads();
             dc_scan(g.dc, buf, T, xchg);
             __syncthreads();
-            for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)] * v;
+            for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)] * (ramp ? gseq[s >> 1] : v);
           }
           __syncthreads();
           return true;
         } else return false;
+      }
+      if (ramp) {
+        const int frames = n / 2;
+        for (int done = 0; done < frames; done += gcap) {
+          const int T = frames - done < gcap ? frames - done : gcap;
+          __syncthreads();
+          lay_out(T);
+          __syncthreads();
+          for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] *= gseq[s >> 1];
+        }
+        __syncthreads();
+        return true;
       }
       __syncthreads();
       for (int i = tid; i < n; i += nt) sig[i] = sig[i] * v;
@@ -210,9 +232,37 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       return true;
     }
     case 1: {  // PanningEffect without ramps (pan.rs:105-158)
-      const PgPan& p = fx.u.pan;
-      if (sm_need_ramp(p.pan) || sm_need_ramp(p.width)) return false;
+      PgPan& p = fx.u.pan;
       float inv_l = p.invert_l ? -1.0f : 1.0f, inv_r = p.invert_r ? -1.0f : 1.0f;
+      if (sm_need_ramp(p.pan) || sm_need_ramp(p.width)) {
+        // moving pan / width (pan.rs:122-156): the two smoothers' value sequences by two lanes (each only if it moves, as the serial loop decides
+        // once per call), the per-frame mid / side and constant-power factors by all lanes
+        if constexpr ((KMASK >> 10) & 1) {
+          const bool pan_ramping = sm_need_ramp(p.pan), width_ramping = sm_need_ramp(p.width);
+          const int cap = fc.tmp_floats / 2 < 1024 ? fc.tmp_floats / 2 : 1024;
+          float* pseq = fc.tmp;
+          float* wseq = fc.tmp + cap;
+          const int frames = n / 2;
+          for (int done = 0; done < frames; done += cap) {
+            const int T = frames - done < cap ? frames - done : cap;
+            __syncthreads();
+            if (tid == 0) { PgSmooth sp = p.pan; for (int k = 0; k < T; ++k) pseq[k] = pan_ramping ? sm_next(sp) : sp.target; p.pan = sp; }
+            else if (tid == 64) { PgSmooth sw = p.width; for (int k = 0; k < T; ++k) wseq[k] = width_ramping ? sm_next(sw) : sw.target; p.width = sw; }
+            __syncthreads();
+            for (int k = tid; k < T; k += nt) {
+              const int f = 2 * (done + k);
+              float l = sig[f] * inv_l, r = sig[f + 1] * inv_r;
+              const float w = wseq[k];
+              if (fabsf(w - 1.0f) > 1e-6f) { const float mid = (l + r) * 0.5f, side = (l - r) * 0.5f; l = mid + side * w; r = mid - side * w; }
+              const float pv = pseq[k];
+              if (fabsf(pv) > 1e-6f) { float pl, pr; panning_factors(pv, pl, pr); l *= pl; r *= pr; }
+              sig[f] = l; sig[f + 1] = r;
+            }
+          }
+          __syncthreads();
+          return true;
+        } else return false;
+      }
       bool has_invert = inv_l < 0.0f || inv_r < 0.0f;
       float w = p.width.target, pv = p.pan.target;
       if (!has_invert && fabsf(pv) < 1e-6f && fabsf(w - 1.0f) < 1e-6f) return true;
@@ -270,10 +320,37 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     case 7: if constexpr ((KMASK >> 7) & 1) return comp_fast(fx, sig, n, fc); else return false;
     case 8: if constexpr ((KMASK >> 8) & 1) return gate_fast(fx, sig, n, fc); else return false;
     case 9: if constexpr ((KMASK >> 9) & 1) {  // DistortionEffect, no ramps (distortion.rs:331-341)
-      const PgDist& d = fx.u.dist;
-      if (sm_need_ramp(d.mix) || sm_need_ramp(d.drive)) return false;
-      if (d.mix.target == 0.0f) return true;
-      if (!(d.mix.target >= 1.0f)) return false;
+      PgDist& d = fx.u.dist;
+      if (!sm_need_ramp(d.mix) && d.mix.target == 0.0f) return true;   // (distortion.rs:331: nothing runs, no smoother moves)
+      if (sm_need_ramp(d.mix) || sm_need_ramp(d.drive) || !(d.mix.target >= 1.0f)) {
+        // a moving drive or mix, or a steady partial mix (distortion.rs:342-361: both smoothers step once per frame): two lanes lay the
+        // sequences out, the waveshaper with its per-frame drive and compensation runs on all lanes
+        if constexpr ((KMASK >> 10) & 1) {
+          const bool full_wet = !sm_need_ramp(d.mix) && d.mix.target >= 1.0f;   // the branch that leaves the mix smoother alone
+          const int cap = fc.tmp_floats / 2 < 1024 ? fc.tmp_floats / 2 : 1024;
+          float* dseq = fc.tmp;
+          float* mseq = fc.tmp + cap;
+          const int ty = d.type;
+          const int frames = n / 2;
+          for (int done = 0; done < frames; done += cap) {
+            const int T = frames - done < cap ? frames - done : cap;
+            __syncthreads();
+            if (tid == 0) { PgSmooth sd = d.drive; for (int k = 0; k < T; ++k) dseq[k] = sm_next(sd); d.drive = sd; }
+            else if (tid == 64 && !full_wet) { PgSmooth sx = d.mix; for (int k = 0; k < T; ++k) mseq[k] = sm_next(sx); d.mix = sx; }
+            __syncthreads();
+            for (int s = tid; s < 2 * T; s += nt) {
+              const float drive = dseq[s >> 1];
+              const float comp = dist_compensation(d.luts, ty, drive);
+              const float dry = sig[2 * done + s];
+              const float wet = dist_shape(ty, dry, drive) * comp;
+              if (full_wet) sig[2 * done + s] = wet;
+              else { const float mix = mseq[s >> 1]; sig[2 * done + s] = (1.0f - mix) * dry + mix * wet; }
+            }
+          }
+          __syncthreads();
+          return true;
+        } else return false;
+      }
       float drive = d.drive.target;
       float comp = dist_compensation(d.luts, d.type, drive);
       int ty = d.type;

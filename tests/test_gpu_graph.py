@@ -1373,3 +1373,41 @@ def test_reverb_wet_ramp_in_a_graph_of_lean_kernels():
     assert gg.dominant_kernel().startswith("pg_stage_fused_kernel") or "pg_unit_kernel_fast" in gg.dominant_kernel()
     assert deferred[3] == 2 and deferred[4] == 2 and deferred[9] == 0, deferred   # both units wait out the ramp on the generic kernel
     assert gg.device_errors() == 0
+
+
+def test_gain_panning_and_distortion_ramps_stay_on_the_time_parallel_kernels():
+    """The memoryless effects while their smoothers move — and the Distortion at a steady partial mix, whose reference loop steps both smoothers per
+    frame: single lanes lay the smoothers' value sequences out, all lanes apply them. Sub-mixers Gain -> Filter, Panning -> Filter and
+    Distortion (mix 0.5) -> Filter (a graph of wide kernels): only the block with the commands goes to the generic kernel."""
+    from phonic_amd.graph import Graph
+
+    def build(g):
+        ids = {}
+        for name, kind, params in (("gain", _capi.FX_GAIN, {"gain": 0.8}), ("pan", _capi.FX_PANNING, {"pan ": -0.2, "wdth": 1.2}),
+                                   ("dist", _capi.FX_DISTORTION, {"driv": 1.0, "mix ": 0.5}), ("dcgain", _capi.FX_GAIN, {"gain": 0.7, "dcfm": 2})):
+            m = g.add_mixer()
+            ids[name] = g.add_effect(m, kind, params=params)
+            g.add_effect(m, _capi.FX_FILTER, params={"cuto": 6000.0})
+            g.add_voice(m, workloads.tone_buffer(len(ids), 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    gg, gc = Graph(SR, 2, 1024, 0), oracle.OracleGraph(SR, 2, 1024)
+    outs, deferred = [], []
+    for g in (gg, gc):
+        ids = build(g)
+        o = np.zeros((10, 2048), np.float32)
+        for b in range(10):
+            if b == 3:
+                g.schedule_param(ids["gain"], "gain", 0.2, b * 1024 + 100)
+                g.schedule_param(ids["pan"], "pan ", 0.7, b * 1024 + 300)
+                g.schedule_param(ids["pan"], "wdth", 0.4, b * 1024 + 300)
+                g.schedule_param(ids["dist"], "driv", 3.0, b * 1024 + 500)
+                g.schedule_param(ids["dist"], "mix ", 0.9, b * 1024 + 700)
+                g.schedule_param(ids["dcgain"], "gain", 1.5, b * 1024 + 900)
+            assert g.write(o[b], b * 1024) == 2048
+            if g is gg:
+                deferred.append(g.deferred_units())
+        outs.append(o.reshape(-1))
+    compare(outs[0], outs[1])
+    assert deferred[2] == 0 and deferred[3] == 4 and deferred[4] == 0 and deferred[5] == 0, deferred   # (block 2: the steady partial mix is on the fast kernel too)
+    assert gg.device_errors() == 0
