@@ -1411,3 +1411,37 @@ def test_gain_panning_and_distortion_ramps_stay_on_the_time_parallel_kernels():
     compare(outs[0], outs[1])
     assert deferred[2] == 0 and deferred[3] == 4 and deferred[4] == 0 and deferred[5] == 0, deferred   # (block 2: the steady partial mix is on the fast kernel too)
     assert gg.device_errors() == 0
+
+
+def test_long_run_past_every_ring_wrap_without_drift():
+    """1100 blocks of 1024 frames (1 126 400 frames, 23 s): the Delay's 262 144-frame f64 lines wrap four times (the other rings — chorus line,
+    predelay, reverb combs and allpasses — many times), the f32 LFO phases and the vibrato phases of the reverb lines pass thousands of
+    periods, the looping sources wrap hundreds of times. The difference to the oracle must not grow: the last 32 blocks are held to the
+    same tolerance as the first 32."""
+    def build(g):
+        workloads.build_c5(g, 2, 0, 2, seconds=0.37)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_CHORUS)
+        g.add_effect(m, _capi.FX_DELAY, params={"mode": 1, "dlay": 3900.0, "fdbk": 0.55, "lfor": 0.31, "lfos": 1, "lfdt": 0.02, "ldfb": 0.2})
+        g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.8})
+        g.add_voice(m, workloads.tone_buffer(9, 44100, 0.41), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_DELAY, params={"dlay": 2600.0, "fdbk": 0.7, "ftyp": 2, "cuto": 2500.0, "driv": 0.2})
+        g.add_effect(m, _capi.FX_REVERB, params={"room": 0.8, "wet ": 0.6}, reverb_seeds=workloads.reverb_seeds(77))
+        g.add_voice(m, workloads.tone_buffer(15, 44100, 0.29, channels=1), 1, 44100, volume=0.6, speed=0.83, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return {}
+    n_blocks = 1100
+    a, b = both(build, n_blocks, 1024, max_frames=1024)
+    compare(a, b)
+    first = compare(a[:32 * 2048], b[:32 * 2048])
+    last = compare(a[-32 * 2048:], b[-32 * 2048:])
+    assert np.abs(a[-32 * 2048:]).max() > 1e-2
+    assert last <= max(4.0 * first, 2e-6), (first, last)
+    from phonic_amd.graph import Graph
+
+    g = Graph(SR, 2, 1024, 0)
+    build(g)
+    out = np.zeros(2048, np.float32)
+    for i in range(5):
+        g.write(out, i * 1024)
+    assert g.deferred_units() == 0

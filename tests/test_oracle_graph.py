@@ -173,3 +173,41 @@ def test_move_and_remove_effect_messages():
         g.move_effect(gain, 1, _capi.MOVE_END)          # not that mixer's effect
     g.remove_effect(gain)                               # []
     assert level(g, 6144) == 0.5
+
+
+def test_compressor_gain_computer_is_discontinuous_at_the_upper_knee_edge():
+    """Why a GPU-vs-oracle tolerance cannot hold on every input behind a Compressor: the reference's gain computer (compressor.rs:258-270)
+    has the branches `t - w/2 < envelope < t + w/2` (knee) and `envelope > t + w/2` (line) and nothing for `envelope == t + w/2`, where the
+    reduction falls to 0 dB — a one-frame click of (w/2)(1 - 1/ratio) = 1.3 dB at the defaults. A slowly released envelope moves by less than
+    30 ulps per frame, so it lands on the edge exactly in a few percent of its crossings. This is seed 301229 of the fuzz family `rates`
+    (Distortion -> Compressor after a move_effect; 44.1 kHz): the oracle's own output changes by 16 % in one frame when its input changes by
+    1e-7 — the size of the difference between the device's and glibc's tanh in the Distortion in front. The device reproduces the click
+    whenever its envelope is bit-equal (pg_log10f restates glibc's log10f for that: fuzz seeds 734, 888), not when an upstream effect
+    differs in the last place."""
+    sizes = [2048, 4096, 4096, 64, 2048, 1365, 1]
+
+    def render(volscale):
+        g = oracle.OracleGraph(44100, 2, 4096)
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_COMPRESSOR, params={"attk": 0.04995590075850487, "rels": 0.8362696766853333})
+        dist = g.add_effect(m, _capi.FX_DISTORTION)
+        g.add_voice(m, workloads.tone_buffer(54, 22050, 0.12), 2, 22050, volume=0.4557180730637565 * volscale, panning=0.8919428354856447, has_repeat=1,
+                    repeat=_capi.PG_REPEAT_FOREVER)
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            if b == 3:
+                g.move_effect(dist, m, _capi.MOVE_DIRECTION, -3)
+            o = np.zeros(2 * n, np.float32)
+            g.write(o, pos)
+            chunks.append(o)
+            pos += n
+        return np.concatenate(chunks).astype(np.float64)
+
+    a, b = render(1.0), render(1.0 + 1e-7)
+    d = np.abs(a - b)
+    i = int(np.argmax(d))
+    assert i // 2 == 13308 and d[i] > 0.1 * abs(a[i])                         # one frame, 16 % apart
+    d[2 * 13308:2 * 13308 + 2] = 0.0
+    assert d.max() < 1e-6                                                     # every other frame follows the 1e-7
+    ratio = a[2 * 13308 + 1] / b[2 * 13308 + 1]
+    assert abs(20.0 * np.log10(ratio) - 1.5 * (1.0 - 1.0 / 8.0)) < 0.01       # the click is the full reduction at the knee's upper edge
