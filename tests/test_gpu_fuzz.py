@@ -110,6 +110,19 @@ def render_plan(plan, g, split=0, events_at_call_start=False, mutations=True):
     return np.concatenate(chunks)
 
 
+def reference_is_discontinuous_here(plan, make_oracle, b, tol_rms, tol_max):
+    """The oracle against itself with every source 1e-7 louder. Where that alone moves the output by more than the tolerance the case sits on a
+    discontinuity of the reference — so far always the Compressor's gain computer, which has no branch for an envelope exactly on the knee's
+    upper edge (tests/test_oracle_graph.py) — and no device-vs-oracle tolerance can hold."""
+    import copy
+
+    p2 = copy.deepcopy(plan)
+    p2["mixers"] = [(chain, [(ti, rate, float(np.float32(vol * (1.0 + 1e-7))) if np.float32(vol * (1.0 + 1e-7)) != np.float32(vol) else vol * (1.0 + 2e-7), pan)
+                             for (ti, rate, vol, pan) in voices]) for chain, voices in plan["mixers"]]
+    d = render_plan(p2, make_oracle()).astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d))) > tol_rms or float(np.abs(d).max()) > tol_max
+
+
 # 888: a Gate whose envelope crosses the threshold where the device's own log10f and the host's differ in the last bit used to open a frame late;
 # 734 (super-block test below): a Compressor whose envelope landed exactly on the upper knee edge — where the reference's gain computer has no
 # branch — on the device only. The level detectors now use the host libm's log10f restated (pg_log10f).
@@ -133,6 +146,9 @@ def test_random_graph_matches_oracle(seed):
     scale = max(1.0, float(np.abs(b).max()))
     what = {"chains": [[(_capi.FX_NAMES[k], p) for (k, p, _) in chain] for chain, _ in plan["mixers"]], "bus": [(_capi.FX_NAMES[k], p) for (k, p, _) in plan["bus"]],
             "rms_per_block": [float(np.sqrt(np.mean(x * x))) for x in np.array_split(d, len(sizes))], "peak": float(np.abs(b).max())}
+    if (float(np.sqrt(np.mean(d * d))) > 1e-5 * scale or float(np.abs(d).max()) > 1e-4 * scale) and reference_is_discontinuous_here(
+            plan, lambda: oracle.OracleGraph(SR, 2, 1024), b, 1e-5 * scale, 1e-4 * scale):
+        pytest.skip("the reference is discontinuous at this input (DESIGN §2 (10))")
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) {what}"
     assert float(np.abs(d).max()) <= 1e-4 * scale, what
 
@@ -421,7 +437,7 @@ def test_random_standalone_effect_sequences(seed):
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), float(np.abs(d).max()), what)
 
 
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16)))
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16))) + ([] if FUZZ_SEEDS else [301229]))
 def test_random_graph_other_rates_and_block_sizes(seed):
     """The flat random graphs at other mixer rates (22.05 / 44.1 / 96 kHz: delay-line lengths, filter coefficients, smoother and tail constants,
     resampler ratios on the other side of one all move) and other max_frames (256 ... 4096: chunking of the time-parallel paths, the staged
@@ -443,6 +459,9 @@ def test_random_graph_other_rates_and_block_sizes(seed):
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     what = {"sr": sr, "max_frames": mf, "sizes": plan["sizes"], "chains": [[_capi.FX_NAMES[k] for (k, _, _) in chain] for chain, _ in plan["mixers"]], "bus": [_capi.FX_NAMES[k] for (k, _, _) in plan["bus"]]}
+    if (float(np.sqrt(np.mean(d * d))) > 1e-5 * scale or float(np.abs(d).max()) > 1e-4 * scale) and reference_is_discontinuous_here(
+            plan, lambda: oracle.OracleGraph(sr, 2, mf), b, 1e-5 * scale, 1e-4 * scale):
+        pytest.skip("the reference is discontinuous at this input (seed 301229: DESIGN §2 (10))")
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), what)
 
 
