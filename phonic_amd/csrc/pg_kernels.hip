@@ -204,23 +204,36 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
     if (!fx_fast_process<KMASK>(fx, sig, n, fc) && fc.err && pg_tid() == 0) atomicOr(fc.err, PG_DEVERR_FAST_DECLINED);
     return;
   } else {
-    if (fast && fx_fast_process<KMASK>(fx, sig, n, fc)) return;
-    __syncthreads();
-    if (pg_tid() == 0) {
-      switch (fx.kind) {
-        case 0: gain_serial(fx, sig, n); break;
-        case 1: pan_serial(fx, sig, n); break;
-        case 2: filter_serial(fx, sig, n); break;
-        case 3: eq5_serial(fx, sig, n); break;
-        case 4: delay_serial(fx, sig, n); break;
-        case 5: reverb_serial(fx, sig, n); break;
-        case 6: chorus_serial(fx, sig, n); break;
-        case 7: comp_serial(fx, sig, n); break;
-        case 8: gate_serial(fx, sig, n); break;
-        default: dist_serial(fx, sig, n); break;
+    // One pass in all cases but one: a Reverb whose room size moves. Its linear smoother arrives after `pending` frames (<= 109 at 44.1 kHz:
+    // reverb.rs:78-84, smoothing.rs:370-382) — only those run on the serial lane; behind them the frame loop of reverb.rs:318-338 keeps
+    // calling next() on settled smoothers, which is the steady state (or the wet ramp) the time-parallel paths render.
+    int off = 0;
+#pragma nounroll
+    while (off < n) {
+      if (fast && fx_fast_process<KMASK>(fx, sig + off, n - off, fc)) return;
+      __syncthreads();
+      int head = n - off;
+      if (fast && off == 0 && fx.kind == 5 && fx.u.reverb.room.kind == SM_LIN && fx.u.reverb.room.pending > 0 &&
+          (long long)fx.u.reverb.room.pending * 2 < (long long)head) head = (int)fx.u.reverb.room.pending * 2;
+      __syncthreads();  // every lane holds `head` before lane 0 moves the smoother
+      float* s = sig + off;
+      if (pg_tid() == 0) {
+        switch (fx.kind) {
+          case 0: gain_serial(fx, s, head); break;
+          case 1: pan_serial(fx, s, head); break;
+          case 2: filter_serial(fx, s, head); break;
+          case 3: eq5_serial(fx, s, head); break;
+          case 4: delay_serial(fx, s, head); break;
+          case 5: reverb_serial(fx, s, head); break;
+          case 6: chorus_serial(fx, s, head); break;
+          case 7: comp_serial(fx, s, head); break;
+          case 8: gate_serial(fx, s, head); break;
+          default: dist_serial(fx, s, head); break;
+        }
       }
+      __syncthreads();
+      off += head;
     }
-    __syncthreads();
   }
 }
 

@@ -1,5 +1,5 @@
-"""usage (GPU box): python tools/exp_reverb_ramp.py — cost of a block while every reverb's `wet` smoother moves: 256 sub-mixers Eq5 -> Reverb -> Gain,
-a wet command to each in block 3, wall time of the two blocks behind it, time-parallel kernels vs the exact serial ones."""
+"""usage (GPU box): python tools/exp_reverb_ramp.py [room] — cost of a block while every reverb's `wet` (or room size) smoother moves: 256 sub-mixers
+Eq5 -> Reverb -> Gain, a command to each in block 3, wall time of the blocks behind it, time-parallel kernels vs the exact serial ones."""
 import os
 import sys
 import time
@@ -27,7 +27,7 @@ for exact in (False, True):
     for b in range(8):
         if b == 3:
             for k, f in enumerate(ids):
-                g.schedule_param(f, "wet ", 0.9, b * 1024 + 10 + k)
+                g.schedule_param(f, "room" if "room" in sys.argv[1:] else "wet ", 0.9, b * 1024 + 10 + k)
         t0 = time.perf_counter()
         assert g.write(o, b * 1024) == 2048
         times.append((time.perf_counter() - t0) * 1e3)
