@@ -1298,7 +1298,8 @@ def test_reverb_wet_ramp_stays_on_the_time_parallel_kernels():
     the three low-pass cutoffs move per frame — reverb_wet_ramp_fast lays the smoother's sequence out on one lane and runs the biquads as
     time-varying blocked scans. Two sub-mixers Eq5 -> Reverb -> Gain (fused wide kernel: it carries the ramp paths) and one plain Reverb
     sub-mixer (staged kernel: no ramp paths, the generic kernel takes the unit while it ramps — with the same time-parallel path). Only the
-    block with the commands is rendered serially; a room-size change (ring lengths change per frame) keeps its unit on the serial lane."""
+    block with the commands is rendered serially; a room-size change (ring lengths change per frame) keeps its unit on the serial lane for the
+    frames of its linear ramp (next test)."""
     from phonic_amd.graph import Graph
 
     def build(g):
@@ -1445,3 +1446,54 @@ def test_long_run_past_every_ring_wrap_without_drift():
     for i in range(5):
         g.write(out, i * 1024)
     assert g.deferred_units() == 0
+
+
+def test_reverb_room_size_ramp_hands_the_rest_of_the_block_back_to_the_time_parallel_path():
+    """ReverbEffect while its room size moves (LinearSmoothedValue, 0.01 x 44100 / fs per frame: <= 109 frames; the ring lengths change per frame):
+    the generic kernel runs the smoother's pending frames on the serial lane and offers the rest of the block to the time-parallel paths (steady
+    state, or the wet ramp when `wet` moves too). Commands at a block start, in mid-block, 40 frames before a block end (the ramp crosses into the
+    next block), growing and shrinking rooms (a shrunk ring may leave a position above its new end: that unit stays serial a block longer), with and
+    without a simultaneous wet change, ragged block sizes, lean / wide / staged units."""
+    from phonic_amd.graph import Graph
+
+    def build(g):
+        ids = []
+        for i in range(2):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_EQ5, params={"gan2": -3.0})
+            ids.append(g.add_effect(m, _capi.FX_REVERB, params={"room": 0.3 + 0.4 * i}, reverb_seeds=workloads.reverb_seeds(60 + i)))
+            g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.9})
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.3), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        for i in range(2):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_GAIN, params={"gain": 0.7})
+            ids.append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(70 + i)))
+            g.add_voice(m, workloads.tone_buffer(5 + i, 48000, 0.3), 2, 48000, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return ids
+
+    sizes = [1024, 1024, 1024, 700, 1024, 333, 1024, 1024, 1024, 1024, 1024, 1024]
+    gg, gc = Graph(SR, 2, 1024, 0), oracle.OracleGraph(SR, 2, 1024)
+    outs = []
+    for g in (gg, gc):
+        ids = build(g)
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            if b == 2:
+                g.schedule_param(ids[0], "room", 0.95, pos)             # at the block start, growing
+                g.schedule_param(ids[2], "room", 0.1, pos + 500)        # mid-block, shrinking
+            if b == 4:
+                g.schedule_param(ids[1], "room", 0.2, pos + n - 40)     # the ramp crosses the block end
+                g.schedule_param(ids[3], "room", 1.0, pos + 17)
+                g.schedule_param(ids[3], "wet ", 0.9, pos + 17)         # room and wet together: the wet ramp takes over behind the room ramp
+            if b == 7:
+                g.schedule_param(ids[0], "room", 0.5, pos + 1000)
+                g.schedule_param(ids[0], "wet ", 0.1, pos + 1010)       # a second command inside the room ramp
+                g.schedule_param(ids[2], "room", 0.6, pos + 1023)
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+    compare(outs[0], outs[1])
+    assert np.abs(outs[0][-2048:]).max() > 1e-3
+    assert gg.device_errors() == 0 and gg.deferred_units() == 0
