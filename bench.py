@@ -15,9 +15,10 @@ Multi-GPU: voices are sharded over ranks (weak scaling: --voices per GPU; strong
 ranks), each rank renders its partial master bus on its GPU, and the partial buses meet in one RCCL sum-reduce to rank 0 per
 super-block (the reference's caller-side sum of worker outputs, src/source/mixed.rs:522-536).
 
-The timed region is `--repeats` legs (default: 5, up to 21 for short legs — a 20-step leg lasts 2 ms) of exactly `--steps` blocks, each bracketed by barrier +
-torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `ms_per_step` / `value` come from the MEDIAN leg and
-the spread is printed under `repeats`.
+The timed region is a series of legs of exactly `--steps` blocks, each bracketed by barrier + torch.cuda.synchronize() on both sides and
+reduced with MAX over ranks, repeated until `--min-seconds` (0.5 s) of wall time are covered (`--repeats` fixes the count);
+`ms_per_step` / `value` come from the MEDIAN leg and the spread is printed under `repeats`. At one GPU a second set of legs pulls the
+same graph with ONE write call per block — the reference's real-time call pattern — and lands in `config.realtime`.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel launch(es) of the graph, named in `roofline.kernel`, hipEvent-timed
 on the launching stream) and `cpu_baseline` (the CPU oracle — a C++ port of the reference path, NOT the Rust binary — on this
@@ -138,27 +139,43 @@ def spawn_ranks(n, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
+
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 600
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    sys.stdout.write(out0 or "")
-    sys.stdout.flush()
-    if any(rc != 0 for rc in rcs):
-        for p in procs:
+    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's stdout (a file, not a pipe: nobody has to drain it while the ranks are polled)
+    deadline = time.time() + float(os.environ.get("PHONIC_BENCH_RANK_TIMEOUT", "900"))
+    failed = None
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out0 if r == 0 else sys.stderr))
+        # one deadline for all ranks; the first rank that fails ends the others at once (a rank that died during start-up would otherwise
+        # leave rank 0 waiting in init_process_group / barrier until the backend's own timeout)
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if time.time() > deadline:
+                failed = "ranks still running at the deadline"
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:   # also on KeyboardInterrupt / SIGTERM of the parent: no GPU process is left behind
             if p.poll() is None:
                 p.kill()
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+    rcs = [p.returncode for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    if failed or any(rc != 0 for rc in rcs):
+        raise SystemExit(f"bench.py: {failed or 'a rank failed'}; rank exit codes {rcs}")
 
 
 def main():
@@ -166,8 +183,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=0, help="timed legs of exactly --steps blocks each, the median leg is reported (default: 5, more for short legs — "
-                    "a 20-step leg lasts 2 ms and single legs scatter by +-8 % with the clock state of the box: 21 legs at 20 steps)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed legs of exactly --steps blocks each, the median leg is reported (default: as many as --min-seconds needs, "
+                    "at least 5 — a 20-step leg lasts 2 ms and single legs scatter by +-8 % with the clock state of the box)")
     ap.add_argument("--workload", default="headline", choices=sorted(B_ALG))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --voices per GPU; strong: --total-voices split over the GPUs")
     ap.add_argument("--voices", type=int, default=0, help="weak scaling: voices PER GPU (default: the config's count)")
@@ -175,14 +192,14 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--superblock", type=int, default=32, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-realtime", action="store_true", help="skip the second set of legs (one write call per block) behind config.realtime")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed legs are repeated until this much wall time is covered (unless --repeats is given)")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
     ap.add_argument("--time-every", type=int, default=1, help="hipEvent-time the dominant kernel every n-th launch round (the event pair costs ~8 us of stream time: once per super-block by default)")
     ap.add_argument("--reduce-every", type=int, default=0, help="multi-GPU: blocks per RCCL master-bus reduce (default: the super-block; 1 = per block, the real-time setting)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
-    if args.repeats <= 0:
-        args.repeats = max(5, min(21, (400 // max(1, args.steps)) | 1))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
 
@@ -217,7 +234,19 @@ def main():
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL or nothing: a group that cannot be created (or cannot carry a first collective) ends the run with one line naming the
+            # rank and RCCL's error and a non-zero exit code — there is no fallback to another backend
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"first all_reduce over {world} rank(s) returned {probe.item()}")
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"bench.py: rank {rank}/{world} (cuda:{local_rank}): RCCL group creation failed: {type(e).__name__}: {' '.join(str(e).split())[:600]}\n")
+                sys.stderr.flush()
+                os._exit(3)
 
     from phonic_amd.graph import Graph
     from phonic_amd.parallel import MasterBusRing, reduce_master_bus, shard_range
@@ -231,10 +260,8 @@ def main():
         total_voices = v_per_gpu * world
         first_voice = rank * v_per_gpu
     block = args.block
-    bus_on_root = name in ("c2", "c4")  # bus effects run once on the root after the reduce
+    bus_on_root = name in ("c2", "c4")  # bus effects: once, behind the sum (on the root after the reduce when there are several ranks)
     sb = max(1, args.superblock)
-    if bus_on_root:
-        sb = 1  # the bus chain (one serial workgroup) runs per block behind the per-block reduce
     g = Graph(48000, 2, block, local_rank)
     if args.exact:
         g.set_fast_math(0)
@@ -252,7 +279,7 @@ def main():
     # partial buses travel in ONE RCCL reduce (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own
     # stream, ordered after the renders by an event) overlaps the renders of the following ones, and the render stream only waits
     # when a buffer comes round again. --superblock 1 is the real-time setting (one call and one reduce per block).
-    M = 1 if bus_on_root else max(sb, args.reduce_every or sb)
+    M = sb if bus_on_root else max(sb, args.reduce_every or sb)  # (c2 / c4: reduce and bus chain once per call, see render)
     M = (M + sb - 1) // sb * sb  # a reduce covers whole super-blocks
     # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
     # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
@@ -265,13 +292,14 @@ def main():
         ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
     pos = 0
 
-    def render(n_blocks):
-        """n_blocks consecutive blocks: super-blocks of `sb` (one ABI call each), the remainder in one smaller call."""
+    def render(n_blocks, per_call=None):
+        """n_blocks consecutive blocks: super-blocks of `per_call` (default: --superblock; one ABI call each), the remainder in one smaller call."""
         nonlocal pos
         done = 0
+        per_call = per_call or sb
         while done < n_blocks:
             left = n_blocks - done
-            parts = (left + sb - 1) // sb                      # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
+            parts = (left + per_call - 1) // per_call          # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
             k = min((left + parts - 1) // parts, ring.m)       # every launch pays about one block time of ramp-up and drain
             if k > ring.room():
                 ring.close()                                    # (the ring's super-block ends where the call does)
@@ -289,14 +317,14 @@ def main():
 
     dist_on = world > 1 or force_dist  # (a forced one-rank group goes through the same barriers and reductions)
 
-    def leg(n_blocks):
+    def leg(n_blocks, per_call=None):
         torch.cuda.synchronize()
         g.kernel_ms(reset=True)
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        render(n_blocks)
+        render(n_blocks, per_call)
         ring.drain()
         torch.cuda.synchronize()
         if dist_on:
@@ -306,15 +334,43 @@ def main():
         ms, launches, blocks = g.kernel_stats(reset=True)
         return dt, ms, launches, blocks
 
+    def legs_for(seconds, per_call=None):
+        """Timed legs of exactly --steps blocks until `seconds` of wall time are covered (at least 5, at most 2001; --repeats overrides):
+        a 20-step leg lasts 2 ms, single legs scatter with the clock state of the box. Returns (legs, per-leg seconds, MAX over ranks)."""
+        first = leg(args.steps, per_call)
+        d0 = first[0]
+        if dist_on:
+            t = torch.tensor([d0], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank runs the same number of legs
+            d0 = float(t.item())
+        n = args.repeats if args.repeats > 0 else max(5, min(2001, int(seconds / max(d0, 1e-6)) | 1))
+        legs = [first] + [leg(args.steps, per_call) for _ in range(n - 1)]
+        dts = [l[0] for l in legs]
+        if dist_on:
+            t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = [float(x) for x in t.tolist()]
+        torch.cuda.synchronize()
+        return legs, dts
+
+    def roofline_of(legs):
+        """Dominant kernel: algorithmic bytes of one launch / its average duration, per leg; a launch renders `blocks_per_launch` blocks of this
+        rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches))."""
+        per_leg = []
+        for (_, ms, launches, blocks) in legs:
+            if launches and ms > 0:
+                bpl = blocks / launches
+                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * block * bpl / (ms * 1e-3) / 1e9, launches))
+        if not per_leg:
+            return [0.0], (0.0, 0.0, 0.0, 0)
+        return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
+
     render(args.warmup)
     ring.drain()
-    legs = [leg(args.steps) for _ in range(max(1, args.repeats))]
-    dts = [l[0] for l in legs]
-    if dist_on:
-        t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dts = [float(x) for x in t.tolist()]
-    torch.cuda.synchronize()
+    legs, dts = legs_for(args.min_seconds)
+    # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
+    # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
+    rt_legs, rt_dts = (legs_for(args.min_seconds / 2, 1) if (sb > 1 and world == 1 and not args.no_realtime) else (None, None))
     last = ring.last_block()
     peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
 
@@ -325,18 +381,7 @@ def main():
         med = int(np.argsort(dts)[len(dts) // 2])
         dt = dts[med]
         value = total_voices * block * args.steps / dt
-        # roofline of the dominant kernel: algorithmic bytes of one launch / its average duration. A launch renders `blocks_per_launch`
-        # blocks of this rank's voices (super-block launches loop over the blocks inside the kernel).
-        per_leg = []
-        for (_, ms, launches, blocks) in legs:
-            if launches and ms > 0:
-                bpl = blocks / launches
-                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * block * bpl / (ms * 1e-3) / 1e9, launches))
-        if per_leg:
-            ach = sorted(p[2] for p in per_leg)
-            ms_l, bpl_l, achieved, launches_l = sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
-        else:
-            ach, ms_l, bpl_l, achieved, launches_l = [0.0], 0.0, 0.0, 0.0, 0
+        ach, (ms_l, bpl_l, achieved, launches_l) = roofline_of(legs)
         traffic, traffic_note = pmc_traffic(name, v_per_gpu, block)
         out = {
             "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample",
@@ -352,7 +397,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "repeats": {"n": len(dts), "reported": "median", "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_median": dt / args.steps * 1e3,
-                        "ms_per_step_max": max(dts) / args.steps * 1e3},
+                        "ms_per_step_max": max(dts) / args.steps * 1e3, "timed_seconds": sum(dts)},
             "config": {
                 "workload": WORKLOAD_TEXT[name],
                 "voices_per_gpu": v_per_gpu,
@@ -389,6 +434,21 @@ def main():
                 "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * block * bpl_l,
             },
         }
+        if rt_legs:
+            rt_dt = rt_dts[int(np.argsort(rt_dts)[len(rt_dts) // 2])]
+            rt_ach, (rt_ms, rt_bpl, rt_achieved, _) = roofline_of(rt_legs)
+            out["config"]["realtime"] = {
+                "what": "one pg_graph_write_device call per 1024-frame block (src/output/wav.rs:210-250, cpal), same graph, same run",
+                "blocks_per_call": 1,
+                "ms_per_step": rt_dt / args.steps * 1e3,
+                "value": total_voices * block * args.steps / rt_dt,
+                "roofline_frac": rt_achieved / HBM_PEAK_GBS,
+                "roofline_frac_min": rt_ach[0] / HBM_PEAK_GBS,
+                "roofline_frac_max": rt_ach[-1] / HBM_PEAK_GBS,
+                "kernel_ms_per_block": rt_ms / rt_bpl if rt_bpl else 0.0,
+                "repeats": len(rt_dts),
+                "timed_seconds": sum(rt_dts),
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, block)
         print(json.dumps(out))

@@ -263,30 +263,58 @@ int pg_graph_synchronize(pg_graph* g);
  * devices: one handle owns one pg_graph per entry of `devices` (the first is the root). Every sub-mixer of the main mixer — with its
  * effects, sources and nested sub-mixers — and every main-mixer source is placed on the least loaded shard when it is added (the greedy
  * placement of WorkerTaskBatcher) and never moves; effects added to mixer 0 form the bus chain on the root. write = one asynchronous
- * render per shard on its own device and stream, the partial buses copied to the root device (peer copies), summed there in shard order,
- * then the bus chain. Ids returned here are global (valid for the pg_sharded_* calls only). Threading as for pg_graph: add_* / write from
- * the owner thread, the control calls from any thread. A device may be listed more than once (several shards on one GPU: how the
- * single-GPU test-suite exercises this path). bench.py's measured multi-GPU path is one process per GPU with an RCCL reduce instead
- * (phonic_amd/parallel.py); both sit on the same kernels and per-graph host code. */
+ * render per shard on its own device and stream, the partial buses summed on the root device, then the bus chain.
+ *
+ * The handle IS the main MixedSource: it takes every call pg_graph takes (the reference's MixerMessage set, src/source/mixed.rs:124-145,
+ * 163-178,422-462) and routes it to the shard that owns the target; ids returned here are global (valid for the pg_sharded_* calls
+ * only) and never reused. A write is cut at the main mixer's event times of ALL shards, so every shard splits its chunks where the one
+ * mixer would (mixed.rs:679-712); the bus chain gets one `audible_input` per chunk, OR-ed over the shards (mixed.rs:696-706); write
+ * returns 0 exactly when pg_graph_write would (mixed.rs:664-670). Threading as for pg_graph: add_* / remove_* / move_* / write from the
+ * owner thread, the control calls (schedule_*, set_voice_*, seek, stop_*) from any thread. A device may be listed more than once
+ * (several shards on one GPU: how the single-GPU test-suite exercises this path; not with PG_REDUCE_RCCL). bench.py's measured multi-GPU
+ * path is one process per GPU with an RCCL reduce through torch.distributed (phonic_amd/parallel.py); both sit on the same kernels and
+ * per-graph host code. */
 typedef struct pg_sharded_graph pg_sharded_graph;
 pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, const int* devices, int n_devices);
 void pg_sharded_destroy(pg_sharded_graph* s);
 int pg_sharded_shard_count(pg_sharded_graph* s);
 int pg_sharded_set_max_blocks_per_launch(pg_sharded_graph* s, int n_blocks);   /* a write holds at most n_blocks x max_frames frames */
+/* How the shards' partial buses meet on the root device.
+ *   PG_REDUCE_PEER_COPY (default): hipMemcpyPeerAsync of every partial to the root + one sum kernel, f32 adds in shard order (deterministic).
+ *   PG_REDUCE_RCCL: ncclReduce(sum, float32, root = shard 0) over xGMI on the shards' own streams inside one ncclGroupStart/End, the
+ *     `audible` words by ncclReduce(max) in the same group (north_star: "RCCL reduce over xGMI for the master-bus sum"). The sum order
+ *     is RCCL's, inside the 1e-5 RMS gate. One communicator per shard from ncclCommInitAll over `devices`, created by this call: every
+ *     device may be listed once only; RCCL is looked up at run time (librccl.so.1 — the one already in the process, e.g. PyTorch's, else
+ *     ROCm's). On failure the call returns PG_ERR_DEVICE / PG_ERR_PARAMETER with RCCL's error text and the mode stays as it was. */
+#define PG_REDUCE_PEER_COPY 0
+#define PG_REDUCE_RCCL 1
+int pg_sharded_set_reduce(pg_sharded_graph* s, int mode);
+int pg_sharded_reduce_mode(pg_sharded_graph* s);
 int pg_sharded_add_mixer(pg_sharded_graph* s);                                  /* Player::add_mixer(None) */
 int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id);          /* nested: lives on its parent's shard */
 int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init);
 int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
                          const pg_voice_options* opt);
 int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id);
+/* Player::remove_mixer / remove_effect / move_effect (src/player.rs:825-867,942-990; MixerMessage::RemoveMixer / RemoveEffect / MoveEffect,
+ * src/source/mixed.rs:422-462): semantics and errors of pg_graph_remove_mixer / _remove_effect / _move_effect. */
+int pg_sharded_remove_mixer(pg_sharded_graph* s, int mixer_id);
+int pg_sharded_remove_effect(pg_sharded_graph* s, int effect_id);
+int pg_sharded_move_effect(pg_sharded_graph* s, int effect_id, int mixer_id, int movement, int offset);
 int pg_sharded_schedule_param(pg_sharded_graph* s, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time);
 int pg_sharded_schedule_reset(pg_sharded_graph* s, int effect_id, uint64_t sample_time);
 int pg_sharded_set_voice_volume(pg_sharded_graph* s, int voice_id, float volume, uint64_t sample_time);
 int pg_sharded_set_voice_panning(pg_sharded_graph* s, int voice_id, float panning, uint64_t sample_time);
+/* FilePlaybackHandle::set_speed / seek (src/player/handles/file.rs:111,150 -> MixerMessage::SetSourceSpeed / SeekSource, mixed.rs:338-383) */
+int pg_sharded_set_voice_speed(pg_sharded_graph* s, int voice_id, double speed, float glide_semitones_per_second, uint64_t sample_time);
+int pg_sharded_seek_voice(pg_sharded_graph* s, int voice_id, double position_seconds, uint64_t sample_time);
 int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time);
 int pg_sharded_stop_all_voices(pg_sharded_graph* s);
-/* Source::write: host buffer (waits for the result) / buffer on the root device (asynchronous on the root shard's stream; at most
- * max_blocks x max_frames frames per call; pg_sharded_synchronize waits for it). Both return the samples written, 0 when nothing plays. */
+int pg_sharded_is_voice_playing(pg_sharded_graph* s, int voice_id);
+/* Source::write: host buffer (waits for the result) / buffer on the root device (asynchronous on the shards' streams, several calls may be
+ * enqueued before pg_sharded_synchronize; at most max_blocks x max_frames frames per call). Both return the samples written, or 0 when
+ * the main mixer has nothing to do (mixed.rs:664-670: no playing source, sub-mixer or pending event on any shard and no effect on
+ * mixer 0; the host learns that sources have ended from the device after a pg_sharded_write, as pg_graph_write does). */
 size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames);
 size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames);
 int pg_sharded_synchronize(pg_sharded_graph* s);

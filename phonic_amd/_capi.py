@@ -13,6 +13,7 @@ FX_NAMES = ["Gain", "Panning", "Filter", "Eq5", "Delay", "Reverb", "Chorus", "Co
 
 PG_MAX_INIT_PARAMS = 16
 MOVE_DIRECTION, MOVE_START, MOVE_END = 0, 1, 2  # EffectMovement (src/player.rs:75-82)
+REDUCE_PEER_COPY, REDUCE_RCCL = 0, 1  # pg_sharded_set_reduce
 PG_REPEAT_FOREVER = 2**64 - 1
 INT64_MAX = 2**63 - 1
 
@@ -163,6 +164,27 @@ def _preload_hip_runtime():
         pass
 
 
+def preload_rccl():
+    """The RCCL that matches the HIP runtime in the process: libphonic_gpu.so looks RCCL up by soname (librccl.so.1) when
+    pg_sharded_set_reduce(PG_REDUCE_RCCL) is called. With PyTorch's runtime loaded (see above) that must be PyTorch's RCCL, so it is
+    loaded first; without torch (or with PHONIC_HIP_RUNTIME=system) the library finds ROCm's own on its run path."""
+    import sys
+
+    if os.environ.get("PHONIC_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def source_hash():
     """16 hex digits over the sources libphonic_gpu.so is built from (csrc/*.hip|.h|.inl, the Makefile, include/phonic_gpu.h). Profiles that
     bench.py quotes (profiles/*_pmc_traffic.json) carry the hash of the build they were measured with."""
@@ -171,7 +193,7 @@ def source_hash():
 
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) + glob.glob(os.path.join(here, "csrc", "*.inl")))
-    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(os.path.dirname(here), "include", "phonic_gpu.h")]
+    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(here, "csrc", "phonic_gpu.map"), os.path.join(os.path.dirname(here), "include", "phonic_gpu.h")]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -248,6 +270,9 @@ def load():
                        ("add_effect", [C.c_int, C.c_int, P(EffectInit)]), ("add_voice", [C.c_int, P(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, P(VoiceOptions)]),
                        ("shard_of_mixer", [C.c_int]), ("schedule_param", [C.c_int, C.c_uint32, C.c_float, C.c_int, C.c_uint64]), ("schedule_reset", [C.c_int, C.c_uint64]),
                        ("set_voice_volume", [C.c_int, C.c_float, C.c_uint64]), ("set_voice_panning", [C.c_int, C.c_float, C.c_uint64]),
+                       ("set_voice_speed", [C.c_int, C.c_double, C.c_float, C.c_uint64]), ("seek_voice", [C.c_int, C.c_double, C.c_uint64]),
+                       ("remove_mixer", [C.c_int]), ("remove_effect", [C.c_int]), ("move_effect", [C.c_int, C.c_int, C.c_int, C.c_int]),
+                       ("set_reduce", [C.c_int]), ("reduce_mode", []), ("is_voice_playing", [C.c_int]),
                        ("stop_voice", [C.c_int, C.c_uint64]), ("stop_all_voices", []), ("synchronize", []), ("device_errors", [])):
         fn = getattr(lib, "pg_sharded_" + name)
         fn.restype = C.c_int

@@ -301,6 +301,11 @@ struct PgLaunch {
   uint32_t fast_scratch_bytes;  // host: LDS arena of the fast kernels for the effect kinds this graph holds (0: the full arena)
   uint32_t pad_scratch;
   int32_t* index_log;     // test hook (generic kernel only, see FastCtx::idx_log): read indices of the time-parallel delay-line paths
+  // Per-block `audible` results of this level's units: block c of launch slot b -> audible_tab[c * audible_stride + b]. PgUnit::audible holds
+  // the last block only; the mixer sum ORs one row of this table per block (audible_input of process_effects, mixed.rs:696-706), so the bus
+  // chain behind a super-block launch sees every block's own flag. nullptr: not collected (standalone effects, bus launches).
+  int32_t* audible_tab;
+  uint64_t audible_stride;
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
 enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take

@@ -5,37 +5,11 @@
 // (src/source/mixed.rs:294-499,679-712, src/utils/event.rs) — all integer sample-time arithmetic, done
 // here on the host and handed to the kernels as per-launch command lists — and the parameter descriptor
 // logic (pg_params.h). All per-sample work happens in pg_kernels.hip.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/phonic_gpu.h"
-#include "pg_ctrl.h"
-#include "pg_dev.h"
-#include "pg_dsp_dev.h"
-#include "pg_params.h"
-
-using namespace pgd;
-using namespace pgh;
-
-size_t pg_fast_scratch_bytes(uint32_t kind_mask);
-hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
-                         const int32_t* order, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0);
+#include "pg_host_internal.h"
 
 // ---- errors ---------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
-static int set_error(int code, const char* fmt, ...) {
+int set_error(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -44,518 +18,23 @@ static int set_error(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
-#define PG_CMD_RING 65536   // commands in flight between two points at which the host knows the stream drained (2 MB device + 2 MB pinned)
-#define PG_CTRL_RING 65536  // control messages waiting for the next write (the reference: 4096 per mixer; here one ring per graph)
-#define HIP_TRY(expr)                                                                                    \
-  do {                                                                                                   \
-    hipError_t _e = (expr);                                                                              \
-    if (_e != hipSuccess) return set_error(PG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-  } while (0)
 
-// ---- device memory helpers ------------------------------------------------------------------------------
-// Every allocation, release and host-blocking HIP call of the library goes through these wrappers and is counted
-// (pg_debug_hip_calls): the reference wraps its audio callback in assert_no_alloc (src/output/cpal.rs:712-715); the test-suite
-// checks the same property here — a write() on a built graph allocates nothing, frees nothing and (on a caller's stream) never blocks.
+// ---- device memory helpers (counted: pg_debug_hip_calls) ---------------------------------------------------
 static std::atomic<uint64_t> g_n_alloc{0}, g_n_free{0}, g_n_sync{0}, g_n_blocking_copy{0};
-static hipError_t pg_malloc(void** p, size_t bytes) { g_n_alloc++; return hipMalloc(p, bytes); }
-static hipError_t pg_host_malloc(void** p, size_t bytes, unsigned flags) { g_n_alloc++; return hipHostMalloc(p, bytes, flags); }
-static hipError_t pg_free(void* p) { g_n_free++; return hipFree(p); }
-static hipError_t pg_host_free(void* p) { g_n_free++; return hipHostFree(p); }
-static hipError_t pg_stream_sync(hipStream_t s) { g_n_sync++; return hipStreamSynchronize(s); }
-static hipError_t pg_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { g_n_blocking_copy++; return hipMemcpy(d, s, n, k); }
-static hipError_t pg_memset(void* d, int v, size_t n) { g_n_blocking_copy++; return hipMemset(d, v, n); }
-
-// Device array that grows by reallocation + device-to-device copy (device-evolved state survives). New elements are collected in a
-// small pinned staging block and travel in batches: a full block is flushed by the (non real-time) call that filled it, the rest by
-// flush_async() on the render stream at the next write — one copy per <= STAGE elements instead of one per element.
-template <class T>
-struct DeviceVec {
-  static constexpr size_t STAGE = 256;
-  T* d = nullptr;
-  size_t n = 0, cap = 0;      // n counts staged elements too
-  T* h_stage = nullptr;       // pinned, STAGE elements
-  size_t n_staged = 0;        // elements [n - n_staged, n) wait in h_stage
-  int reserve(size_t want) {  // allocates: graph construction only
-    if (want <= cap) return PG_OK;
-    size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 16);
-    T* nd = nullptr;
-    HIP_TRY(pg_malloc((void**)&nd, ncap * sizeof(T)));
-    const size_t on_device = n - n_staged;
-    if (d && on_device) HIP_TRY(pg_memcpy(nd, d, on_device * sizeof(T), hipMemcpyDeviceToDevice));
-    if (d) (void)pg_free(d);
-    d = nd;
-    cap = ncap;
-    return PG_OK;
-  }
-  int flush() {  // blocking (graph construction)
-    if (n_staged) HIP_TRY(pg_memcpy(d + (n - n_staged), h_stage, n_staged * sizeof(T), hipMemcpyHostToDevice));
-    n_staged = 0;
-    return PG_OK;
-  }
-  int flush_async(hipStream_t s) {  // from write(): pinned source, no allocation, no wait; the staging block is not touched again before the
-    if (n_staged) HIP_TRY(hipMemcpyAsync(d + (n - n_staged), h_stage, n_staged * sizeof(T), hipMemcpyHostToDevice, s));  // next mutation, which drains the stream first
-    n_staged = 0;
-    return PG_OK;
-  }
-  int push(const T& v, int* index) {
-    int rc = reserve(n + 1);
-    if (rc) return rc;
-    if (!h_stage) HIP_TRY(pg_host_malloc((void**)&h_stage, STAGE * sizeof(T), hipHostMallocDefault));
-    if (n_staged == STAGE && (rc = flush())) return rc;
-    h_stage[n_staged++] = v;
-    *index = (int)n++;
-    return PG_OK;
-  }
-  void release() { if (d) (void)pg_free(d); if (h_stage) (void)pg_host_free(h_stage); d = nullptr; h_stage = nullptr; n = cap = n_staged = 0; }
-};
-
-// Table rebuilt from the host mirror at every topology change: capacity is reserved by the mutating calls (reserve: may allocate),
-// the contents travel with ONE asynchronous copy from pinned staging inside write (upload_async: never allocates).
-template <class T>
-struct DeviceTable {
-  T* d = nullptr;
-  T* h = nullptr;  // pinned staging, same capacity
-  size_t n = 0, cap = 0;
-  int reserve(size_t want) {
-    if (want <= cap) return PG_OK;
-    size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 64);
-    if (d) (void)pg_free(d);
-    if (h) (void)pg_host_free(h);
-    d = nullptr; h = nullptr; cap = 0;
-    HIP_TRY(pg_malloc((void**)&d, ncap * sizeof(T)));
-    HIP_TRY(pg_host_malloc((void**)&h, ncap * sizeof(T), hipHostMallocDefault));
-    cap = ncap;
-    return PG_OK;
-  }
-  int upload_async(const std::vector<T>& v, hipStream_t s) {
-    if (v.size() > cap) return set_error(PG_ERR_STATE, "device table capacity was not reserved by the mutating call");
-    if (!v.empty()) {
-      memcpy(h, v.data(), v.size() * sizeof(T));
-      HIP_TRY(hipMemcpyAsync(d, h, v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    }
-    n = v.size();
-    return PG_OK;
-  }
-  void release() { if (d) (void)pg_free(d); if (h) (void)pg_host_free(h); d = nullptr; h = nullptr; n = cap = 0; }
-};
-
-static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
-
-// ---- smoother construction (constructors of src/utils/smoothing.rs + SmoothedParameterValue) --------------
-static PgSmooth make_smooth(const ParamSpec& p, float value, uint32_t sr) {
-  PgSmooth s;
-  memset(&s, 0, sizeof s);
-  s.comp = 44100.0f / (float)sr;  // set_sample_rate
-  s.current = s.target = value;
-  switch (p.smooth) {
-    case S_LIN:  // LinearSmoothedValue::default().with_step(step); init(v); set_sample_rate(sr)  :257-310,394-401
-      s.kind = SM_LIN; s.a = p.smooth_arg; s.b = s.a * s.comp; s.pending = 0; break;
-    case S_SPRING:  // SpringSmoothedValue::default().with_duration(d)  :434-474
-      s.kind = SM_SPRING; s.a = 5.5f / (float)(size_t)p.smooth_arg; s.b = 0.0f; break;
-    default:  // ExponentialSmoothedValue (inertia 1/256 unless stated)  :139,156-170
-      s.kind = SM_EXP; s.a = p.smooth_arg > 0.0f ? p.smooth_arg : 1.0f / 256.0f; break;
-  }
-  return s;
-}
-
-// distortion LUT (DistortionType::rms_compensation, src/effect/distortion.rs:88-122): pure function of the
-// shaper, built once per device on the host with the same f32 arithmetic as the reference's `new()`.
-static float h_dist_shape(int type, float sample, float drive) {
-  const float MAX_DRIVE = 4.0f, PI32 = 3.14159274101257324f;
-  float t = drive / MAX_DRIVE;
-  switch (type) {
-    case 0: { float gain = 1.0f + (t * t) * 14.0f; float x = sample * gain; if (x >= 1.0f) return 1.0f; if (x > -1.0f) { if (gain <= 1.0f) return sample; return (3.0f / 2.0f) * (x - (x * x * x) / 3.0f); } return -1.0f; }
-    case 1: { float gain = 1.0f + (t * t) * 24.0f; float th = 1.0f / gain; return h_clamp(sample, -th, th) * gain; }
-    case 2: { float curve = 0.6f * (t * t) + 0.4f * t; float gain = 1.0f + curve * 19.0f; float dc = std::exp((0.1f * sample) / (0.0253f * 1.68f)) - 1.0f; return 2.0f / PI32 * std::atan(dc * gain); }
-    case 3: { float gain = 1.0f + (1.0f - std::exp(-3.0f * t)) * 29.0f; float a = sample * gain; float s = (a < 0.0f) ? -1.0f * (1.0f - std::exp(-std::fabs(a))) : 1.0f * (1.0f - std::exp(-std::fabs(a))); return 1.5f * (s + std::fabs(s)); }
-    default: { float gain = 1.0f + (t * t) * 3.0f; float x = sample * gain; float th = 1.0f / gain; if (x > th || x < -th) return std::fabs(std::fmod(std::fabs(x - th), th * 4.0f) - th * 2.0f) - th; return x; }
-  }
-}
-static void build_dist_luts(float* luts /*[5][256]*/) {
-  const int N = 256;
-  static const float PARTIALS[5][2] = {{1.0f, 0.60f}, {2.7f, 0.25f}, {5.3f, 0.10f}, {9.1f, 0.03f}, {14.6f, 0.02f}};
-  float partials_peak = 0.0f;
-  for (int p = 0; p < 5; ++p) partials_peak += PARTIALS[p][1];
-  for (int type = 0; type < 5; ++type)
-    for (int li = 0; li < 256; ++li) {
-      float drive = (float)li / 255.0f * 4.0f;
-      float in_sq = 0.0f, out_sq = 0.0f;
-      for (int i = 0; i < N; ++i) {
-        float t = 6.28318548202514648f * ((float)i + 0.5f) / (float)N;
-        float s = 0.0f;
-        for (int p = 0; p < 5; ++p) s += PARTIALS[p][1] * std::sin(PARTIALS[p][0] * t);
-        float sample = s / partials_peak;
-        in_sq += sample * sample;
-        float o = h_dist_shape(type, sample, drive);
-        out_sq += o * o;
-      }
-      float in_rms = std::sqrt(in_sq / (float)N), out_rms = std::sqrt(out_sq / (float)N);
-      luts[type * 256 + li] = (out_rms > 1e-10f) ? in_rms / out_rms : 1.0f;
-    }
-}
-// vibrato rotation table of the reverb fast path: cos/sin(j * depth_i * vib_speed), j = 0..128, for the eight lines
-// (depths: src/effect/reverb.rs:137-144; increment depth*speed: reverb.rs:601-603). Read-only, shared by all instances.
-static std::mutex g_tables_mutex;  // the shared read-only tables are built once per device, from whichever thread gets there first;
-static std::map<int, double*> g_vib_tabs;  // they live until the process ends (a few KB per device)
-static int get_vib_tab(int device, const double** out) {
-  std::lock_guard<std::mutex> lock(g_tables_mutex);
-  auto it = g_vib_tabs.find(device);
-  if (it == g_vib_tabs.end()) {
-    static const double depths[8] = {0.003251, 0.002999, 0.002917, 0.002749, 0.002503, 0.002423, 0.002146, 0.002088};
-    std::vector<double> h(8 * 129 * 2);
-    for (int i = 0; i < 8; ++i) {
-      const double d = depths[i] * 0.1;
-      for (int j = 0; j <= 128; ++j) { h[(i * 129 + j) * 2] = std::cos((double)j * d); h[(i * 129 + j) * 2 + 1] = std::sin((double)j * d); }
-    }
-    double* dp = nullptr;
-    HIP_TRY(pg_malloc((void**)&dp, h.size() * 8));
-    HIP_TRY(pg_memcpy(dp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
-    it = g_vib_tabs.emplace(device, dp).first;
-  }
-  *out = it->second;
-  return PG_OK;
-}
-static std::map<int, float*> g_dist_luts;  // per device
-static int get_dist_luts(int device, const float** out) {
-  std::lock_guard<std::mutex> lock(g_tables_mutex);
-  auto it = g_dist_luts.find(device);
-  if (it == g_dist_luts.end()) {
-    std::vector<float> h(5 * 256);
-    build_dist_luts(h.data());
-    float* d = nullptr;
-    HIP_TRY(pg_malloc((void**)&d, h.size() * 4));
-    HIP_TRY(pg_memcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    it = g_dist_luts.emplace(device, d).first;
-  }
-  *out = it->second;
-  return PG_OK;
-}
-
-// ---- effect instance: host mirror + construction of the device state ---------------------------------------
-struct HostFx {
-  int kind = 0;
-  std::vector<float> init_raw;   // raw value per parameter after `new()/with_parameters`
-  std::vector<float> target;     // shadow of the targets (for nothing on the hot path; introspection only)
-  bool with_params = false;
-  bool has_seeds = false;
-  uint32_t fpd_l = 16386, fpd_r = 16386;
-  double vib[16] = {0};
-  void* d_mem = nullptr;         // delay-line memory owned by this effect
-  size_t d_mem_bytes = 0;
-  int last_mixer = -1;           // graph effects: the mixer the effect belonged to when it was removed (its late events stay that mixer's events)
-};
-
-static int host_fx_from_init(int kind, const pg_effect_init* init, HostFx& h) {
-  if (kind < 0 || kind >= PG_FX_KIND_COUNT) return set_error(PG_ERR_PARAMETER, "unknown effect kind %d", kind);
-  const KindInfo& k = KINDS[kind];
-  h.kind = kind;
-  h.init_raw.resize(k.n_params);
-  for (int i = 0; i < k.n_params; ++i) h.init_raw[i] = k.params[i].def;
-  if (init) {
-    if (init->n_params > PG_MAX_INIT_PARAMS) return set_error(PG_ERR_PARAMETER, "too many init parameters");
-    for (uint32_t i = 0; i < init->n_params; ++i) {
-      int pi = find_param(kind, init->fourcc[i]);
-      if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", init->fourcc[i], k.name);
-      const ParamSpec& p = k.params[pi];
-      float v = init->value[i];
-      if (p.type == PG_PARAM_FLOAT && !(v >= p.min && v <= p.max)) return set_error(PG_ERR_PARAMETER, "Value out of bounds for '%s'", p.name);
-      if (p.type == PG_PARAM_ENUM && !((int)v >= 0 && (int)v < p.n_values)) return set_error(PG_ERR_PARAMETER, "Invalid enum index for '%s'", p.name);
-      if (kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)v >= 5)
-        return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random draw from an OS-seeded RNG in the reference and are not supported");
-      h.init_raw[pi] = v;
-      h.with_params = true;
-    }
-    if (init->has_reverb_seeds) {
-      h.has_seeds = true;
-      h.fpd_l = init->reverb_fpd_l; h.fpd_r = init->reverb_fpd_r;
-      memcpy(h.vib, init->reverb_vib_phase, sizeof h.vib);
-    }
-  }
-  h.target = h.init_raw;
-  return PG_OK;
-}
-
-// State of the effect right after `Effect::initialize(sample_rate, 2, max_frames)`.
-static int build_fx_device_state(HostFx& h, uint32_t sr, int device, bool standalone, PgFx& fx) {
-  memset(&fx, 0, sizeof fx);
-  const KindInfo& k = KINDS[h.kind];
-  const ParamSpec* P = k.params;
-  const std::vector<float>& v = h.init_raw;
-  fx.kind = h.kind;
-  fx.sample_rate = sr;
-  fx.bypassed = 1;                         // EffectProcessor::new  effect.rs:26-33
-  fx.tail_counter = 0;
-  fx.silence_counter = PG_USIZE_MAX;
-  fx.standalone = standalone ? 1 : 0;
-  auto alloc = [&](size_t bytes) -> int {
-    h.d_mem_bytes = bytes;
-    HIP_TRY(pg_malloc(&h.d_mem, bytes));
-    HIP_TRY(pg_memset(h.d_mem, 0, bytes));
-    return PG_OK;
-  };
-  switch (h.kind) {
-    case PG_FX_GAIN: {  // gain.rs:123-141
-      PgGain& g = fx.u.gain;
-      g.gain = make_smooth(P[0], v[0], sr);
-      g.dc_mode = (int)v[1];
-      double hz = g.dc_mode == 1 ? 1.0 : (g.dc_mode == 3 ? 20.0 : 5.0);  // unwrap_or(Default)
-      for (int c = 0; c < 2; ++c) { g.dc[c].x1 = g.dc[c].y1 = 0.0; g.dc[c].r = dc_r(hz, sr); }
-    } break;
-    case PG_FX_PANNING: {
-      PgPan& p = fx.u.pan;
-      p.pan = make_smooth(P[0], v[0], sr);
-      p.width = make_smooth(P[1], v[1], sr);
-      p.invert_l = v[2] != 0.0f; p.invert_r = v[3] != 0.0f;
-    } break;
-    case PG_FX_FILTER: {  // filter.rs:87-115,141-164
-      PgFilter& f = fx.u.filter;
-      f.type = (int)v[0];
-      f.cutoff = make_smooth(P[1], v[1], sr);
-      f.q = make_smooth(P[2], v[2], sr);
-      memset(&f.coef, 0, sizeof f.coef);
-      biquad_set(f.coef, 0, 44100, 22050.0f, 0.707f, 0.0f);  // new(): coefficients for 44100 Hz (!)
-      if (h.with_params) {
-        float c = clampf(v[1], 20.0f, 44100.0f / 2.0f);
-        if (!biquad_set(f.coef, filter_to_biquad(f.type), 44100, c, v[2], 0.0f)) return set_error(PG_ERR_PARAMETER, "Invalid filter parameters");
-      }
-      float c = clampf(f.coef.cutoff, 20.0f, (float)sr / 2.0f);  // initialize(): set_cutoff only
-      if (f.coef.cutoff != c) { f.coef.cutoff = c; biquad_apply(f.coef); }
-    } break;
-    case PG_FX_EQ5: {  // eq5.rs:152-170,268-294
-      PgEq5& e = fx.u.eq5;
-      for (int i = 0; i < 5; ++i) {
-        e.gains[i] = make_smooth(P[i * 3], v[i * 3], sr);
-        e.freqs[i] = make_smooth(P[i * 3 + 1], v[i * 3 + 1], sr);
-        e.bws[i] = make_smooth(P[i * 3 + 2], v[i * 3 + 2], sr);
-        memset(&e.coef[i], 0, sizeof e.coef[i]);
-        float c = clampf(e.freqs[i].current, 20.0f, (float)sr / 2.0f);
-        int bt = i == 0 ? 7 : (i == 4 ? 8 : 6);
-        if (!biquad_set(e.coef[i], bt, sr, c, e.bws[i].current, e.gains[i].current)) return set_error(PG_ERR_PARAMETER, "Invalid EQ parameters");
-      }
-    } break;
-    case PG_FX_DELAY: {  // delay.rs:273-332
-      PgDelay& d = fx.u.delay;
-      d.mode = (int)v[P_DELAY_MODE]; d.filter_type = (int)v[P_DELAY_FTYPE]; d.lfo_shape = (int)v[P_DELAY_LFO_SHAPE];
-      d.delay_time = make_smooth(P[P_DELAY_TIME], v[P_DELAY_TIME], sr);
-      d.feedback = make_smooth(P[P_DELAY_FEEDBACK], v[P_DELAY_FEEDBACK], sr);
-      d.cutoff = make_smooth(P[P_DELAY_CUTOFF], v[P_DELAY_CUTOFF], sr);
-      d.drive = make_smooth(P[P_DELAY_DRIVE], v[P_DELAY_DRIVE], sr);
-      d.wet = make_smooth(P[P_DELAY_WET], v[P_DELAY_WET], sr);
-      d.width = make_smooth(P[P_DELAY_WIDTH], v[P_DELAY_WIDTH], sr);
-      d.lfo_rate = make_smooth(P[P_DELAY_LFO_RATE], v[P_DELAY_LFO_RATE], sr);
-      d.d_time = make_smooth(P[P_DELAY_D_TIME], v[P_DELAY_D_TIME], sr);
-      d.d_feedback = make_smooth(P[P_DELAY_D_FEEDBACK], v[P_DELAY_D_FEEDBACK], sr);
-      d.d_filter = make_smooth(P[P_DELAY_D_FILTER], v[P_DELAY_D_FILTER], sr);
-      size_t max_delay_samples = (size_t)std::ceil((4000.0f + 50.0f) * (float)sr / 1000.0f);
-      size_t frames = next_pow2(max_delay_samples + 4);
-      int rc = alloc(frames * 8 * 2);
-      if (rc) return rc;
-      d.line[0] = (double*)h.d_mem; d.line[1] = d.line[0] + frames;
-      d.mask = (uint32_t)(frames - 1);
-      memset(&d.coef, 0, sizeof d.coef);
-      if (!svf_set(d.coef, d.filter_type, sr, clampf(d.cutoff.target, 20.0f, (float)sr / 2.0f), 0.302f)) return set_error(PG_ERR_PARAMETER, "Invalid delay filter");
-      d.lfo.phase = 0.0f; d.lfo.phase_inc = (float)((double)d.lfo_rate.target / (double)sr); d.lfo.waveform = d.lfo_shape;
-      for (int c = 0; c < 2; ++c) { d.dc[c].x1 = d.dc[c].y1 = 0.0; d.dc[c].r = dc_r(5.0, sr); }
-    } break;
-    case PG_FX_REVERB: {  // reverb.rs:94-151,391-407
-      PgReverb& r = fx.u.reverb;
-      r.room = make_smooth(P[0], v[0], sr);
-      r.wet = make_smooth(P[1], v[1], sr);
-      r.fpd_l = h.fpd_l; r.fpd_r = h.fpd_r;
-      static const size_t sizes[8] = {8111, 7511, 7311, 6911, 6311, 6111, 5511, 4911};
-      static const double depths[8] = {0.003251, 0.002999, 0.002917, 0.002749, 0.002503, 0.002423, 0.002146, 0.002088};
-      static const size_t apsizes[4] = {4511, 4311, 3911, 3311};
-      size_t total = 0;
-      for (int i = 0; i < 8; ++i) total += (sizes[i] + 1) * 2;
-      for (int i = 0; i < 4; ++i) total += apsizes[i] * 2;
-      total += 4096 * 2;  // DelayLine::new(3111) -> next_power_of_two
-      int rc = alloc(total * 8);
-      if (rc) return rc;
-      double* p = (double*)h.d_mem;
-      for (int i = 0; i < 8; ++i) {
-        PgReverbLine& l = r.line[i];
-        l.buf = p; p += (sizes[i] + 1) * 2;
-        l.frames = (uint32_t)(sizes[i] + 1); l.count = 1; l.delay = 1;
-        l.depth = depths[i];
-        l.vib_phase[0] = h.vib[i * 2]; l.vib_phase[1] = h.vib[i * 2 + 1];
-      }
-      for (int i = 0; i < 4; ++i) { r.ap[i].buf = p; p += apsizes[i] * 2; r.ap[i].frames = (uint32_t)apsizes[i]; r.ap[i].delay = 0; r.ap[i].write_pos = 0; }
-      r.pre = p; r.pre_mask = 4095; r.pre_write_pos = 0;
-      rc = get_vib_tab(device, &r.vib_tab);
-      if (rc) return rc;
-    } break;
-    case PG_FX_CHORUS: {  // chorus.rs:263-309
-      PgChorus& c = fx.u.chorus;
-      c.rate = make_smooth(P[P_CHORUS_RATE], v[P_CHORUS_RATE], sr);
-      c.depth = make_smooth(P[P_CHORUS_DEPTH], v[P_CHORUS_DEPTH], sr);
-      c.feedback = make_smooth(P[P_CHORUS_FEEDBACK], v[P_CHORUS_FEEDBACK], sr);
-      c.delay = make_smooth(P[P_CHORUS_DELAY], v[P_CHORUS_DELAY], sr);
-      c.wet = make_smooth(P[P_CHORUS_WET], v[P_CHORUS_WET], sr);
-      c.phase = make_smooth(P[P_CHORUS_PHASE], v[P_CHORUS_PHASE], sr);
-      c.filter_type = (int)v[P_CHORUS_FTYPE];
-      c.freq = make_smooth(P[P_CHORUS_FREQ], v[P_CHORUS_FREQ], sr);
-      c.res = make_smooth(P[P_CHORUS_RES], v[P_CHORUS_RES], sr);
-      c.lfo_range = 256.0f * ((float)sr / 44100.0f);
-      size_t max_depth = (size_t)std::ceil(c.lfo_range);
-      size_t max_delay = (size_t)std::ceil(100.0f * (float)sr / 1000.0f);
-      size_t frames = next_pow2(2 + max_delay + 2 * max_depth + 1);
-      int rc = alloc(frames * 8 * 2);
-      if (rc) return rc;
-      c.line[0] = (double*)h.d_mem; c.line[1] = c.line[0] + frames;
-      c.mask = (uint32_t)(frames - 1);
-      memset(&c.coef, 0, sizeof c.coef);
-      if (!svf_set(c.coef, c.filter_type, sr, clampf(c.freq.target, 20.0f, (float)sr / 2.0f), c.res.target)) return set_error(PG_ERR_PARAMETER, "Invalid chorus filter");
-      c.current_phase = 0.0;  // reset() :201-221
-      for (int i = 0; i < 2; ++i) { c.osc[i].phase = 0.0f; c.osc[i].waveform = 0; lfo_set_rate(c.osc[i], sr, (double)c.rate.current); }
-      lfo_set_phase_degrees(c.osc[0], (float)c.current_phase);
-      lfo_set_phase_degrees(c.osc[1], (float)(c.current_phase + (double)c.phase.current));
-    } break;
-    case PG_FX_COMPRESSOR: {  // compressor.rs:196-228
-      PgComp& c = fx.u.comp;
-      c.threshold = v[0]; c.ratio = v[1]; c.knee = v[2]; c.attack = v[3]; c.release = v[4];
-      c.makeup = make_smooth(P[5], v[5], sr);
-      c.lookahead = v[6];
-      c.env_attack = env_coeff(c.attack, sr); c.env_release = env_coeff(c.release, sr);
-      c.env_current = c.ratio >= 20.0f ? -120.0f : 0.0f;
-      size_t maxf = next_pow2((size_t)std::ceil(0.2f * (float)sr) + 1);
-      int rc = alloc(maxf * 2 * 8);
-      if (rc) return rc;
-      c.line = (double*)h.d_mem; c.line_frames = (uint32_t)maxf;
-      c.delay_frames = (uint32_t)f2u64(std::ceil(c.lookahead * (float)sr));
-      c.mask = c.delay_frames > 0 ? (uint32_t)(next_pow2(c.delay_frames) - 1) : 0;
-      c.write_pos = 0; c.peak_pos = 0; c.peak_value = 0.0;
-    } break;
-    case PG_FX_GATE: {  // gate.rs:122-145
-      PgGate& g = fx.u.gate;
-      g.threshold = v[0]; g.attack = v[1]; g.hold = v[2]; g.release = v[3]; g.range = v[4];
-      g.env_attack = env_coeff(g.attack, sr); g.env_release = env_coeff(g.release, sr);
-      g.env_current = -120.0f; g.hold_counter = 0; g.gate_gain_db = g.range;
-      g.attack_coeff = std::exp(-1.0f / (g.attack * (float)sr));
-      g.release_coeff = std::exp(-1.0f / (g.release * (float)sr));
-    } break;
-    default: {  // distortion.rs:232-256,314-324
-      PgDist& d = fx.u.dist;
-      d.type = (int)v[0];
-      d.drive = make_smooth(P[1], v[1], sr);
-      d.mix = make_smooth(P[2], v[2], sr);
-      int rc = get_dist_luts(device, &d.luts);
-      if (rc) return rc;
-    } break;
-  }
-  return PG_OK;
-}
-
-// ---- the graph --------------------------------------------------------------------------------------------
-struct Event {  // MixerEvent (src/source/mixed.rs:47-109) resolved to a device command
-  uint64_t sample_time;
-  uint64_t seq;
-  PgCmd cmd;  // unit/frame filled per launch
-  int mixer;  // owning mixer (0 = main)
-};
-
-struct HostVoice { int mixer; int dev_index; uint64_t start_time; void* d_pcm; void* d_stage; bool outer; };
-struct HostMixer {
-  int unit_slot = -1;              // sub-mixer unit; for the main mixer: the bus unit
-  std::vector<int> voices;         // voice ids in playing order (sorted by start time, insert-before-equal)
-  std::vector<int> fx;             // effect ids in chain order
-  std::vector<Event> events;       // sorted by sample_time (stable: insert after equal, event.rs:31-38)
-  std::vector<PgCmd> messages;     // StopSource messages: applied at the start of the next write
-  std::vector<Event> bus_events;   // main mixer only, defer_bus mode: effect events waiting for pg_graph_process_bus_device
-  int parent = 0;                  // Player::add_mixer(parent): 0 = the main mixer
-  int depth = 1;                   // main mixer 0, its sub-mixers 1, their sub-mixers 2 ...
-  std::vector<int> children;       // nested sub-mixers, in the order they were added
-  bool removed = false;            // Player::remove_mixer: gone from its parent (with everything under it)
-  bool remove_pending = false;     // MixerMessage::RemoveAllPendingEvents waiting for the next write (it needs that write's position)
-  uint64_t remove_event_seq = 0;   // ... it covers the events queued before it (Event::seq below this) and the sources added before it
-  size_t remove_voice_limit = 0;   //     (voice ids below this): messages are processed in order (mixed.rs:294-313), what arrives later stays
-};
-// Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
-// deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
-struct Level { int off = 0, cnt = 0, n_staged = 0, n_staged_wide = 0, n_static_defer = 0; };
-
-struct pg_graph {
-  int device = 0;
-  uint32_t sample_rate = 48000, channels = 2;
-  size_t max_frames = 4096;
-  hipStream_t stream = nullptr;
-  bool failed = false;  // sticky: GuardedSource semantics
-  int fast = 1;
-  bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
-  uint32_t fast_kind_mask = 0;  // effect kinds held by the units the fast kernels render: sizes their LDS arena (pg_fast_scratch_bytes)
-  int timing_period = 0;   // time every n-th round with a hipEvent pair (0: never, the default); pg_graph_set_timing_period creates the pairs
-  int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
-  int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
-  int n_staged_wide = 0;   // ... of level 2 (leading effects beyond Gain / Panning)
-  int n_static_defer = 0;  // graph units that always run on the generic kernel
-  double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
-  DeviceTable<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
-  DeviceTable<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
-  DeviceTable<PgUnit> d_topo;     // topology fields of every unit, patched into d_units by pg_patch_units_kernel
-  std::vector<Level> levels;    // deepest first
-  uint64_t defer_phase = 0;     // one deferral hand-shake per level launch (two counters, alternating)
-  int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
-  size_t defer_rows = 0;
-  size_t stage_rows = 0;
-  bool defer_bus = false;
-  size_t max_blocks = 1;        // blocks of max_frames one launch sequence may render (pg_graph_set_max_blocks_per_launch); sizes d_unit_out
-  size_t unit_out_blocks = 0;   // ... as allocated
-  int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
-  // host mirrors
-  std::vector<HostMixer> mixers;        // [0] = main
-  std::vector<HostVoice> voices;
-  std::vector<std::unique_ptr<HostFx>> fx;
-  std::vector<int> fx_mixer;            // effect id -> mixer id
-  std::vector<int> source_unit_of_voice;  // main-mixer voices: unit slot
-  uint64_t event_seq = 0;
-  int main_active_voices = 0;           // feedback from the device (sync write only)
-  bool ever_had_main_voice = false;
-  // device tables
-  DeviceVec<PgUnit> d_units;
-  DeviceVec<PgVoice> d_voices;
-  DeviceVec<PgFx> d_fx;
-  DeviceTable<int32_t> d_voice_index, d_fx_index, d_order;
-  // Command lists of the launch rounds: a device ring fed from a pinned host ring of the same size by asynchronous copies, one region
-  // per round. A region is reused only after PG_CMD_RING commands have gone through since the last point at which the host knew the
-  // stream to be drained (then it waits once): rounds with parameter automation neither allocate nor block.
-  PgCmd* d_cmd_ring = nullptr;
-  PgCmd* h_cmd_ring = nullptr;
-  PgCmd* d_cmd_overflow = nullptr;
-  size_t cmd_head = 0, cmds_since_sync = 0;
-  hipStream_t last_stream = nullptr;   // the stream of the last write: mutating calls drain it before they touch device tables
-  // control path (pg_ctrl.h): messages from any thread, drained at the top of write like MixedSource::process_messages
-  pgc::CtrlRing ctrl{PG_CTRL_RING};
-  pgc::ChunkTable<int8_t> fx_kind_tab;     // effect id -> kind, -1 once removed (readable from any thread)
-  pgc::ChunkTable<int8_t> voice_alive_tab; // voice id -> 1 while it can take messages
-  DeviceVec<PgSchedEntry> d_sched;       // [classes][2 banks]
-  std::map<uint32_t, int> sched_class_of_ratio;
-  uint64_t launch_counter = 0;
-  std::vector<PgUnit> h_units;          // topology part only (kind, offsets); state fields are device-owned
-  bool topo_dirty = true;
-  std::vector<int32_t> order;           // launch order: sub-mixer units, then main-mixer source units by start time
-  int n_graph_units = 0;                // units excluding bus
-  // buffers
-  float* d_unit_out = nullptr; size_t unit_out_rows = 0;
-  float* d_partial = nullptr; size_t partial_rows = 0;
-  float* d_bus = nullptr;               // [2*max_frames + 4]
-  int* d_audible = nullptr;
-  float* h_pinned = nullptr;
-  unsigned long long* h_feedback = nullptr;   // pinned, device-visible: (round << 32 | deferred units) written by the generic kernel
-  unsigned long long* d_feedback = nullptr;   // its device address
-  uint64_t last_change_round = 0;             // last round that may have left a unit out of steady state (topology, commands, mode switches)
-  uint32_t stride = 0;
-  unsigned long long* d_diag = nullptr;  // diagnostic builds
-  // timing of the dominant kernel
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  std::vector<uint32_t> ev_blocks;  // max_frames blocks the timed launch rendered (super-block launches: several)
-  size_t ev_used = 0;
-};
+hipError_t pg_malloc(void** p, size_t bytes) { g_n_alloc++; return hipMalloc(p, bytes); }
+hipError_t pg_host_malloc(void** p, size_t bytes, unsigned flags) { g_n_alloc++; return hipHostMalloc(p, bytes, flags); }
+hipError_t pg_free(void* p) { g_n_free++; return hipFree(p); }
+hipError_t pg_host_free(void* p) { g_n_free++; return hipHostFree(p); }
+hipError_t pg_stream_sync(hipStream_t s) { g_n_sync++; return hipStreamSynchronize(s); }
+hipError_t pg_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { g_n_blocking_copy++; return hipMemcpy(d, s, n, k); }
+hipError_t pg_memset(void* d, int v, size_t n) { g_n_blocking_copy++; return hipMemset(d, v, n); }
 
 static int graph_fail(pg_graph* g, int code) { g->failed = true; return code; }
 
 // Calls that change the graph (add_* / remove_* / move_* / mode switches) are not real-time calls: they first wait for everything the
 // last write enqueued — on the graph's own stream and on the caller's stream the last write used — so that no launch in flight reads a
 // table that is about to be re-uploaded, re-allocated or patched.
-static int graph_quiesce(pg_graph* g) {
+int graph_quiesce(pg_graph* g) {
   (void)hipSetDevice(g->device);
   HIP_TRY(pg_stream_sync(g->stream));
   if (g->last_stream && g->last_stream != g->stream) HIP_TRY(pg_stream_sync(g->last_stream));
@@ -578,12 +57,13 @@ __global__ void pg_patch_units_kernel(PgUnit* units, const PgUnit* topo, int n) 
   units[i].child_off = topo[i].child_off; units[i].n_children = topo[i].n_children;
   units[i].maybe_ramping = 1;  // topology changed: the generic kernel re-evaluates the steady-state condition on the next block
 }
-__global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, float* status) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int active = 0;
-    for (int i = 0; i < n; ++i) active += voices[idx[i]].active ? 1 : 0;
-    ((int*)status)[0] = active;
-  }
+// Device feedback for the "nothing left to play" early return of MixedSource::write (mixed.rs:664-670, :715): how many main-mixer sources
+// are still alive, written to a mapped host word (visible to the host once the stream has drained).
+__global__ void pg_status_kernel(const PgVoice* voices, const int32_t* idx, int n, volatile int* status) {  // one wave
+  int active = 0;
+  for (int i = threadIdx.x; i < n; i += 64) active += voices[idx[i]].active ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) active += __shfl_xor(active, off, 64);
+  if (threadIdx.x == 0) { *status = active; __threadfence_system(); }
 }
 
 static int new_unit(pg_graph* g, int kind) {
@@ -725,6 +205,10 @@ static int graph_reserve(pg_graph* g) {
     g->d_unit_out = nullptr;
     size_t nr = rows > g->unit_out_rows ? std::max(rows, g->unit_out_rows * 2) : g->unit_out_rows;
     HIP_TRY(pg_malloc((void**)&g->d_unit_out, (nr * g->stride * g->max_blocks + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
+    if (g->d_audible_tab) (void)pg_free(g->d_audible_tab);
+    g->d_audible_tab = nullptr;
+    HIP_TRY(pg_malloc((void**)&g->d_audible_tab, nr * g->max_blocks * sizeof(int32_t)));  // one `audible` word per unit row and block of a super-block
+    HIP_TRY(pg_memset(g->d_audible_tab, 0, nr * g->max_blocks * sizeof(int32_t)));
     g->unit_out_rows = nr;
     g->unit_out_blocks = g->max_blocks;
   }
@@ -770,21 +254,6 @@ int pg_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return -PG_ERR_DEVICE;
   return n;
 }
-const char* pg_effect_kind_name(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].name : nullptr; }
-int pg_effect_kind_weight(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].weight : -1; }
-int pg_effect_kind_param_count(int kind) { return (kind >= 0 && kind < PG_FX_KIND_COUNT) ? KINDS[kind].n_params : -1; }
-int pg_effect_kind_param(int kind, int index, pg_param_desc* out) {
-  if (kind < 0 || kind >= PG_FX_KIND_COUNT || index < 0 || index >= KINDS[kind].n_params) return set_error(PG_ERR_NOT_FOUND, "no such parameter");
-  const ParamSpec& p = KINDS[kind].params[index];
-  out->fourcc = p.fourcc; out->type = p.type; out->min = p.min; out->max = p.max; out->default_value = p.def;
-  out->scaling = p.scaling; out->scaling_arg0 = p.sa; out->scaling_arg1 = p.sb; out->n_values = p.n_values; out->name = p.name;
-  return PG_OK;
-}
-void pg_voice_options_default(pg_voice_options* o) {  // FilePlaybackOptions::default()  file.rs:94-112
-  memset(o, 0, sizeof *o);
-  o->volume = 1.0f; o->panning = 0.0f; o->speed = 1.0;
-  o->fade_in_seconds = 0.0f; o->fade_out_seconds = 0.05f;
-}
 
 // ---- graph --------------------------------------------------------------------------------------------------
 pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, int device) {
@@ -795,12 +264,12 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   g->device = device; g->sample_rate = sample_rate; g->channels = 2; g->max_frames = max_frames;
   g->stride = (uint32_t)(2 * max_frames);
   if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
-  if (pg_malloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || pg_malloc((void**)&g->d_audible, 16) != hipSuccess ||
+  if (pg_malloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || pg_malloc((void**)&g->d_audible, PG_AUDIBLE_SLOTS * sizeof(int)) != hipSuccess ||
       pg_host_malloc((void**)&g->h_pinned, (g->stride + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
     return nullptr;
   }
-  (void)pg_memset(g->d_audible, 0, 16);
+  (void)pg_memset(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int));
   if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     *g->h_feedback = ~0ull;  // nothing reported yet
@@ -827,6 +296,7 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->d_cmd_overflow) (void)pg_free(g->d_cmd_overflow);
   if (g->h_cmd_ring) (void)pg_host_free(g->h_cmd_ring);
   if (g->d_unit_out) (void)pg_free(g->d_unit_out);
+  if (g->d_audible_tab) (void)pg_free(g->d_audible_tab);
   if (g->d_partial) (void)pg_free(g->d_partial);
   if (g->d_stage) (void)pg_free(g->d_stage);
   if (g->d_defer) (void)pg_free(g->d_defer);
@@ -1147,18 +617,6 @@ int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // M
   return voice_message(g, voice_id, pgc::CT_VOICE_STOP, 0.0f, 0.0, sample_time);
 }
 
-// insert_event (src/utils/event.rs:31-38): sorted by sample time, after the events of the same time
-// PgCmd::value64 of a parameter update: the coefficients that follow from a new attack / release time of the Compressor's and the Gate's envelope
-// follower (EnvelopeFollower::set_attack_time / set_release_time, envelope.rs:27-42) and of the Gate's gain smoothing (gate.rs:80-90), computed here
-// with the host's expf — the same call the effect's initial state was built with, and the one the reference makes.
-static uint64_t fx_param_aux(int kind, int param, float raw, uint32_t sr) {
-  float lo = 0.0f, hi = 0.0f;
-  if (kind == PG_FX_COMPRESSOR && (param == P_COMP_ATTACK || param == P_COMP_RELEASE)) lo = env_coeff(raw, sr);
-  else if (kind == PG_FX_GATE && (param == P_GATE_ATTACK || param == P_GATE_RELEASE)) { lo = env_coeff(raw, sr); hi = std::exp(-1.0f / (raw * (float)sr)); }
-  uint32_t l, h;
-  memcpy(&l, &lo, 4); memcpy(&h, &hi, 4);
-  return (uint64_t)l | ((uint64_t)h << 32);
-}
 static void push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
   HostMixer& mx = g->mixers[mixer];
   Event e{sample_time, g->event_seq++, cmd, mixer};
@@ -1332,10 +790,12 @@ static bool graph_steady(const pg_graph* g) {
   return fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
 }
 // A super-block launch sequence renders several blocks of max_frames per workgroup: only in steady state (nobody would render the
-// later blocks of a unit that defers itself), in the single-launch kernels, and with no bus chain behind the sum (it needs the
-// `audible` result of every block).
+// later blocks of a unit that defers itself) and in the single-launch kernels. A bus chain behind the sum is no obstacle: the mixer
+// sum leaves one `audible` word per block (PgLaunch::audible_tab) and ONE bus launch walks the summed blocks in order, taking the
+// chain's per-block decisions block by block (the reference's chunk loop inside one write call, mixed.rs:679-712); the bus unit is
+// rendered by the generic kernel, which needs no steady state of its own.
 static bool graph_super_ok(const pg_graph* g) {
-  return g->max_blocks > 1 && g->staged_mode != 2 && (g->defer_bus || g->mixers[0].fx.empty()) && graph_steady(g);
+  return g->max_blocks > 1 && g->staged_mode != 2 && graph_steady(g);
 }
 
 // The command list of one round -> a fresh region of the device ring (asynchronous copy from the pinned ring on the round's stream).
@@ -1367,8 +827,10 @@ static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream
 }
 
 // One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
-// n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok().
-static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1) {
+// n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok(). The `audible` word of block c of the round goes to
+// d_audible[audible_slot + c] (the bus chain's audible_input; in defer_bus mode the caller reads the words of a whole write call).
+static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1,
+                        int audible_slot = 0) {
   const PgCmd* d_cmds = nullptr;
   if (!cmds.empty()) { int rc = stage_commands(g, cmds, stream, &d_cmds); if (rc) return rc; }
   PgLaunch L;
@@ -1405,6 +867,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     // this level's slice of the per-slot tables: launch slot b of the level = row lv.off + b
     L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
     L.unit_out = g->d_unit_out + (size_t)lv.off * g->stride;
+    L.audible_tab = g->d_audible_tab + lv.off; L.audible_stride = g->unit_out_rows;
     L.slot_info = g->d_slot_info.d + lv.off;
     if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
     g->defer_phase++;
@@ -1446,36 +909,63 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.mode = 0;
   // the main mixer sums the rows of its own sub-mixers and sources: the last level
   const Level& top = g->levels.back();
-  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_units.d, g->d_order.d + top.off, g->d_audible, stream,
+  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_audible_tab + top.off, g->unit_out_rows, g->d_audible + audible_slot, stream,
                         n_chunks, (size_t)L.chunk_stride));
   if (run_bus && !g->mixers[0].fx.empty()) {
-    PgLaunch B = L;
+    PgLaunch B = L;  // (n_chunks rides along: the generic kernel walks the summed blocks of a super-block in order)
     B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
-    B.bus = d_dst; B.bus_audible = g->d_audible;
+    B.bus = d_dst; B.bus_audible = g->d_audible + audible_slot; B.audible_tab = nullptr;
     HIP_TRY(pg_launch_units(B, stream));
   }
   return PG_OK;
 }
 
+}  // extern "C"
+
 // MixedSource::write of the main mixer (src/source/mixed.rs:659-719)
-static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream) {
+// `begin`: this call opens a write of the main mixer (process_messages first, mixed.rs:659-661). The sharded handle renders one write
+// as several calls — one per run of frames between two main-mixer events of ANY shard — and opens it itself (graph_begin_write on
+// every shard, then begin = false), so that all shards cut their rounds at the same frames as the one main mixer would.
+void graph_begin_write(pg_graph* g, uint64_t pos) {
+  drain_control_messages(g);  // process_messages (mixed.rs:294-499)
+  apply_remove_pending(g, pos);
+}
+// "Return early and avoid touching the buffer if there's nothing to do" (mixed.rs:664-670): no playing sources, no effects, no
+// sub-mixers, no events. (Sources of the main mixer that ended are dropped after the write they ended in, :715 — the host learns
+// their number from the device after every synchronous write, graph_collect_status.)
+bool graph_is_empty(const pg_graph* g) {
+  bool no_sub_mixers = true;  // self.mixers.is_empty(): sub-mixers that were removed again do not count
+  for (size_t m = 1; m < g->mixers.size(); ++m) no_sub_mixers &= g->mixers[m].removed;
+  return g->main_active_voices == 0 && g->mixers[0].fx.empty() && no_sub_mixers && g->mixers[0].events.empty();
+}
+uint64_t graph_next_main_event(const pg_graph* g) { return g->mixers[0].events.empty() ? UINT64_MAX : g->mixers[0].events.front().sample_time; }
+// The number of main-mixer sources still alive -> the graph's mapped status word, behind everything enqueued on `stream` so far;
+// graph_collect_status reads it once the stream has drained.
+int graph_enqueue_status(pg_graph* g, hipStream_t stream) {
+  if (!g->d_feedback || g->topo_dirty) return PG_OK;
+  const int n_main = (int)g->mixers[0].voices.size();  // the main-mixer voices are the last n_main entries of the voice index table
+  hipLaunchKernelGGL(pg_status_kernel, dim3(1), dim3(64), 0, stream, g->d_voices.d, g->d_voice_index.d + (g->d_voice_index.n - (size_t)n_main), n_main,
+                     (volatile int*)(g->d_feedback + 1));
+  HIP_TRY(hipGetLastError());
+  g->status_pending = true;
+  return PG_OK;
+}
+void graph_collect_status(pg_graph* g) {
+  if (!g->status_pending) return;
+  g->status_pending = false;
+  g->main_active_voices = *(volatile int*)(g->h_feedback + 1);
+}
+
+size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin) {
   if (g->failed) return 0;
   if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   (void)hipSetDevice(g->device);
   // a caller that moves from one stream to another without a graph mutation in between: the tables and rings are ordered per stream
   if (g->last_stream && g->last_stream != stream) { if (pg_stream_sync(g->last_stream) != hipSuccess) { g->failed = true; return 0; } g->cmds_since_sync = 0; }
   g->last_stream = stream;
-  drain_control_messages(g);  // process_messages (mixed.rs:294-499)
-  apply_remove_pending(g, pos);
+  if (begin) graph_begin_write(g, pos);
   if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
-  // "Return early and avoid touching the buffer if there's nothing to do" (:664-670)
-  bool any_events = false;
-  for (auto& m : g->mixers) any_events |= !m.events.empty();
-  bool main_sources_empty = g->main_active_voices == 0;
-  bool no_sub_mixers = true;  // self.mixers.is_empty(): sub-mixers that were removed again do not count
-  for (size_t m = 1; m < g->mixers.size(); ++m) no_sub_mixers &= g->mixers[m].removed;
-  if (main_sources_empty && g->mixers[0].fx.empty() && no_sub_mixers && g->mixers[0].events.empty()) return 0;
-  (void)any_events;
+  if (graph_is_empty(g)) return 0;
   const uint64_t frames = n_samples / 2;
   uint64_t done = 0;
   bool first = true;
@@ -1574,11 +1064,16 @@ static size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint
       if (t_next != UINT64_MAX && t_next < now + k * n) k = (t_next - now) / n;  // (t_next >= now + n: no command fell into this block)
       if (k < 1) k = 1;
     }
-    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds, (int)k)) { g->failed = true; return 0; }
+    // where the blocks' `audible` words go: with the bus chain deferred to the caller, word c of the call belongs to its c-th chunk (the
+    // sharded handle cuts its calls at every main-mixer event, so chunks and blocks coincide there); else the round's own words
+    const int slot = g->defer_bus ? (int)std::min<uint64_t>(done / g->max_frames, (uint64_t)PG_AUDIBLE_SLOTS - k) : 0;
+    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds, (int)k, slot)) { g->failed = true; return 0; }
     done += n * k;
   }
   return n_samples;
 }
+
+extern "C" {
 
 size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
@@ -1600,11 +1095,7 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
     size_t w = graph_write_impl(g, g->d_bus, n, pos, g->stream);
     if (w == 0) { if (g->failed) return 0; if (off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
     // device feedback: how many main-mixer sources are still alive (transient sources are dropped when exhausted, :715)
-    int n_main = (int)g->mixers[0].voices.size();  // the main-mixer voices are the last n_main entries of the voice index table
-    hipLaunchKernelGGL(pg_status_kernel, dim3(1), dim3(64), 0, g->stream, g->d_voices.d, g->d_voice_index.d + (g->d_voice_index.n - (size_t)n_main), n_main,
-                       g->d_bus + cap);
-    if (hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-        hipMemcpyAsync(g->h_pinned + cap, g->d_bus + cap, 4 * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+    if (graph_enqueue_status(g, g->stream) != PG_OK || hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         pg_stream_sync(g->stream) != hipSuccess) {
       g->failed = true;
       set_error(PG_ERR_DEVICE, "device failure in write: %s", hipGetErrorString(hipGetLastError()));
@@ -1612,14 +1103,19 @@ size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in
     }
     g->cmds_since_sync = 0;
     memcpy(out + off, g->h_pinned, n * sizeof(float));
-    g->main_active_voices = ((int*)(g->h_pinned + cap))[0];
+    graph_collect_status(g);
     off += n; pos += n / 2; total += n;
   }
   return total;
 }
 
-// `bus_audible`: device flag "the summed input is audible" (audible_input of process_effects, mixed.rs:627-655); nullptr = audible
-static int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, hipStream_t s, int* bus_audible) {
+}  // extern "C"
+
+// The main mixer's effect chain over a summed bus that the caller holds (pg_graph_process_bus_device, the sharded handle).
+// `bus_audible`: device words "the summed input of block c of this call is audible" (audible_input of process_effects, mixed.rs:627-655,
+// word c = frames [c * max_frames, +max_frames) of the call); nullptr = audible. Blocks without a bus event at their head are
+// rendered by ONE launch that walks them in order (as launch_round does behind a super-block).
+int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, hipStream_t s, int* bus_audible) {
   if (g->failed) return PG_ERR_DEVICE;
   (void)hipSetDevice(g->device);
   if (g->mixers[0].fx.empty()) return PG_OK;
@@ -1643,6 +1139,12 @@ static int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_
     if (!main.bus_events.empty()) n64 = std::min<uint64_t>(n64, main.bus_events.front().sample_time - now);
     if (n64 == 0) continue;
     const uint32_t n = (uint32_t)n64;
+    uint64_t k = 1;  // whole blocks this launch walks
+    if (cmds.empty() && n == g->max_frames) {
+      k = (frames - done) / g->max_frames;
+      if (!main.bus_events.empty()) k = std::min<uint64_t>(k, (main.bus_events.front().sample_time - now) / n);
+      k = std::max<uint64_t>(1, std::min<uint64_t>(k, PG_AUDIBLE_SLOTS));
+    }
     const PgCmd* d_cmds = nullptr;
     if (!cmds.empty()) { int rc = stage_commands(g, cmds, s, &d_cmds); if (rc) return rc; }
     PgLaunch B;
@@ -1652,446 +1154,19 @@ static int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_
     B.cmds = d_cmds; B.n_cmds = (int)cmds.size(); B.error_word = g->d_error;
     B.n_frames = n; B.pos = now; B.sample_rate = g->sample_rate; B.fast = g->fast;
     B.n_units = 1; B.unit_base = main.unit_slot;
-    B.bus = d_bus + done * 2; B.bus_audible = bus_audible;
+    B.n_chunks = (int)k;
+    B.bus = d_bus + done * 2;
+    B.bus_audible = bus_audible ? bus_audible + std::min<uint64_t>(done / g->max_frames, (uint64_t)PG_AUDIBLE_SLOTS - k) : nullptr;
     HIP_TRY(pg_launch_units(B, s));
-    done += n;
+    done += (uint64_t)n * k;
   }
   return PG_OK;
 }
+
+extern "C" {
+
 int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
   return process_bus_impl(g, d_bus, n_samples, pos_in_frames, hip_stream ? (hipStream_t)hip_stream : g->stream, nullptr);
-}
-
-// ---- voice-sharded graph: one object, n per-device graphs (SURVEY §8b `n_gpus`, §8e) ----------------------------------------------
-// The reference's only parallel axis is independent sub-mixers handed to worker threads, each rendering into a private buffer that the
-// caller sums (SubMixerThreadPool, src/source/mixed/submixer/thread_pool.rs:92-121,350-412; src/source/mixed.rs:522-536). Here the
-// workers are GPUs: every sub-mixer (with everything under it) and every main-mixer source lives on ONE shard — the least loaded one
-// when it is added, the greedy placement of WorkerTaskBatcher — state never migrates, each shard renders a partial master bus on its
-// own device and stream, the partials travel to the root device (peer copies over xGMI) and are summed there in shard order, and the
-// main mixer's effect chain runs once, on the root, behind the sum. One process, one caller thread; the measured multi-GPU path of
-// bench.py (one process per GPU, RCCL reduce) shares everything below the ABI with this one.
-__global__ void pg_shard_sum_kernel(float* __restrict__ bus, const float* __restrict__ own, const float* __restrict__ gathered, int n_peers, size_t peer_stride, int n,
-                                    const int* __restrict__ flags, int n_flags, int* __restrict__ audible_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && audible_out) { int a = 0; for (int k = 0; k < n_flags; ++k) a |= flags[k]; *audible_out = a; }
-  if (i >= n) return;
-  float acc = own[i];
-  for (int p = 0; p < n_peers; ++p) acc = acc + gathered[(size_t)p * peer_stride + i];  // shard order: deterministic
-  bus[i] = acc;
-}
-
-struct pg_sharded_graph {
-  std::vector<pg_graph*> shards;
-  std::vector<int> load;                 // sub-mixers + main-mixer sources placed on each shard
-  uint32_t sample_rate = 48000;
-  size_t max_frames = 0, max_blocks = 1, stride = 0;
-  std::vector<float*> d_partial;         // per shard, on its device: [max_blocks * stride] partial master bus
-  float* d_gather = nullptr;             // root device: the peers' partials [(n - 1)][max_blocks * stride]
-  int* d_flags = nullptr;                // root device: the shards' "audible" flags [n]
-  float* d_bus = nullptr;                // root device: the summed bus of a write with a host buffer
-  float* h_pinned = nullptr;
-  std::vector<hipEvent_t> done;          // per shard: partial (and flag) arrived on the root
-  bool failed = false;
-  // global id -> shard << 24 | local id; append-only, readable from any thread (control calls)
-  pgc::ChunkTable<int32_t> mixer_map, fx_map, voice_map;
-};
-static inline int shard_of(int32_t packed) { return (int)((uint32_t)packed >> 24); }
-static inline int local_of(int32_t packed) { return (int)((uint32_t)packed & 0xffffffu); }
-
-static int sharded_alloc_buffers(pg_sharded_graph* s) {
-  const size_t words = s->stride * s->max_blocks + 4;
-  const size_t n = s->shards.size();
-  for (size_t i = 0; i < n; ++i) {
-    HIP_TRY(hipSetDevice(s->shards[i]->device));
-    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
-    s->d_partial[i] = nullptr;
-    HIP_TRY(pg_malloc((void**)&s->d_partial[i], words * sizeof(float)));
-  }
-  HIP_TRY(hipSetDevice(s->shards[0]->device));
-  if (s->d_gather) (void)pg_free(s->d_gather);
-  if (s->d_bus) (void)pg_free(s->d_bus);
-  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
-  s->d_gather = nullptr; s->d_bus = nullptr; s->h_pinned = nullptr;
-  HIP_TRY(pg_malloc((void**)&s->d_gather, std::max<size_t>(n - 1, 1) * words * sizeof(float)));
-  HIP_TRY(pg_malloc((void**)&s->d_bus, words * sizeof(float)));
-  HIP_TRY(pg_host_malloc((void**)&s->h_pinned, words * sizeof(float), hipHostMallocDefault));
-  return PG_OK;
-}
-
-pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, const int* devices, int n_devices) {
-  if (n_devices < 1 || n_devices > 64 || !devices) { set_error(PG_ERR_PARAMETER, "1..=64 shards"); return nullptr; }
-  std::unique_ptr<pg_sharded_graph> s(new pg_sharded_graph());
-  s->sample_rate = sample_rate; s->max_frames = max_frames; s->stride = 2 * max_frames;
-  for (int i = 0; i < n_devices; ++i) {
-    pg_graph* g = pg_graph_create(sample_rate, channel_count, max_frames, devices[i]);
-    if (!g) { for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
-    g->defer_bus = true;  // the main mixer's chain runs once, behind the sum of all shards
-    s->shards.push_back(g);
-    s->load.push_back(0);
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipEventCreate failed"); for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
-    s->done.push_back(e);
-  }
-  s->d_partial.assign((size_t)n_devices, nullptr);
-  (void)hipSetDevice(devices[0]);
-  if (pg_malloc((void**)&s->d_flags, 64 * sizeof(int)) != hipSuccess || sharded_alloc_buffers(s.get())) { set_error(PG_ERR_DEVICE, "device allocation failed"); return nullptr; }
-  (void)pg_memset(s->d_flags, 0, 64 * sizeof(int));
-  s->mixer_map.append(0);  // global mixer 0 = the main mixer (its chain lives on the root shard)
-  return s.release();
-}
-void pg_sharded_destroy(pg_sharded_graph* s) {
-  if (!s) return;
-  for (size_t i = 0; i < s->shards.size(); ++i) {
-    (void)hipSetDevice(s->shards[i]->device);
-    (void)pg_stream_sync(s->shards[i]->stream);
-    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
-    (void)hipEventDestroy(s->done[i]);
-  }
-  (void)hipSetDevice(s->shards[0]->device);
-  if (s->d_gather) (void)pg_free(s->d_gather);
-  if (s->d_bus) (void)pg_free(s->d_bus);
-  if (s->d_flags) (void)pg_free(s->d_flags);
-  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
-  for (pg_graph* g : s->shards) pg_graph_destroy(g);
-  delete s;
-}
-int pg_sharded_shard_count(pg_sharded_graph* s) { return (int)s->shards.size(); }
-int pg_sharded_set_max_blocks_per_launch(pg_sharded_graph* s, int n_blocks) {
-  for (pg_graph* g : s->shards) { int rc = pg_graph_set_max_blocks_per_launch(g, n_blocks); if (rc) return rc; }
-  s->max_blocks = (size_t)n_blocks;
-  return sharded_alloc_buffers(s);
-}
-static int sharded_least_loaded(const pg_sharded_graph* s) {
-  int best = 0;
-  for (size_t i = 1; i < s->load.size(); ++i) if (s->load[i] < s->load[best]) best = (int)i;
-  return best;
-}
-static bool sharded_mixer(pg_sharded_graph* s, int mixer_id, int32_t& packed) {
-  if (mixer_id < 0 || (size_t)mixer_id >= s->mixer_map.size()) { set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id); return false; }
-  packed = s->mixer_map.get((size_t)mixer_id);
-  return true;
-}
-int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id) {
-  int32_t pk;
-  if (!sharded_mixer(s, parent_mixer_id, pk)) return -PG_ERR_NOT_FOUND;
-  const int shard = parent_mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);  // a nested sub-mixer lives with its parent
-  const int local = pg_graph_add_mixer_to(s->shards[shard], parent_mixer_id == 0 ? 0 : local_of(pk));
-  if (local < 0) return local;
-  if (parent_mixer_id == 0) s->load[shard] += 1;
-  const int id = (int)s->mixer_map.size();
-  if (local > 0xffffff || !s->mixer_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many mixers");
-  return id;
-}
-int pg_sharded_add_mixer(pg_sharded_graph* s) { return pg_sharded_add_mixer_to(s, 0); }
-int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init) {
-  int32_t pk;
-  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
-  const int shard = mixer_id == 0 ? 0 : shard_of(pk);  // main-mixer effects: the bus chain on the root
-  const int local = pg_graph_add_effect(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), kind, init);
-  if (local < 0) return local;
-  const int id = (int)s->fx_map.size();
-  if (local > 0xffffff || !s->fx_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many effects");
-  return id;
-}
-int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate, const pg_voice_options* opt) {
-  int32_t pk;
-  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
-  const int shard = mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);
-  const int local = pg_graph_add_voice(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), pcm, n_frames, src_channels, src_rate, opt);
-  if (local < 0) return local;
-  if (mixer_id == 0) s->load[shard] += 1;
-  const int id = (int)s->voice_map.size();
-  if (local > 0xffffff || !s->voice_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many voices");
-  return id;
-}
-int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id) {
-  int32_t pk;
-  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
-  return mixer_id == 0 ? 0 : shard_of(pk);
-}
-// control calls (any thread): routed to the owning shard's message ring
-#define SHARDED_FX(s, effect_id, pk) \
-  if ((effect_id) < 0 || (size_t)(effect_id) >= (s)->fx_map.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", (effect_id)); \
-  const int32_t pk = (s)->fx_map.get((size_t)(effect_id))
-#define SHARDED_VOICE(s, voice_id, pk) \
-  if ((voice_id) < 0 || (size_t)(voice_id) >= (s)->voice_map.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", (voice_id)); \
-  const int32_t pk = (s)->voice_map.get((size_t)(voice_id))
-int pg_sharded_schedule_param(pg_sharded_graph* s, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
-  SHARDED_FX(s, effect_id, pk);
-  return pg_graph_schedule_param(s->shards[shard_of(pk)], local_of(pk), fourcc, value, is_normalized, sample_time);
-}
-int pg_sharded_schedule_reset(pg_sharded_graph* s, int effect_id, uint64_t sample_time) {
-  SHARDED_FX(s, effect_id, pk);
-  return pg_graph_schedule_reset(s->shards[shard_of(pk)], local_of(pk), sample_time);
-}
-int pg_sharded_set_voice_volume(pg_sharded_graph* s, int voice_id, float volume, uint64_t sample_time) {
-  SHARDED_VOICE(s, voice_id, pk);
-  return pg_graph_set_voice_volume(s->shards[shard_of(pk)], local_of(pk), volume, sample_time);
-}
-int pg_sharded_set_voice_panning(pg_sharded_graph* s, int voice_id, float panning, uint64_t sample_time) {
-  SHARDED_VOICE(s, voice_id, pk);
-  return pg_graph_set_voice_panning(s->shards[shard_of(pk)], local_of(pk), panning, sample_time);
-}
-int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time) {
-  SHARDED_VOICE(s, voice_id, pk);
-  return pg_graph_stop_voice(s->shards[shard_of(pk)], local_of(pk), sample_time);
-}
-int pg_sharded_stop_all_voices(pg_sharded_graph* s) {
-  for (pg_graph* g : s->shards) { int rc = pg_graph_stop_all_voices(g); if (rc) return rc; }
-  return PG_OK;
-}
-
-// Source::write of the sharded main mixer: n asynchronous renders, partials -> root, sum in shard order, bus chain, result in d_out
-// (root device) on the root shard's stream. Returns the samples written, 0 when every shard is empty and the main mixer has no chain.
-static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos) {
-  if (s->failed) return 0;
-  const size_t cap = s->stride * s->max_blocks;
-  if (n_samples > cap || n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "a sharded write holds at most max_blocks x max_frames stereo frames"); return 0; }
-  const size_t n = s->shards.size();
-  pg_graph* root = s->shards[0];
-  bool any = false;
-  for (size_t i = 0; i < n; ++i) {
-    pg_graph* g = s->shards[i];
-    (void)hipSetDevice(g->device);
-    const size_t w = graph_write_impl(g, s->d_partial[i], n_samples, pos, g->stream);
-    if (g->failed) { s->failed = true; return 0; }
-    if (w == 0) { if (hipMemsetAsync(s->d_partial[i], 0, n_samples * sizeof(float), g->stream) != hipSuccess) { s->failed = true; return 0; } }
-    else any = true;
-    if (i > 0) {  // partial bus and the shard's `audible` flag -> the root device; the root's stream waits for their arrival only
-      if (hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4), root->device, s->d_partial[i], g->device, n_samples * sizeof(float), g->stream) != hipSuccess ||
-          hipMemcpyPeerAsync(s->d_flags + i, root->device, g->d_audible, g->device, sizeof(int), g->stream) != hipSuccess ||
-          hipEventRecord(s->done[i], g->stream) != hipSuccess) { s->failed = true; return 0; }
-    }
-  }
-  if (!any && root->mixers[0].fx.empty()) return 0;
-  (void)hipSetDevice(root->device);
-  for (size_t i = 1; i < n; ++i) if (hipStreamWaitEvent(root->stream, s->done[i], 0) != hipSuccess) { s->failed = true; return 0; }
-  if (hipMemcpyAsync(s->d_flags, root->d_audible, sizeof(int), hipMemcpyDeviceToDevice, root->stream) != hipSuccess) { s->failed = true; return 0; }
-  hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_out, s->d_partial[0], s->d_gather, (int)n - 1, cap + 4,
-                     (int)n_samples, s->d_flags, (int)n, root->d_audible);
-  if (hipGetLastError() != hipSuccess) { s->failed = true; return 0; }
-  if (process_bus_impl(root, d_out, n_samples, pos, root->stream, root->d_audible)) { s->failed = true; return 0; }
-  return n_samples;
-}
-size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames) { return sharded_write_impl(s, d_out, n_samples, pos_in_frames); }
-int pg_sharded_synchronize(pg_sharded_graph* s) {
-  for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); HIP_TRY(pg_stream_sync(g->stream)); g->cmds_since_sync = 0; }
-  return PG_OK;
-}
-size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames) {
-  const size_t cap = s->stride * s->max_blocks;
-  size_t off = 0, total = 0;
-  uint64_t pos = pos_in_frames;
-  while (off < n_samples) {
-    const size_t n = std::min(cap, n_samples - off);
-    const size_t w = sharded_write_impl(s, s->d_bus, n, pos);
-    if (w == 0) { if (s->failed || off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
-    pg_graph* root = s->shards[0];
-    (void)hipSetDevice(root->device);
-    if (hipMemcpyAsync(s->h_pinned, s->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, root->stream) != hipSuccess || pg_sharded_synchronize(s) != PG_OK) { s->failed = true; return 0; }
-    memcpy(out + off, s->h_pinned, n * sizeof(float));
-    off += n; pos += n / 2; total += n;
-  }
-  return total;
-}
-int pg_sharded_device_errors(pg_sharded_graph* s) {
-  int e = 0;
-  for (pg_graph* g : s->shards) { const int r = pg_graph_device_errors(g); if (r < 0) return r; e |= r; }
-  return e;
-}
-
-// ---- standalone effect: a one-unit graph whose unit is UNIT_EFFECT -------------------------------------------
-struct pg_effect {
-  int kind = 0, device = 0;
-  HostFx host;
-  bool initialized = false;
-  uint32_t sample_rate = 0;
-  size_t max_frames = 0;
-  hipStream_t stream = nullptr;
-  PgUnit* d_unit = nullptr;
-  PgFx* d_fx = nullptr;
-  int32_t* d_fx_index = nullptr;
-  PgCmd* d_cmds = nullptr;
-  float* d_buf = nullptr;
-  int32_t* d_idx_log = nullptr;  // test hook (pg_effect_debug_index_log)
-  size_t idx_log_words = 0;
-  std::vector<PgCmd> pending;
-  size_t cmd_cap = 64;           // commands d_cmds holds
-};
-
-pg_effect* pg_effect_create(int kind, const pg_effect_init* init, int device) {
-  std::unique_ptr<pg_effect> e(new pg_effect());
-  e->kind = kind; e->device = device;
-  if (host_fx_from_init(kind, init, e->host)) return nullptr;
-  return e.release();
-}
-void pg_effect_destroy(pg_effect* e) {
-  if (!e) return;
-  if (e->initialized) {
-    (void)hipSetDevice(e->device);
-    (void)pg_stream_sync(e->stream);
-    (void)pg_free(e->d_unit); (void)pg_free(e->d_fx); (void)pg_free(e->d_fx_index); (void)pg_free(e->d_cmds); (void)pg_free(e->d_buf);
-    if (e->host.d_mem) (void)pg_free(e->host.d_mem);
-    if (e->d_idx_log) (void)pg_free(e->d_idx_log);
-    (void)hipStreamDestroy(e->stream);
-  }
-  delete e;
-}
-int pg_effect_initialize(pg_effect* e, uint32_t sample_rate, size_t channel_count, size_t max_frames) {
-  if (e->initialized) return set_error(PG_ERR_STATE, "effect is already initialized");
-  if (channel_count != 2) return set_error(PG_ERR_PARAMETER, "%sEffect only supports stereo I/O", KINDS[e->kind].name);
-  if (sample_rate == 0 || max_frames == 0 || max_frames > PG_MAX_FRAMES) return set_error(PG_ERR_PARAMETER, "max_frames must be in 1..=%d", PG_MAX_FRAMES);
-  HIP_TRY(hipSetDevice(e->device));
-  PgFx fx;
-  int rc = build_fx_device_state(e->host, sample_rate, e->device, true, fx);
-  if (rc) return rc;
-  HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  PgUnit u;
-  memset(&u, 0, sizeof u);
-  u.kind = UNIT_EFFECT; u.n_fx = 1; u.fx_off = 0; u.effects_bypassed = 0;
-  int32_t zero = 0;
-  HIP_TRY(pg_malloc((void**)&e->d_unit, sizeof u));
-  HIP_TRY(pg_malloc((void**)&e->d_fx, sizeof fx));
-  HIP_TRY(pg_malloc((void**)&e->d_fx_index, 4));
-  HIP_TRY(pg_malloc((void**)&e->d_cmds, sizeof(PgCmd) * 64));
-  e->cmd_cap = 64;
-  HIP_TRY(pg_malloc((void**)&e->d_buf, max_frames * 2 * sizeof(float)));
-  HIP_TRY(pg_memcpy(e->d_unit, &u, sizeof u, hipMemcpyHostToDevice));
-  HIP_TRY(pg_memcpy(e->d_fx, &fx, sizeof fx, hipMemcpyHostToDevice));
-  HIP_TRY(pg_memcpy(e->d_fx_index, &zero, 4, hipMemcpyHostToDevice));
-  e->sample_rate = sample_rate; e->max_frames = max_frames; e->initialized = true;
-  return PG_OK;
-}
-// Test hook: collect the floor()-derived read indices of the effect's delay lines during the following process calls (time-parallel
-// paths of Reverb: ((frame * 8 + line) * 2 + channel) -> read_1 of ReverbDelayLine::get; Delay / Chorus: (frame * 2 + channel) ->
-// read_idx1 of InterpolatedDelayLine::process), `words` slots, -1 = not written. out == nullptr: (re)arm the log; else copy it out.
-int pg_effect_debug_index_log(pg_effect* e, int32_t* out, size_t words) {
-  if (!e->initialized) return set_error(PG_ERR_STATE, "effect is not initialized");
-  HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(pg_stream_sync(e->stream));
-  if (!out) {
-    if (words > e->idx_log_words) {
-      if (e->d_idx_log) (void)pg_free(e->d_idx_log);
-      e->d_idx_log = nullptr;
-      HIP_TRY(pg_malloc((void**)&e->d_idx_log, words * sizeof(int32_t)));
-      e->idx_log_words = words;
-    }
-    if (e->d_idx_log) HIP_TRY(pg_memset(e->d_idx_log, 0xff, e->idx_log_words * sizeof(int32_t)));
-    return PG_OK;
-  }
-  if (!e->d_idx_log || words > e->idx_log_words) return set_error(PG_ERR_PARAMETER, "index log is not armed for %zu words", words);
-  HIP_TRY(pg_memcpy(out, e->d_idx_log, words * sizeof(int32_t), hipMemcpyDeviceToHost));
-  return PG_OK;
-}
-int pg_effect_process_started(pg_effect*) { return PG_OK; }  // no-ops for all stock effects (src/effect.rs:127-139)
-int pg_effect_process_stopped(pg_effect*) { return PG_OK; }
-
-// room for one more queued command (a launch applies commands at the head of the frames it renders, so a launch of no frames cannot flush them:
-// the queue grows instead)
-static int effect_reserve_cmd(pg_effect* e) {
-  if (e->pending.size() < e->cmd_cap) return PG_OK;
-  HIP_TRY(hipSetDevice(e->device));
-  PgCmd* bigger = nullptr;
-  HIP_TRY(pg_malloc((void**)&bigger, sizeof(PgCmd) * e->cmd_cap * 2));
-  HIP_TRY(pg_stream_sync(e->stream));
-  (void)pg_free(e->d_cmds);
-  e->d_cmds = bigger;
-  e->cmd_cap *= 2;
-  return PG_OK;
-}
-static int effect_run(pg_effect* e, float* host_buf, size_t n_samples, uint64_t pos) {
-  HIP_TRY(hipSetDevice(e->device));
-  if (n_samples) HIP_TRY(hipMemcpyAsync(e->d_buf, host_buf, n_samples * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  if (!e->pending.empty()) HIP_TRY(hipMemcpyAsync(e->d_cmds, e->pending.data(), e->pending.size() * sizeof(PgCmd), hipMemcpyHostToDevice, e->stream));
-  PgLaunch L;
-  memset(&L, 0, sizeof L);
-  L.units = e->d_unit; L.fx = e->d_fx; L.fx_index = e->d_fx_index;
-  L.cmds = e->d_cmds; L.n_cmds = (int)e->pending.size();
-  L.n_units = 1; L.unit_base = 0; L.n_frames = (uint32_t)(n_samples / 2); L.pos = pos; L.sample_rate = e->sample_rate; L.fast = 1;
-  L.bus = e->d_buf;
-  L.index_log = e->d_idx_log;
-  HIP_TRY(pg_launch_units(L, e->stream));
-  if (n_samples) HIP_TRY(hipMemcpyAsync(host_buf, e->d_buf, n_samples * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(pg_stream_sync(e->stream));
-  e->pending.clear();
-  return PG_OK;
-}
-int pg_effect_process(pg_effect* e, float* interleaved, size_t n_samples, uint64_t pos_in_frames) {
-  if (!e->initialized) return set_error(PG_ERR_STATE, "effect is not initialized");
-  if (n_samples % 2 != 0 || n_samples / 2 > e->max_frames) return set_error(PG_ERR_PARAMETER, "buffer must hold <= max_frames stereo frames");
-  if (n_samples == 0) return PG_OK;  // nothing to render: parameter updates and messages received so far stay queued, in order, for the next call that does
-  return effect_run(e, interleaved, n_samples, pos_in_frames);
-}
-int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_normalized) {
-  int pi = find_param(e->kind, fourcc);
-  if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[e->kind].name);
-  float raw;
-  if (!resolve_update(KINDS[e->kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;
-  if (e->kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
-    return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
-  e->host.target[pi] = raw;
-  if (!e->initialized) { e->host.init_raw[pi] = raw; return PG_OK; }  // before initialize: plain value update
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_FX_PARAM; c.unit = 0; c.target = 0; c.param = pi; c.value = raw; c.frame = 0; c.value64 = fx_param_aux(e->kind, pi, raw, e->sample_rate);
-  int rc = effect_reserve_cmd(e);
-  if (rc) return rc;
-  e->pending.push_back(c);
-  return PG_OK;
-}
-int pg_effect_message_reset(pg_effect* e) {
-  if (e->kind != PG_FX_DELAY && e->kind != PG_FX_REVERB && e->kind != PG_FX_CHORUS)
-    return set_error(PG_ERR_PARAMETER, "%sEffect: Invalid/unknown message payload", KINDS[e->kind].name);
-  if (!e->initialized) return PG_OK;
-  PgCmd c;
-  memset(&c, 0, sizeof c);
-  c.type = CMD_FX_RESET; c.unit = 0; c.target = 0;
-  int rc = effect_reserve_cmd(e);
-  if (rc) return rc;
-  e->pending.push_back(c);
-  return PG_OK;
-}
-int64_t pg_effect_tail(pg_effect* e) {  // Effect::process_tail from the target values (host shadow)
-  const std::vector<float>& t = e->host.target;
-  double sr = (double)e->sample_rate;
-  switch (e->kind) {
-    case PG_FX_GAIN: { int m = (int)t[1]; return m == 0 ? 0 : (int64_t)((uint64_t)e->sample_rate / (uint64_t)(m == 1 ? 1 : (m == 2 ? 5 : 20))); }
-    case PG_FX_PANNING: return 0;
-    case PG_FX_FILTER: return e->sample_rate / 10;
-    case PG_FX_EQ5: return e->sample_rate / 5;
-    case PG_FX_DELAY: {
-      if (t[P_DELAY_DRIVE] > 0.0f) return -1;
-      double delay_ms = (double)(t[P_DELAY_TIME] + 50.0f);
-      double fb = (double)std::fabs(t[P_DELAY_FEEDBACK]);
-      if (fb >= 0.9999) return INT64_MAX;
-      if (fb < 0.001) return (int64_t)d2u64(std::ceil(delay_ms * sr / 1000.0));
-      double ds = delay_ms * sr / 1000.0;
-      return (int64_t)std::max<uint64_t>(d2u64(std::ceil(ds + ds * std::log10(0.001) / std::log10(fb))), 1);
-    }
-    case PG_FX_REVERB: {
-      double rs = (double)t[0];
-      double size = (rs * rs * 75.0) + 25.0;
-      uint64_t max_delay = d2u64(79.0 * size);
-      double tt = 1.0 - (0.82 - (((1.0 - rs) * 0.7) + (size * 0.002)));
-      double fb = 1.0 - (tt * tt) * (tt * tt);
-      if (fb >= 1.0) return INT64_MAX;
-      if (fb == 0.0) return (int64_t)max_delay;
-      return (int64_t)(max_delay + d2u64((double)max_delay * std::log10(0.001) / std::log10(fb)));
-    }
-    case PG_FX_CHORUS: {
-      float srf = (float)e->sample_rate;
-      float total_ms = t[P_CHORUS_DELAY] + 256.0f * 1000.0f / srf;
-      float fb = std::fabs(t[P_CHORUS_FEEDBACK]);
-      if (fb >= 1.0f) return INT64_MAX;
-      if (fb < 0.001f) return (int64_t)f2u64(std::ceil(total_ms * srf / 1000.0f));
-      float total = total_ms * srf / 1000.0f;
-      float decay = total + (float)((double)total * std::log10(0.001) / std::log10((double)fb));
-      return (int64_t)f2u64(std::ceil(decay));
-    }
-    case PG_FX_COMPRESSOR: return (int64_t)(f2u64(std::ceil(t[P_COMP_LOOKAHEAD] * (float)e->sample_rate)) + f2u64(std::ceil(t[P_COMP_RELEASE] * (float)e->sample_rate)));
-    case PG_FX_GATE: return (int64_t)(f2u64(std::ceil(t[P_GATE_HOLD] * (float)e->sample_rate)) + f2u64(std::ceil(t[P_GATE_RELEASE] * (float)e->sample_rate)));
-    default: return 0;
-  }
 }
 
 }  // extern "C"

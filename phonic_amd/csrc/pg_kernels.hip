@@ -373,7 +373,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   if (FAST_ONLY && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
   bool fx0_fresh = FAST_ONLY && unit.n_fx > 0;  // the generic kernel applies commands to the global copy first
   const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
-  float* ext = L.bus;
+  float* ext = L.bus + (size_t)chunk * 2 * (size_t)N;  // (a bus launch behind a super-block: block c of the summed bus)
   if (external) {
     for (int i = tid; i < 2 * N; i += nt) sig[i] = ext[i];
   } else {
@@ -429,7 +429,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     const uint64_t pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)frame0;
     bool audible_input;
     if (external) {
-      audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (*L.bus_audible != 0) : true);
+      audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[chunk] != 0) : true);
     } else {
       audible_input = false;
       if (!FAST_ONLY && unit.n_children > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
@@ -501,10 +501,11 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     if (tid == 0) {
       unit.audible = (int)(call_mask & 1ull);  // the first call; later calls of the round (nested sub-mixers only) in call_audible
       if (!FAST_ONLY) unit.call_audible = call_mask;
+      if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = call_mask != 0 ? 1 : 0;  // (mixers of the main mixer are never split by an ancestor: one call)
     }
   } else {
     for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
-    if (tid == 0) unit.audible = any_audible ? 1 : 0;
+    if (tid == 0) { unit.audible = any_audible ? 1 : 0; if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = any_audible ? 1 : 0; }
   }
   PG_STAMP(L.diag, 15);
   // schedule cache: representatives replay the next block's resampler schedule (piece = this launch's length, capped)
@@ -557,9 +558,14 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
     }
     return;
   }
+  // n_chunks > 1 reaches this kernel only as the bus launch behind a super-block (the host renders steady-state graphs that way): the
+  // chain runs over the summed blocks one after the other, every per-block decision (audible_input, bypass, tails) taken per block
+  const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
   for (int slot = (int)blockIdx.x; slot < L.n_units; slot += (int)gridDim.x) {
-    pg_unit_body<false, PG_KMASK_ALL>(L, slot);
-    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+      pg_unit_body<false, PG_KMASK_ALL>(L, slot, c);
+      __syncthreads();
+    }
   }
 }
 
@@ -797,6 +803,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
     } else { unit.silence_counter = 0; audible = 1; }
     unit.audible = audible;
+    if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = audible;
     ctl[3] = audible;
   }
   __syncthreads();
@@ -931,12 +938,12 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_1(const float* __restrict__ 
   *(float4*)(partial + (size_t)g * stride + (size_t)s4 * 4) = acc;
 }
 __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ partial, uint32_t stride, int n_groups, float* __restrict__ bus, int n_samples,
-                                                      const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int n_units,
+                                                      const int32_t* __restrict__ audible_row, int n_units,
                                                       int* __restrict__ audible_out) {
   int s4 = blockIdx.x * blockDim.x + pg_tid();
-  if (blockIdx.x == gridDim.x - 1 && audible_out) {  // the extra last block: OR of the units' audible flags (wave reduction)
+  if (blockIdx.x == gridDim.x - 1 && audible_out) {  // the extra last block: OR of the units' audible flags of this block (wave reduction)
     int a = 0;
-    for (int u = pg_tid(); u < n_units; u += 64) a |= units[order[u]].audible;
+    for (int u = pg_tid(); u < n_units; u += 64) a |= audible_row[u];
     for (int off = 32; off > 0; off >>= 1) a |= __shfl_xor(a, off, 64);
     if (pg_tid() == 0) *audible_out = a;
     return;
@@ -959,7 +966,7 @@ __global__ void __launch_bounds__(64) pg_mix_kernel_2(const float* __restrict__ 
 #define PG_MIX_MAX_GROUPS 256
 #define PG_MIX_COLS 4
 __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ unit_out, uint32_t stride, int n_units, int n_groups, float* __restrict__ bus,
-                                                      int n_samples, const PgUnit* __restrict__ units, const int32_t* __restrict__ order, int* __restrict__ audible_out,
+                                                      int n_samples, const int32_t* __restrict__ audible_tab, size_t audible_stride, int* __restrict__ audible_out,
                                                       size_t chunk_stride) {
   // super-block launches: blockIdx.y = block of the super-block (its unit rows chunk_stride floats further, its bus n_samples further)
   unit_out += (size_t)blockIdx.y * chunk_stride;
@@ -967,13 +974,14 @@ __global__ void __launch_bounds__(256) pg_mix_kernel(const float* __restrict__ u
   const int n_vec4 = (n_samples + 3) / 4;
   __shared__ float4 part[PG_MIX_MAX_GROUPS][PG_MIX_COLS];
   const int t = pg_tid();
-  if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags (two dependent loads per unit: all 256
-    if (!audible_out || blockIdx.y + 1 != gridDim.y) return;  // lanes take part so that few of those trips follow one another)
+  if (blockIdx.x == gridDim.x - 1) {  // the extra last block: OR of the units' audible flags of block blockIdx.y -> audible_out[blockIdx.y]
+    if (!audible_out) return;
+    const int32_t* row = audible_tab + (size_t)blockIdx.y * audible_stride;
     int a = 0;
 #pragma unroll 4
-    for (int u = t; u < n_units; u += 256) a |= units[order[u]].audible;
+    for (int u = t; u < n_units; u += 256) a |= row[u];
     a = __syncthreads_or(a);
-    if (t == 0) *audible_out = a;
+    if (t == 0) audible_out[blockIdx.y] = a;
     return;
   }
   const int col = t & (PG_MIX_COLS - 1), sub = t / PG_MIX_COLS;  // 64 sub-groups
@@ -1077,22 +1085,22 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0
   else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   return hipGetLastError();
 }
-hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const PgUnit* units,
-                         const int32_t* order, int* audible_out, hipStream_t stream, int n_chunks, size_t chunk_stride) {
+hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
+                         size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks, size_t chunk_stride) {
   int n_vec4 = (int)((n_samples + 3) / 4);
   int group = 16;
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
   if (n_chunks < 1) n_chunks = 1;
   if (n_groups <= PG_MIX_MAX_GROUPS) {
-    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, units, order,
-                       audible_out, chunk_stride);
+    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, audible_tab,
+                       audible_stride, audible_out, chunk_stride);
     return hipGetLastError();
   }
   dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
   for (int c = 0; c < n_chunks; ++c) {  // (the partials buffer holds one block: the launches of consecutive blocks follow each other in stream order)
     hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out + (size_t)c * chunk_stride, stride, n_units, group, partial, n_vec4);
-    hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus + (size_t)c * n_samples, (int)n_samples, units, order, n_units, c + 1 == n_chunks ? audible_out : nullptr);
+    hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus + (size_t)c * n_samples, (int)n_samples, audible_tab + (size_t)c * audible_stride, n_units, audible_out ? audible_out + c : nullptr);
   }
   return hipGetLastError();
 }

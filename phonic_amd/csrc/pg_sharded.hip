@@ -1,0 +1,426 @@
+// ---- voice-sharded graph: one object, n per-device graphs (SURVEY §8b `n_gpus`, §8e) ----------------------------------------------
+// The reference's only parallel axis is independent sub-mixers handed to worker threads, each rendering into a private buffer that the
+// caller sums (SubMixerThreadPool, src/source/mixed/submixer/thread_pool.rs:92-121,350-412; src/source/mixed.rs:522-536). Here the
+// workers are GPUs: every sub-mixer (with everything under it) and every main-mixer source lives on ONE shard — the least loaded one
+// when it is added, the greedy placement of WorkerTaskBatcher — state never migrates, each shard renders a partial master bus on its
+// own device and stream, the partials meet on the root device and the main mixer's effect chain runs once, on the root, behind the
+// sum. Two ways for the partials to meet (pg_sharded_set_reduce): peer copies + a sum kernel in shard order (default, deterministic),
+// or an RCCL ncclReduce(sum) over xGMI on the shards' own streams. One process, one caller thread; the measured multi-GPU path of
+// bench.py (one process per GPU, RCCL reduce through torch.distributed) shares everything below the ABI with this one.
+//
+// The handle is the ONE main MixedSource: every call the reference's mixer takes is routed to the shard that owns its target
+// (src/source/mixed.rs:124-145,163-178,422-462), a write is cut at the main mixer's event times of ALL shards (so every shard splits
+// its chunks where the one mixer would, mixed.rs:679-712), the bus chain sees one `audible` word per chunk, OR-ed over the shards
+// (process_effects, mixed.rs:627-655), and write returns 0 exactly when the one mixer would (mixed.rs:664-670).
+#include "pg_host_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the entry points are looked up at run time (pg_sharded_set_reduce), the library does not link RCCL
+
+// bus[i] = own[i] + sum of the peers' partials in shard order; audible_out[c] = OR over the shards of their flag for chunk c
+__global__ void pg_shard_sum_kernel(float* __restrict__ bus, const float* __restrict__ own, const float* __restrict__ gathered, int n_peers, size_t peer_stride, int n,
+                                    const int* __restrict__ flags, int n_shards, int n_chunks, int* __restrict__ audible_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_chunks && audible_out) {
+    int a = 0;
+    for (int k = 0; k < n_shards; ++k) a |= flags[k * PG_AUDIBLE_SLOTS + (int)threadIdx.x];
+    audible_out[threadIdx.x] = a;
+  }
+  if (i >= n) return;
+  float acc = own[i];
+  for (int p = 0; p < n_peers; ++p) acc = acc + gathered[(size_t)p * peer_stride + i];  // shard order: deterministic
+  bus[i] = acc;
+}
+
+// RCCL entry points, resolved from the RCCL the process already holds (soname librccl.so.1: the one PyTorch bundles when the host is
+// Python) or from the ROCm installation on the library's run path
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static std::mutex g_rccl_mutex;
+static RcclApi g_rccl;
+static int rccl_load() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (g_rccl.handle) return PG_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return set_error(PG_ERR_DEVICE, "RCCL is not available: %s", dlerror());
+  RcclApi a;
+  a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+  a.Reduce = (decltype(a.Reduce))dlsym(h, "ncclReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Reduce || !a.GetErrorString) { dlclose(h); return set_error(PG_ERR_DEVICE, "RCCL lacks an entry point"); }
+  a.handle = h;
+  g_rccl = a;
+  return PG_OK;
+}
+
+struct pg_sharded_graph {
+  std::vector<pg_graph*> shards;
+  std::vector<int> load;                 // sub-mixers + main-mixer sources placed on each shard
+  uint32_t sample_rate = 48000;
+  size_t max_frames = 0, max_blocks = 1, stride = 0;
+  std::vector<float*> d_partial;         // per shard, on its device: [max_blocks * stride] partial master bus
+  float* d_gather = nullptr;             // root device: the peers' partials [(n - 1)][max_blocks * stride]
+  int* d_flags = nullptr;                // root device: the shards' `audible` words [n][PG_AUDIBLE_SLOTS] of the segment being summed
+  float* d_bus = nullptr;                // root device: the summed bus of a write with a host buffer
+  float* h_pinned = nullptr;
+  std::vector<hipEvent_t> done;          // per shard: partial (and flags) arrived on the root
+  hipEvent_t summed = nullptr;           // root: the sum kernel has read d_gather / d_flags (the peers' next copies wait for it)
+  bool summed_recorded = false;
+  bool failed = false;
+  int reduce_mode = PG_REDUCE_PEER_COPY;
+  std::vector<ncclComm_t> comms;         // PG_REDUCE_RCCL: one communicator per shard (ncclCommInitAll over the shards' devices)
+  // global id -> shard << 24 | local id; append-only, readable from any thread (control calls)
+  pgc::ChunkTable<int32_t> mixer_map, fx_map, voice_map;
+};
+static inline int shard_of(int32_t packed) { return (int)((uint32_t)packed >> 24); }
+static inline int local_of(int32_t packed) { return (int)((uint32_t)packed & 0xffffffu); }
+
+static int sharded_alloc_buffers(pg_sharded_graph* s) {
+  const size_t words = s->stride * s->max_blocks + 4;
+  const size_t n = s->shards.size();
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(hipSetDevice(s->shards[i]->device));
+    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
+    s->d_partial[i] = nullptr;
+    HIP_TRY(pg_malloc((void**)&s->d_partial[i], words * sizeof(float)));
+  }
+  HIP_TRY(hipSetDevice(s->shards[0]->device));
+  if (s->d_gather) (void)pg_free(s->d_gather);
+  if (s->d_bus) (void)pg_free(s->d_bus);
+  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
+  s->d_gather = nullptr; s->d_bus = nullptr; s->h_pinned = nullptr;
+  HIP_TRY(pg_malloc((void**)&s->d_gather, std::max<size_t>(n - 1, 1) * words * sizeof(float)));
+  HIP_TRY(pg_malloc((void**)&s->d_bus, words * sizeof(float)));
+  HIP_TRY(pg_host_malloc((void**)&s->h_pinned, words * sizeof(float), hipHostMallocDefault));
+  return PG_OK;
+}
+static void sharded_drop_comms(pg_sharded_graph* s) {
+  for (ncclComm_t c : s->comms) if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+  s->comms.clear();
+}
+static int sharded_wait_all(pg_sharded_graph* s) {
+  for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); HIP_TRY(pg_stream_sync(g->stream)); g->cmds_since_sync = 0; }
+  return PG_OK;
+}
+
+extern "C" {
+
+pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, const int* devices, int n_devices) {
+  if (n_devices < 1 || n_devices > 64 || !devices) { set_error(PG_ERR_PARAMETER, "1..=64 shards"); return nullptr; }
+  std::unique_ptr<pg_sharded_graph> s(new pg_sharded_graph());
+  s->sample_rate = sample_rate; s->max_frames = max_frames; s->stride = 2 * max_frames;
+  for (int i = 0; i < n_devices; ++i) {
+    pg_graph* g = pg_graph_create(sample_rate, channel_count, max_frames, devices[i]);
+    if (!g) { for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
+    g->defer_bus = true;  // the main mixer's chain runs once, behind the sum of all shards
+    s->shards.push_back(g);
+    s->load.push_back(0);
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipEventCreate failed"); for (pg_graph* h : s->shards) pg_graph_destroy(h); return nullptr; }
+    s->done.push_back(e);
+  }
+  s->d_partial.assign((size_t)n_devices, nullptr);
+  (void)hipSetDevice(devices[0]);
+  const size_t flag_bytes = (size_t)n_devices * PG_AUDIBLE_SLOTS * sizeof(int);
+  if (hipEventCreateWithFlags(&s->summed, hipEventDisableTiming) != hipSuccess || pg_malloc((void**)&s->d_flags, flag_bytes) != hipSuccess || sharded_alloc_buffers(s.get())) {
+    set_error(PG_ERR_DEVICE, "device allocation failed");
+    return nullptr;
+  }
+  (void)pg_memset(s->d_flags, 0, flag_bytes);
+  s->mixer_map.append(0);  // global mixer 0 = the main mixer (its chain lives on the root shard)
+  return s.release();
+}
+void pg_sharded_destroy(pg_sharded_graph* s) {
+  if (!s) return;
+  (void)sharded_wait_all(s);
+  sharded_drop_comms(s);
+  for (size_t i = 0; i < s->shards.size(); ++i) {
+    (void)hipSetDevice(s->shards[i]->device);
+    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
+    (void)hipEventDestroy(s->done[i]);
+  }
+  (void)hipSetDevice(s->shards[0]->device);
+  if (s->summed) (void)hipEventDestroy(s->summed);
+  if (s->d_gather) (void)pg_free(s->d_gather);
+  if (s->d_bus) (void)pg_free(s->d_bus);
+  if (s->d_flags) (void)pg_free(s->d_flags);
+  if (s->h_pinned) (void)pg_host_free(s->h_pinned);
+  for (pg_graph* g : s->shards) pg_graph_destroy(g);
+  delete s;
+}
+int pg_sharded_shard_count(pg_sharded_graph* s) { return (int)s->shards.size(); }
+int pg_sharded_set_max_blocks_per_launch(pg_sharded_graph* s, int n_blocks) {
+  { int rc = sharded_wait_all(s); if (rc) return rc; }
+  for (pg_graph* g : s->shards) { int rc = pg_graph_set_max_blocks_per_launch(g, n_blocks); if (rc) return rc; }
+  s->max_blocks = (size_t)n_blocks;
+  return sharded_alloc_buffers(s);
+}
+// How the partial buses meet on the root. PG_REDUCE_RCCL creates one communicator per shard (ncclCommInitAll over the shards' devices:
+// every device may then be listed once only) and fails with PG_ERR_DEVICE + the RCCL error text when that is impossible — the mode
+// stays what it was; there is no silent fallback.
+int pg_sharded_set_reduce(pg_sharded_graph* s, int mode) {
+  if (mode != PG_REDUCE_PEER_COPY && mode != PG_REDUCE_RCCL) return set_error(PG_ERR_PARAMETER, "unknown reduce mode %d", mode);
+  if (mode == s->reduce_mode) return PG_OK;
+  { int rc = sharded_wait_all(s); if (rc) return rc; }
+  if (mode == PG_REDUCE_PEER_COPY) { sharded_drop_comms(s); s->reduce_mode = mode; return PG_OK; }
+  { int rc = rccl_load(); if (rc) return rc; }
+  std::vector<int> devs;
+  for (pg_graph* g : s->shards) devs.push_back(g->device);
+  for (size_t i = 0; i < devs.size(); ++i) for (size_t j = i + 1; j < devs.size(); ++j)
+    if (devs[i] == devs[j]) return set_error(PG_ERR_PARAMETER, "PG_REDUCE_RCCL needs one device per shard (device %d is listed twice)", devs[i]);
+  std::vector<ncclComm_t> comms(devs.size(), nullptr);
+  const ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+  if (r != ncclSuccess) return set_error(PG_ERR_DEVICE, "ncclCommInitAll over %d device(s) failed: %s", (int)devs.size(), g_rccl.GetErrorString(r));
+  s->comms = comms;
+  s->reduce_mode = mode;
+  return PG_OK;
+}
+int pg_sharded_reduce_mode(pg_sharded_graph* s) { return s->reduce_mode; }
+
+static int sharded_least_loaded(const pg_sharded_graph* s) {
+  int best = 0;
+  for (size_t i = 1; i < s->load.size(); ++i) if (s->load[i] < s->load[best]) best = (int)i;
+  return best;
+}
+static bool sharded_mixer(pg_sharded_graph* s, int mixer_id, int32_t& packed) {
+  if (mixer_id < 0 || (size_t)mixer_id >= s->mixer_map.size()) { set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id); return false; }
+  packed = s->mixer_map.get((size_t)mixer_id);
+  return true;
+}
+int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id) {
+  int32_t pk;
+  if (!sharded_mixer(s, parent_mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = parent_mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);  // a nested sub-mixer lives with its parent
+  const int local = pg_graph_add_mixer_to(s->shards[shard], parent_mixer_id == 0 ? 0 : local_of(pk));
+  if (local < 0) return local;
+  if (parent_mixer_id == 0) s->load[shard] += 1;
+  const int id = (int)s->mixer_map.size();
+  if (local > 0xffffff || !s->mixer_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many mixers");
+  return id;
+}
+int pg_sharded_add_mixer(pg_sharded_graph* s) { return pg_sharded_add_mixer_to(s, 0); }
+int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = mixer_id == 0 ? 0 : shard_of(pk);  // main-mixer effects: the bus chain on the root
+  const int local = pg_graph_add_effect(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), kind, init);
+  if (local < 0) return local;
+  const int id = (int)s->fx_map.size();
+  if (local > 0xffffff || !s->fx_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many effects");
+  return id;
+}
+int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate, const pg_voice_options* opt) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);
+  const int local = pg_graph_add_voice(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), pcm, n_frames, src_channels, src_rate, opt);
+  if (local < 0) return local;
+  if (mixer_id == 0) s->load[shard] += 1;
+  const int id = (int)s->voice_map.size();
+  if (local > 0xffffff || !s->voice_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many voices");
+  return id;
+}
+int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  return mixer_id == 0 ? 0 : shard_of(pk);
+}
+// Player::remove_mixer / remove_effect / move_effect (src/player.rs:825-867,942-990 -> MixerMessage::RemoveMixer / RemoveEffect / MoveEffect,
+// src/source/mixed.rs:422-462) on the shard that owns the target; ids stay global and are never reused.
+int pg_sharded_remove_mixer(pg_sharded_graph* s, int mixer_id) {
+  if (mixer_id == 0) return set_error(PG_ERR_PARAMETER, "Cannot remove the main mixer");
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return PG_ERR_NOT_FOUND;
+  pg_graph* g = s->shards[shard_of(pk)];
+  const int local = local_of(pk);
+  const bool top_level = local > 0 && local < (int)g->mixers.size() && !g->mixers[local].removed && g->mixers[local].parent == 0;
+  const int rc = pg_graph_remove_mixer(g, local);
+  if (rc == PG_OK && top_level && s->load[shard_of(pk)] > 0) s->load[shard_of(pk)] -= 1;  // the shard has room for the next sub-mixer again
+  return rc;
+}
+int pg_sharded_remove_effect(pg_sharded_graph* s, int effect_id) {
+  if (effect_id < 0 || (size_t)effect_id >= s->fx_map.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  const int32_t pk = s->fx_map.get((size_t)effect_id);
+  return pg_graph_remove_effect(s->shards[shard_of(pk)], local_of(pk));
+}
+int pg_sharded_move_effect(pg_sharded_graph* s, int effect_id, int mixer_id, int movement, int offset) {
+  if (effect_id < 0 || (size_t)effect_id >= s->fx_map.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", effect_id);
+  int32_t mk;
+  if (!sharded_mixer(s, mixer_id, mk)) return PG_ERR_NOT_FOUND;
+  const int32_t pk = s->fx_map.get((size_t)effect_id);
+  const int m_shard = mixer_id == 0 ? 0 : shard_of(mk), m_local = mixer_id == 0 ? 0 : local_of(mk);
+  if (m_shard != shard_of(pk)) return set_error(PG_ERR_PARAMETER, "Effect %d does not belong to mixer %d", effect_id, mixer_id);
+  return pg_graph_move_effect(s->shards[m_shard], local_of(pk), m_local, movement, offset);
+}
+// control calls (any thread): routed to the owning shard's message ring
+#define SHARDED_FX(s, effect_id, pk) \
+  if ((effect_id) < 0 || (size_t)(effect_id) >= (s)->fx_map.size()) return set_error(PG_ERR_NOT_FOUND, "Effect with id %d not found", (effect_id)); \
+  const int32_t pk = (s)->fx_map.get((size_t)(effect_id))
+#define SHARDED_VOICE(s, voice_id, pk) \
+  if ((voice_id) < 0 || (size_t)(voice_id) >= (s)->voice_map.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", (voice_id)); \
+  const int32_t pk = (s)->voice_map.get((size_t)(voice_id))
+int pg_sharded_schedule_param(pg_sharded_graph* s, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
+  SHARDED_FX(s, effect_id, pk);
+  return pg_graph_schedule_param(s->shards[shard_of(pk)], local_of(pk), fourcc, value, is_normalized, sample_time);
+}
+int pg_sharded_schedule_reset(pg_sharded_graph* s, int effect_id, uint64_t sample_time) {
+  SHARDED_FX(s, effect_id, pk);
+  return pg_graph_schedule_reset(s->shards[shard_of(pk)], local_of(pk), sample_time);
+}
+int pg_sharded_set_voice_volume(pg_sharded_graph* s, int voice_id, float volume, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_set_voice_volume(s->shards[shard_of(pk)], local_of(pk), volume, sample_time);
+}
+int pg_sharded_set_voice_panning(pg_sharded_graph* s, int voice_id, float panning, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_set_voice_panning(s->shards[shard_of(pk)], local_of(pk), panning, sample_time);
+}
+int pg_sharded_set_voice_speed(pg_sharded_graph* s, int voice_id, double speed, float glide_semitones_per_second, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_set_voice_speed(s->shards[shard_of(pk)], local_of(pk), speed, glide_semitones_per_second, sample_time);
+}
+int pg_sharded_seek_voice(pg_sharded_graph* s, int voice_id, double position_seconds, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_seek_voice(s->shards[shard_of(pk)], local_of(pk), position_seconds, sample_time);
+}
+int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_stop_voice(s->shards[shard_of(pk)], local_of(pk), sample_time);
+}
+int pg_sharded_stop_all_voices(pg_sharded_graph* s) {
+  for (pg_graph* g : s->shards) { int rc = pg_graph_stop_all_voices(g); if (rc) return rc; }
+  return PG_OK;
+}
+int pg_sharded_is_voice_playing(pg_sharded_graph* s, int voice_id) {
+  if (voice_id < 0 || (size_t)voice_id >= s->voice_map.size()) return 0;
+  const int32_t pk = s->voice_map.get((size_t)voice_id);
+  return pg_graph_is_voice_playing(s->shards[shard_of(pk)], local_of(pk));
+}
+
+}  // extern "C"
+
+// One segment of a write: frames without a main-mixer event of any shard inside. Every shard renders its partial bus (asynchronously, on
+// its own device and stream) and its `audible` words, one per chunk of max_frames; partials and words meet on the root; the bus chain
+// runs behind the sum with the OR-ed words.
+static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_samples, size_t n_samples, uint64_t pos) {
+  const size_t cap = s->stride * s->max_blocks;
+  const size_t n = s->shards.size();
+  pg_graph* root = s->shards[0];
+  const int n_chunks = (int)std::min<size_t>((n_samples / 2 + s->max_frames - 1) / s->max_frames, PG_AUDIBLE_SLOTS);
+  const bool rccl = s->reduce_mode == PG_REDUCE_RCCL;
+  for (size_t i = 0; i < n; ++i) {
+    pg_graph* g = s->shards[i];
+    HIP_TRY(hipSetDevice(g->device));
+    float* part = s->d_partial[i] + off_samples;
+    const size_t w = graph_write_impl(g, part, n_samples, pos, g->stream, false);
+    if (g->failed) return PG_ERR_DEVICE;
+    if (w == 0) {  // nothing on this shard: a silent partial and silent flags (not the words an earlier call left there)
+      HIP_TRY(hipMemsetAsync(part, 0, n_samples * sizeof(float), g->stream));
+      HIP_TRY(hipMemsetAsync(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int), g->stream));
+    }
+    if (rccl) continue;
+    // the root's sum of the previous segment (or call) must have read the gather buffers before this shard overwrites them
+    if (s->summed_recorded) HIP_TRY(hipStreamWaitEvent(g->stream, s->summed, 0));
+    if (i > 0) {
+      HIP_TRY(hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4) + off_samples, root->device, part, g->device, n_samples * sizeof(float), g->stream));
+      HIP_TRY(hipMemcpyPeerAsync(s->d_flags + i * PG_AUDIBLE_SLOTS, root->device, g->d_audible, g->device, (size_t)n_chunks * sizeof(int), g->stream));
+      HIP_TRY(hipEventRecord(s->done[i], g->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(s->d_flags, g->d_audible, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, g->stream));
+    }
+  }
+  HIP_TRY(hipSetDevice(root->device));
+  if (rccl) {
+    // ncclReduce(sum) of the partial buses and ncclReduce(max) of the `audible` words (0 / 1: max = OR), root = shard 0, every shard's
+    // operation on its own stream behind its render; the root's stream then holds the summed bus and the words
+    ncclResult_t r = g_rccl.GroupStart();
+    for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+      pg_graph* g = s->shards[i];
+      r = g_rccl.Reduce(s->d_partial[i] + off_samples, i == 0 ? d_out + off_samples : nullptr, n_samples, ncclFloat32, ncclSum, 0, s->comms[i], g->stream);
+      if (r == ncclSuccess) r = g_rccl.Reduce(g->d_audible, i == 0 ? (void*)s->d_flags : nullptr, (size_t)n_chunks, ncclInt32, ncclMax, 0, s->comms[i], g->stream);
+    }
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return set_error(PG_ERR_DEVICE, "ncclReduce of the master bus failed: %s", g_rccl.GetErrorString(r));
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(hipMemcpyAsync(root->d_audible, s->d_flags, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, root->stream));
+  } else {
+    for (size_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root->stream, s->done[i], 0));
+    hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_out + off_samples, s->d_partial[0] + off_samples,
+                       s->d_gather + off_samples, (int)n - 1, cap + 4, (int)n_samples, s->d_flags, (int)n, n_chunks, root->d_audible);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->summed, root->stream));
+    s->summed_recorded = true;
+  }
+  return process_bus_impl(root, d_out + off_samples, n_samples, pos, root->stream, root->d_audible);
+}
+
+// Source::write of the sharded main mixer, result in d_out (root device) on the root shard's stream. Returns the samples written, 0
+// when the one main mixer would return 0: no playing source, no sub-mixer and no pending event on any shard, and no effect on mixer 0.
+static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos) {
+  if (s->failed) return 0;
+  const size_t cap = s->stride * s->max_blocks;
+  if (n_samples > cap || n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "a sharded write holds at most max_blocks x max_frames stereo frames"); return 0; }
+  // process_messages of the one mixer: every shard takes its messages now, none later in this call
+  bool empty = true;
+  for (pg_graph* g : s->shards) {
+    if (g->failed) { s->failed = true; return 0; }
+    graph_begin_write(g, pos);
+    empty &= graph_is_empty(g);
+  }
+  if (empty) return 0;
+  const uint64_t frames = n_samples / 2;
+  uint64_t done = 0;
+  while (done < frames) {
+    // the segment ends where the next main-mixer event of any shard comes due (events at or before `now` apply at the segment's head)
+    const uint64_t now = pos + done;
+    uint64_t n = frames - done;
+    for (pg_graph* g : s->shards)
+      for (const Event& e : g->mixers[0].events) { if (e.sample_time > now) { n = std::min<uint64_t>(n, e.sample_time - now); break; } }
+    if (sharded_render_segment(s, d_out, (size_t)done * 2, (size_t)n * 2, now)) { s->failed = true; return 0; }
+    done += n;
+  }
+  return n_samples;
+}
+
+extern "C" {
+
+size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames) { return sharded_write_impl(s, d_out, n_samples, pos_in_frames); }
+int pg_sharded_synchronize(pg_sharded_graph* s) { return sharded_wait_all(s); }
+size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames) {
+  const size_t cap = s->stride * s->max_blocks;
+  size_t off = 0, total = 0;
+  uint64_t pos = pos_in_frames;
+  while (off < n_samples) {
+    const size_t n = std::min(cap, n_samples - off);
+    const size_t w = sharded_write_impl(s, s->d_bus, n, pos);
+    if (w == 0) { if (s->failed || off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
+    pg_graph* root = s->shards[0];
+    // device feedback per shard: how many of its main-mixer sources are still alive (transient sources are dropped when exhausted, mixed.rs:715)
+    for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); if (graph_enqueue_status(g, g->stream) != PG_OK) { s->failed = true; return 0; } }
+    (void)hipSetDevice(root->device);
+    if (hipMemcpyAsync(s->h_pinned, s->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, root->stream) != hipSuccess || sharded_wait_all(s) != PG_OK) { s->failed = true; return 0; }
+    for (pg_graph* g : s->shards) graph_collect_status(g);
+    memcpy(out + off, s->h_pinned, n * sizeof(float));
+    off += n; pos += n / 2; total += n;
+  }
+  return total;
+}
+int pg_sharded_device_errors(pg_sharded_graph* s) {
+  int e = 0;
+  for (pg_graph* g : s->shards) { const int r = pg_graph_device_errors(g); if (r < 0) return r; e |= r; }
+  return e;
+}
+
+}  // extern "C"

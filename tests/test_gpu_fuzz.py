@@ -190,8 +190,12 @@ def test_random_graph_on_three_shards(seed):
 
     plan = make_plan(seed)
     g = ShardedGraph([0, 0, 0], SR, 2, 1024)
-    a = render_plan(plan, g, mutations=False)
-    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024), mutations=False)
+    if seed % 2:   # odd seeds: whole-block calls of one to four blocks rendered as super-blocks (bus decisions per block, flags OR-ed over the shards)
+        rng = np.random.default_rng(13000 + seed)
+        plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+        g.set_max_blocks_per_launch(4)
+    a = render_plan(plan, g)                                     # chain mutations (move_effect / remove_effect) included; the oracle gets the same calls and
+    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))      # walks them in chunks of its 1024-frame mix buffer, counted from every event, like the device
     assert np.isfinite(a).all() and g.device_errors() == 0
     if float(np.abs(b).max()) <= 1e-4:
         assert float(np.abs(a).max()) <= 1e-4

@@ -896,6 +896,66 @@ def test_superblock_launch_is_bit_identical_to_single_blocks():
     assert np.abs(sup[-2 * N:]).max() > 1e-3
 
 
+@pytest.mark.parametrize("bus", ["limiter", "eq5_reverb"])
+def test_superblock_launch_with_a_bus_chain_is_bit_identical_to_single_blocks(bus):
+    """Super-block launches for graphs whose MAIN mixer has effects (BASELINE configs 2 and 4): the mixer sum of all blocks is one launch
+    (grid.y = blocks, one `audible` word per block) and ONE bus launch walks the summed blocks in order, taking the chain's per-block
+    decisions — audible_input, bypass, tails (src/source/mixed.rs:627-655) — block by block, as MixedSource::write does with its chunks
+    inside one call (mixed.rs:679-712). Bit-identical to the block-by-block pull: one-shot voices end inside a call, the chain rings
+    out, bypasses itself and wakes up again when a late voice starts; a bus parameter event splits a call."""
+    from phonic_amd.graph import Graph
+
+    N, per_call, calls = 1024, 8, 14
+
+    def build(g):
+        for i in range(6):
+            g.add_voice(0, workloads.tone_buffer(i, 44100, 0.3 + 0.05 * i), 2, 44100, volume=0.3, panning=workloads.voice_pan(i))      # one-shots, 14-26 blocks long
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_FILTER, params={"cuto": 3000.0})
+        g.add_voice(m, workloads.tone_buffer(9, 48000, 0.2), 2, 48000, volume=0.4)
+        g.add_voice(0, workloads.tone_buffer(20, 48000, 0.1), 2, 48000, volume=0.5, start_time=(9 * per_call + 3) * N + 5)     # late: wakes the chain up
+        if bus == "limiter":
+            return [g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -32.0, "rato": 20.0, "knee": 0.0, "gain": 0.0, "look": 0.01, "rels": 0.1})]
+        return [g.add_effect(0, _capi.FX_EQ5, params={"gan2": 3.0}), g.add_effect(0, _capi.FX_REVERB, params={"room": 0.15}, reverb_seeds=workloads.reverb_seeds(5))]
+
+    outs, stats = [], []
+    for mode in ("single", "super", "oracle"):
+        g = oracle.OracleGraph(SR, 2, N) if mode == "oracle" else Graph(SR, 2, N, 0)
+        if mode == "super":
+            g.set_max_blocks_per_launch(per_call)
+        if mode != "oracle":
+            g.set_timing_period(1)
+        ids = build(g)
+        chunks, pos = [], 0
+        warm = np.zeros(2 * 2 * N, np.float32)
+        assert g.write(warm, pos) == warm.size
+        chunks.append(warm)
+        pos += 2 * N
+        if mode != "oracle":
+            g.kernel_stats(reset=True)
+        for c in range(calls):
+            if c == 1:
+                g.schedule_param(ids[0], "thrs" if bus == "limiter" else "gan4", -9.0, pos + 2 * N + 300)
+            o = np.zeros(per_call * 2 * N, np.float32)
+            assert g.write(o, pos) in (0, o.size)
+            chunks.append(o)
+            pos += per_call * N
+        outs.append(np.concatenate(chunks))
+        if mode != "oracle":
+            _, launches, blocks = g.kernel_stats(reset=True)
+            stats.append((launches, blocks))
+            assert g.device_errors() == 0
+    single, sup, ref = outs
+    assert np.array_equal(single, sup), int(np.count_nonzero(single != sup))
+    compare(sup, ref)
+    assert stats[0][1] == stats[0][0]                 # one block per launch
+    assert stats[1][1] > 2 * stats[1][0]              # super-block launches carried most blocks
+    per_block = np.abs(ref.reshape(-1, 2 * N)).max(axis=1)
+    assert per_block[5] > 1e-2 and per_block[60:75].max() < 1e-5 and per_block[76] > 1e-3      # audible, rung out, woken up again by the late voice
+    if bus == "limiter":
+        assert (per_block[60:75] == 0.0).all()                                                    # (the limiter's known tail is over: the chain is bypassed)
+
+
 def test_write_allocates_nothing_and_never_blocks_on_a_callers_stream():
     """The reference runs its audio callback under assert_no_alloc (src/output/cpal.rs:712-715). Here: all device / pinned allocations
     happen in the graph-changing calls (grow-by-doubling in add_*), the topology tables travel with asynchronous copies from pinned
@@ -1065,21 +1125,25 @@ def test_control_calls_from_another_thread_while_rendering():
 @pytest.mark.parametrize("n_shards", [1, 3])
 def test_sharded_graph_object_matches_the_single_graph(n_shards):
     """pg_sharded_*: ONE handle that owns a graph per device and renders the main mixer as n partial buses + a sum on the root + the
-    bus chain (the C-ABI form of the multi-GPU path; with 1-GPU boxes every shard sits on device 0). Same build / automation calls as
-    the plain graph: per-voice chains on sub-mixers (placed on the least loaded shard), plain main-mixer sources, a nested sub-mixer
-    (must land on its parent's shard), a bus chain with a limiter (non-linear: the sum must happen before it), parameter events on a
-    sub-mixer effect, on a bus effect and on voices, a stop, and a super-block write. Checked against the oracle and against the
-    unsharded graph (f32 order of the voice sum differs)."""
+    bus chain (the C-ABI form of the multi-GPU path; with 1-GPU boxes every shard sits on device 0). The handle takes every call the
+    plain graph takes (the reference's MixerMessage set, src/source/mixed.rs:124-145,163-178,422-462): per-voice chains on sub-mixers
+    (placed on the least loaded shard), plain main-mixer sources, a nested sub-mixer (must land on its parent's shard), a bus chain with
+    a limiter (non-linear: the sum must happen before it), parameter events on a sub-mixer effect, on a bus effect and on voices, a stop,
+    set_speed with a glide, seek, move_effect on a sub-mixer chain and on the bus chain, remove_effect, remove_mixer (with the ids under
+    it). Main-mixer events of one shard must cut the chunks of ALL shards (the per-call logic of the other shards' sub-mixers sees the
+    same calls as in the one mixer). Checked against the oracle and against the unsharded graph (f32 order of the voice sum differs)."""
     from phonic_amd.graph import Graph, ShardedGraph
+    import phonic_amd
 
-    N, blocks = 1024, 10
+    N, blocks = 1024, 14
 
     def build(g):
-        ids = {"fx": [], "v": []}
+        ids = {"fx": [], "rv": [], "v": [], "m": []}
         for i in range(7):
             m = g.add_mixer()
+            ids["m"].append(m)
             ids["fx"].append(g.add_effect(m, _capi.FX_FILTER, params={"cuto": 1500.0 + 300 * i}))
-            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            ids["rv"].append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i)))
             ids["v"].append(g.add_voice(m, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.3, panning=workloads.voice_pan(i), has_repeat=1,
                                         repeat=_capi.PG_REPEAT_FOREVER))
             if i == 2:
@@ -1090,17 +1154,29 @@ def test_sharded_graph_object_matches_the_single_graph(n_shards):
         for i in range(4):
             ids["v"].append(g.add_voice(0, workloads.tone_buffer(10 + i, 48000, 0.2), 2, 48000, volume=0.2, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
         ids["eq"] = g.add_effect(0, _capi.FX_EQ5, params={"gan2": 4.0})
-        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -20.0, "rato": 20.0, "knee": 0.0, "gain": 0.0, "look": 0.02})
+        ids["lim"] = g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -20.0, "rato": 20.0, "knee": 0.0, "gain": 0.0, "look": 0.02})
         return ids
 
     def automate(g, ids, b, pos):
         if b == 3:
             g.schedule_param(ids["fx"][1], "cuto", 500.0, pos + 300)
             g.schedule_param(ids["eq"], "gan4", -9.0, pos + 600)
-            g.set_voice_volume(ids["v"][8], 0.05, pos + 100)
+            g.set_voice_volume(ids["v"][8], 0.05, pos + 100)      # a main-mixer source: its event cuts every shard's chunk
             g.set_voice_panning(ids["v"][0], 0.9, pos + 900)
+        if b == 5:
+            g.set_voice_speed(ids["v"][1], 1.5, pos + 128, glide=24.0)
+            g.set_voice_speed(ids["v"][7], 0.75, pos + 700)          # a main-mixer source, immediate
+            g.seek_voice(ids["v"][3], 0.05, pos + 512)
         if b == 6:
             g.stop_voice(ids["v"][9], pos + 200)
+        if b == 7:
+            g.move_effect(ids["rv"][4], ids["m"][4], _capi.MOVE_START)       # Reverb in front of the Filter
+            g.move_effect(ids["lim"], 0, _capi.MOVE_DIRECTION, -1)           # the bus chain: limiter in front of the Eq5
+        if b == 9:
+            g.remove_effect(ids["fx"][5])
+            g.remove_mixer(ids["nested"][0])                                  # with its nested sub-mixer
+        if b == 11:
+            g.remove_effect(ids["eq"])
 
     outs = []
     for mode in ("sharded", "single", "oracle"):
@@ -1118,12 +1194,166 @@ def test_sharded_graph_object_matches_the_single_graph(n_shards):
         outs.append(o.reshape(-1))
         if mode == "sharded":
             assert g.device_errors() == 0
-            with pytest.raises(Exception):
-                g.schedule_param(9999, "cuto", 100.0, 0)
+            assert g.is_voice_playing(ids["v"][0]) and not g.is_voice_playing(ids["v"][9])
+            for call in (lambda: g.schedule_param(9999, "cuto", 100.0, 0), lambda: g.remove_mixer(ids["nested"][0]), lambda: g.remove_mixer(ids["nested"][1]),
+                         lambda: g.remove_effect(ids["fx"][5]), lambda: g.add_effect(ids["nested"][1], _capi.FX_GAIN), lambda: g.set_voice_speed(9999, 1.0, 0),
+                         lambda: g.seek_voice(9999, 0.0, 0)):
+                with pytest.raises(phonic_amd.PhonicError) as ei:
+                    call()
+                assert ei.value.code == _capi.PG_ERR_NOT_FOUND
+            with pytest.raises(phonic_amd.PhonicError) as ei:
+                g.remove_mixer(0)
+            assert ei.value.code == _capi.PG_ERR_PARAMETER
+            with pytest.raises(phonic_amd.PhonicError) as ei:      # an effect of another mixer
+                g.move_effect(ids["rv"][0], ids["m"][1], _capi.MOVE_END)
+            assert ei.value.code == _capi.PG_ERR_PARAMETER
     compare(outs[0], outs[2])
     compare(outs[1], outs[2])
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5
     assert np.abs(outs[0]).max() > 1e-2
+
+
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_sharded_superblock_write_takes_the_bus_decisions_per_block(n_shards):
+    """A sharded write that spans several blocks (pg_sharded_set_max_blocks_per_launch): the bus chain behind the sum must see ONE
+    `audible_input` per block (process_effects, src/source/mixed.rs:627-655,696-706), OR-ed over the shards — not one word for the whole
+    call. One-shot voices end in the second block of a four-block call; the bus chain (Gain -> Delay with a known tail) must run over
+    the audible blocks, count its tail down from the first silent one and bypass itself when the tail is over, exactly as the oracle
+    rendering the same calls. An empty shard must contribute silence and a clear flag, not what an earlier call left in its buffers."""
+    from phonic_amd.graph import ShardedGraph
+
+    N, per_call, calls = 1024, 4, 15
+
+    def build(g):
+        ids = []
+        for i in range(4):   # main-mixer one-shots, spread over the shards: ~1.4 blocks long, starting in call 2 (a source's `audible` ends with it; a
+            ids.append(g.add_voice(0, workloads.tone_buffer(i, 48000, 0.03), 2, 48000, volume=0.5, start_time=2 * per_call * N))   # sub-mixer's only 2 s later)
+        g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.8})
+        g.add_effect(0, _capi.FX_DELAY, params={"dlay": 30.0, "fdbk": 0.3, "wet_": 0.6})
+        return ids
+
+    outs = []
+    for mode in ("sharded", "oracle"):
+        g = ShardedGraph([0] * n_shards, SR, 2, N) if mode == "sharded" else oracle.OracleGraph(SR, 2, N)
+        if mode == "sharded":
+            g.set_max_blocks_per_launch(per_call)
+        build(g)
+        o = np.zeros((calls, per_call * 2 * N), np.float32)
+        for c in range(calls):
+            assert g.write(o[c], c * per_call * N) == o[c].size
+        outs.append(o.reshape(-1))
+        if mode == "sharded":
+            assert g.device_errors() == 0
+    compare(outs[0], outs[1])
+    audible = outs[1].reshape(calls * per_call, -1)
+    assert np.abs(audible[2 * per_call + 1]).max() > 1e-2          # the voices play in blocks 8-9 ...
+    assert np.abs(audible[2 * per_call + 3]).max() > 1e-4          # ... the delay's repeats ring on in the silent blocks of the same call
+    assert np.abs(audible[-1]).max() == 0.0                        # ... and the chain has bypassed itself at the end
+
+
+def test_sharded_write_returns_zero_when_the_main_mixer_has_nothing_left():
+    """MixedSource::write returns 0 without touching the buffer when there is no playing source, no effect, no sub-mixer and no event
+    (src/source/mixed.rs:664-670); exhausted transient sources are dropped after the write they ended in (:715). The sharded handle
+    must do the same as the plain graph, call for call: main-mixer one-shot sources spread over three shards, then a sub-mixer that is
+    removed again."""
+    from phonic_amd.graph import Graph, ShardedGraph
+
+    N = 512
+    rets = []
+    for mode in ("sharded", "single", "oracle"):
+        g = ShardedGraph([0, 0, 0], SR, 2, N) if mode == "sharded" else (Graph(SR, 2, N, 0) if mode == "single" else oracle.OracleGraph(SR, 2, N))
+        r, pos = [], 0
+        buf = np.full(2 * N, 7.0, np.float32)
+        r.append(g.write(buf, pos)); assert buf[0] == 7.0      # empty graph: 0, buffer untouched
+        for i in range(4):
+            g.add_voice(0, workloads.tone_buffer(i, 48000, 0.01 + 0.004 * i), 2, 48000, volume=0.4, fade_out_seconds=-1.0)
+        for b in range(6):
+            buf[:] = 7.0
+            r.append(g.write(buf, pos)); pos += N
+        assert buf[0] == 7.0                                    # the last call found nothing to do
+        m = g.add_mixer()
+        r.append(g.write(buf, pos)); pos += N                  # a sub-mixer: the main mixer is not empty
+        g.remove_mixer(m)
+        buf[:] = 7.0
+        r.append(g.write(buf, pos)); pos += N
+        assert buf[0] == 7.0
+        rets.append(r)
+    assert rets[0] == rets[1] == rets[2], rets
+    assert rets[2][0] == 0 and rets[2][1] == 2 * N and rets[2][6] == 0 and rets[2][7] == 2 * N and rets[2][8] == 0
+
+
+def test_sharded_asynchronous_writes_back_to_back():
+    """pg_sharded_write_device is asynchronous: several calls may be enqueued before one pg_sharded_synchronize. The peers' copies of
+    call k + 1 into the root's gather buffers must wait for the root's sum of call k (round-2 advisor finding: a write-after-read race
+    on d_gather / d_flags). 40 calls in flight on three shards against the same render taken one synchronous call at a time."""
+    import torch
+    from phonic_amd.graph import ShardedGraph
+
+    N, per_call, calls = 1024, 2, 40
+
+    def build(g):
+        for i in range(9):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.1), 2, 44100, volume=0.3, panning=workloads.voice_pan(i), has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -24.0, "rato": 20.0, "knee": 0.0, "gain": 0.0})
+
+    a = ShardedGraph([0, 0, 0], SR, 2, N); a.set_max_blocks_per_launch(per_call); build(a)
+    b = ShardedGraph([0, 0, 0], SR, 2, N); b.set_max_blocks_per_launch(per_call); build(b)
+    d = torch.zeros((calls, per_call * 2 * N), dtype=torch.float32, device="cuda:0")
+    for c in range(calls):
+        assert a.write_device(d[c].data_ptr(), per_call * 2 * N, c * per_call * N) == per_call * 2 * N
+    a.synchronize()
+    ref = np.zeros((calls, per_call * 2 * N), np.float32)
+    for c in range(calls):
+        assert b.write(ref[c], c * per_call * N) == per_call * 2 * N
+    assert a.device_errors() == 0 and b.device_errors() == 0
+    assert np.array_equal(d.cpu().numpy(), ref)
+    assert np.abs(ref).max() > 1e-2
+
+
+def test_sharded_rccl_reduce_on_a_one_device_communicator():
+    """PG_REDUCE_RCCL: the partial buses meet by ncclReduce(sum) (and the `audible` words by ncclReduce(max)) on the shards' streams
+    instead of peer copies + the sum kernel. A 1-GPU box can only hold a one-rank communicator (ncclCommInitAll over one device), which
+    still runs every RCCL call of the path; two shards on ONE device must be refused with RCCL / parameter error text, leaving the mode as
+    it was — no silent fallback."""
+    from phonic_amd.graph import ShardedGraph
+    import phonic_amd
+
+    N, blocks = 1024, 8
+
+    def build(g):
+        for i in range(5):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.1), 2, 44100, volume=0.3, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        eq = g.add_effect(0, _capi.FX_EQ5, params={"gan3": 5.0})
+        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -20.0, "rato": 20.0, "knee": 0.0, "gain": 0.0})
+        return eq
+
+    outs = []
+    for mode in ("rccl", "oracle"):
+        g = ShardedGraph([0], SR, 2, N) if mode == "rccl" else oracle.OracleGraph(SR, 2, N)
+        if mode == "rccl":
+            g.set_max_blocks_per_launch(2)
+            g.set_reduce(_capi.REDUCE_RCCL)
+            assert g.reduce_mode() == _capi.REDUCE_RCCL
+        eq = build(g)
+        o = np.zeros((blocks // 2, 2 * 2 * N), np.float32)
+        for c in range(blocks // 2):
+            if c == 2:
+                g.schedule_param(eq, "gan1", -6.0, c * 2 * N + 777)      # a bus event inside a call: the call is rendered as two segments
+            assert g.write(o[c], c * 2 * N) == o[c].size
+        outs.append(o.reshape(-1))
+        if mode == "rccl":
+            assert g.device_errors() == 0
+    compare(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-2
+    g2 = ShardedGraph([0, 0], SR, 2, N)
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        g2.set_reduce(_capi.REDUCE_RCCL)
+    assert "device 0 is listed twice" in str(ei.value)
+    assert g2.reduce_mode() == _capi.REDUCE_PEER_COPY
 
 
 @pytest.mark.parametrize("file_rate,source_rate,channels", [(44100, 32000, 2), (48000, 96000, 2), (22050, 22050, 1), (44100, 44100, 2)])
