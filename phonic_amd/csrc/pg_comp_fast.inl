@@ -52,6 +52,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     float* sp = sig + 2 * f0;
     const uint32_t wp0 = c.write_pos;
     __syncthreads();
+    PG_STAMP(fc.diag, 24);
     // 1. frame peaks (delay.rs:245-247): history from the line, the block from the signal
     for (int i = tid; i < TOT; i += nt) {
       float p;
@@ -66,10 +67,22 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     }
     if (tid == 0) { red[0] = 0; red[1] = -0x7fffffff; }
     __syncthreads();
-    // 2. tracked peak after the piece: maximum of the last window and its newest holder (peaks are >= 0: their bits order like ints)
-    for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0) atomicMax(&red[0], (int)__float_as_uint(a0[i]));
-    __syncthreads();
-    { const float m = __uint_as_float((uint32_t)red[0]); for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0 && a0[i] == m) atomicMax(&red[1], i - H); }
+    PG_STAMP(fc.diag, 25);
+    // 2. tracked peak after the piece: maximum of the last window and its newest holder (peaks are >= 0: their bits order like ints).
+    // (Per-lane maxima, a wave reduction, ONE LDS atomic per wave: 960 atomics on one LDS word serialise — 20 K cycles of a lone workgroup.)
+    {
+      int mx = 0;
+      for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0) mx = max(mx, (int)__float_as_uint(a0[i]));
+      for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+      if ((tid & 63) == 0) atomicMax(&red[0], mx);
+      __syncthreads();
+      const float m = __uint_as_float((uint32_t)red[0]);
+      int at = -0x7fffffff;
+      for (int i = TOT - W + tid; i < TOT; i += nt) if (i >= 0 && a0[i] == m) at = max(at, i - H);
+      for (int off = 32; off > 0; off >>= 1) at = max(at, __shfl_xor(at, off, 64));
+      if ((tid & 63) == 0) atomicMax(&red[1], at);
+    }
+    PG_STAMP(fc.diag, 26);
     // 3. input level in dB (compressor.rs:241-255)
     if (limiter) {
       float* src = a0; float* dst = a1;
@@ -91,20 +104,52 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       for (int n = tid; n < N; n += nt) { const float fp = a0[n + H]; env[n] = (fp > 1e-6f) ? 20.0f * pg_log10f(fp) : -120.0f; }
     }
     __syncthreads();
-    // 4. envelope follower: the one serial recurrence; meanwhile the other lanes stage the input (the output pass overwrites it)
-    if (tid == 0) {
+    PG_STAMP(fc.diag, 27);
+    // 4. envelope follower: the one serial recurrence. Wave 0 walks it 64 frames at a time: the lanes load 64 levels at once, the chain runs on
+    // values broadcast from a register (v_readlane) and every lane keeps the envelope of its own frame — one LDS round trip per 64 frames
+    // instead of one per frame (130 cycles per frame on a lone lane: 133 K of the 200 K cycles a bus limiter spent on a block). Same f32
+    // operations in the same order as EnvelopeFollower::run (envelope.rs:51-60): subtract, multiply, add, the branch as a select.
+    // Meanwhile the other waves stage the input (the output pass overwrites it).
+    if (tid < 64) {
       float cur = c.env_current;
       const float att = c.env_attack, rel = c.env_release;
-      for (int n = 0; n < N; ++n) env[n] = env_run(cur, att, rel, env[n]);
-      c.env_current = cur;
-      if (makeup_ramps) { PgSmooth m = c.makeup; for (int n = 0; n < N; ++n) a0[n] = sm_next(m); c.makeup = m; }  // makeup_gain.next_value() per frame (a0 is free by now)
-      c.peak_value = (double)__uint_as_float((uint32_t)red[0]);
-      c.peak_pos = (wp0 + (uint32_t)red[1]) & mask;
-      c.write_pos = (wp0 + (uint32_t)N) & mask;
+      for (int base = 0; base < N; base += 64) {
+        const int cnt = N - base < 64 ? N - base : 64;
+        const float mine = tid < cnt ? env[base + tid] : 0.0f;
+        float out = 0.0f;
+        if (cnt == 64) {
+#pragma unroll
+          for (int k = 0; k < 64; ++k) {
+            const float x = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine), k));
+            const float d = cur - x;
+            const float a = x + att * d, r = x + rel * d;
+            cur = x > cur ? a : r;
+            out = tid == k ? cur : out;
+          }
+        } else {
+          for (int k = 0; k < cnt; ++k) {
+            const float x = __shfl(mine, k, 64);
+            const float d = cur - x;
+            const float a = x + att * d, r = x + rel * d;
+            cur = x > cur ? a : r;
+            out = tid == k ? cur : out;
+          }
+        }
+        if (tid < cnt) env[base + tid] = out;
+      }
+      if (tid == 0) {
+        c.env_current = cur;
+        if (makeup_ramps) { PgSmooth m = c.makeup; for (int n = 0; n < N; ++n) a0[n] = sm_next(m); c.makeup = m; }  // makeup_gain.next_value() per frame (a0 is free by now)
+        c.peak_value = (double)__uint_as_float((uint32_t)red[0]);
+        c.peak_pos = (wp0 + (uint32_t)red[1]) & mask;
+        c.write_pos = (wp0 + (uint32_t)N) & mask;
+      }
+      if (nt <= 64) for (int i = tid; i < 2 * N; i += nt) a1[i] = sp[i];
     } else {
-      for (int i = tid - 1; i < 2 * N; i += nt - 1) a1[i] = sp[i];
+      for (int i = tid - 64; i < 2 * N; i += nt - 64) a1[i] = sp[i];
     }
     __syncthreads();
+    PG_STAMP(fc.diag, 28);
     // 5. gain and output (compressor.rs:257-292); 6. the block's input goes into the line
     for (int s = tid; s < 2 * N; s += nt) {
       const int n = s >> 1, ch = s & 1;
@@ -113,9 +158,11 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       sp[s] = delayed * total_gain;
     }
     __syncthreads();  // every read of the line's history is done before its slots are rewritten
+    PG_STAMP(fc.diag, 29);
     // (the ring is only next_pow2(delay) frames long: of the frames that share a slot, the last one stays — write only those)
     for (int s = tid; s < 2 * N; s += nt) if ((s >> 1) >= N - (int)(mask + 1)) line[((wp0 + (uint32_t)(s >> 1)) & mask) * 2 + (s & 1)] = (double)a1[s];
     __syncthreads();
+    PG_STAMP(fc.diag, 30);
   }
   return true;
 }
