@@ -86,6 +86,16 @@ typedef struct pg_effect_init {
   uint32_t reverb_fpd_l;
   uint32_t reverb_fpd_r;
   double reverb_vib_phase[16];
+  /* The Delay's LFO shapes Random and Smooth Random (LfoWaveform, src/utils/dsp/lfo.rs:35-46) draw from `SmallRng::from_os_rng()`
+   * (lfo.rs:73): the reference is not reproducible there. Here the generator's state is an explicit input, like the reverb's seeds:
+   * rand ^0.9's SmallRng on 64-bit targets is Xoshiro256++ (Blackman / Vigna; state = four u64), `random::<f32>()` = (next_u64() >> 40) *
+   * 2^-24 (StandardUniform: the upper 24 bits of next_u32 = the upper 32 of next_u64). `lfo_rng_state` is that state as
+   * Effect::initialize finds it (Lfo::new then draws sample_hold, jitter_current, jitter_target from it, lfo.rs:74-76). Without a
+   * seed (or with an all-zero state, which xoshiro cannot hold) the state is SplitMix64(0x5EED0000) x 4 — every unseeded Delay then
+   * runs the same random sequence. */
+  uint32_t has_lfo_seed;
+  uint32_t reserved_lfo;
+  uint64_t lfo_rng_state[4];
 } pg_effect_init;
 
 /* ---- parameter descriptors: `Effect::parameters()` (src/effect.rs:105-111) -------------- */

@@ -22,7 +22,12 @@ std::unique_ptr<Effect> make_effect(int kind, const pg_effect_init* init) {
     case PG_FX_PANNING: e.reset(new PanningEffect()); break;
     case PG_FX_FILTER: e.reset(new FilterEffect()); break;
     case PG_FX_EQ5: e.reset(new Eq5Effect()); break;
-    case PG_FX_DELAY: e.reset(new DelayEffect()); break;
+    case PG_FX_DELAY: {
+      DelayEffect* d = new DelayEffect();
+      if (init && init->has_lfo_seed && (init->lfo_rng_state[0] | init->lfo_rng_state[1] | init->lfo_rng_state[2] | init->lfo_rng_state[3]) != 0)
+        d->lfo_seed = SmallRng(init->lfo_rng_state);
+      e.reset(d);
+    } break;
     case PG_FX_REVERB: {
       double zero[16] = {0};
       if (init && init->has_reverb_seeds) e.reset(new ReverbEffect(init->reverb_fpd_l, init->reverb_fpd_r, init->reverb_vib_phase));
@@ -340,6 +345,11 @@ float po_db_to_linear(float v) { return db_to_linear(v); }
 float po_linear_to_db(float v) { return linear_to_db(v); }
 void po_panning_factors(float p, float* l, float* r) { panning_factors(p, *l, *r); }
 float po_sine_approx(float x) { return sine_approx(x); }
+// the generator behind the LFO's random shapes: n x next_u64 and n x random::<f32>() from the given Xoshiro256++ state (known-answer tests)
+void po_small_rng_run(const uint64_t state[4], size_t n, uint64_t* out_u64, float* out_f32) {
+  SmallRng a(state), b(state);
+  for (size_t i = 0; i < n; ++i) { if (out_u64) out_u64[i] = a.next_u64(); if (out_f32) out_f32[i] = b.random_f32(); }
+}
 
 // smoothers: kind 0 = exponential(inertia arg), 1 = linear(step arg), 2 = spring(duration arg)
 // ops are replayed on a fresh smoother created with (value, sample_rate); returns current after `n_ramps` ramps

@@ -269,12 +269,47 @@ inline float sine_approx(float x) {  // :9-19
   return P * (y * std::fabs(y) - y) + y;
 }
 enum class LfoWaveform { Sine, Triangle, RampUp, RampDown, Square, Random, SmoothRandom };
-struct Lfo {  // :50-253  (Random / SmoothRandom use SmallRng::from_os_rng(): non-deterministic, excluded)
+// rand ^0.9 (a dependency of the reference, not vendored): `SmallRng` on 64-bit targets is Xoshiro256++ (D. Blackman, S. Vigna, public
+// domain reference xoshiro256plusplus.c; known answers for the state {1, 2, 3, 4} in tests/test_oracle_kats.py), `next_u32` its upper
+// half, and `random::<f32>()` (StandardUniform) 24 bits of that times 2^-24. The reference seeds it from the OS (lfo.rs:73): the state is
+// an explicit input here (pg_effect_init::lfo_rng_state), and SplitMix64(0x5EED0000) x 4 when none is given.
+struct SmallRng {
+  uint64_t s[4];
+  SmallRng() { uint64_t z = 0x5EED0000ull; for (int i = 0; i < 4; ++i) { z += 0x9E3779B97F4A7C15ull; uint64_t x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; s[i] = x ^ (x >> 31); } }
+  explicit SmallRng(const uint64_t st[4]) { for (int i = 0; i < 4; ++i) s[i] = st[i]; }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next_u64() {
+    const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return result;
+  }
+  uint32_t next_u32() { return (uint32_t)(next_u64() >> 32); }
+  float random_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+};
+
+struct Lfo {  // :50-253
   float phase = 0.0f, phase_inc = 0.0f;
   LfoWaveform waveform = LfoWaveform::Sine;
+  float sample_hold_value = 0.0f, jitter_current = 0.0f, jitter_target = 0.0f;
+  SmallRng rng;
   Lfo() : Lfo(44100, 1.0, LfoWaveform::Sine) {}
-  Lfo(uint32_t sample_rate, double rate, LfoWaveform w) : phase(0.0f), phase_inc((float)(rate / (double)sample_rate)), waveform(w) {}
-  void reset() { phase = 0.0f; }
+  Lfo(uint32_t sample_rate, double rate, LfoWaveform w, const SmallRng& seeded = SmallRng())  // :70-86 (`SmallRng::from_os_rng()` -> the seeded state)
+      : phase(0.0f), phase_inc((float)(rate / (double)sample_rate)), waveform(w), rng(seeded) {
+    sample_hold_value = rng.random_f32() * 2.0f - 1.0f;
+    jitter_current = rng.random_f32() * 2.0f - 1.0f;
+    jitter_target = rng.random_f32() * 2.0f - 1.0f;
+  }
+  void reset() {  // :89-99
+    phase = 0.0f;
+    if (waveform == LfoWaveform::Random || waveform == LfoWaveform::SmoothRandom) {
+      sample_hold_value = rng.random_f32() * 2.0f - 1.0f;
+      jitter_current = jitter_target;
+      jitter_target = rng.random_f32() * 2.0f - 1.0f;
+    }
+  }
   void set_rate(uint32_t sample_rate, double rate) { phase_inc = (float)(rate / (double)sample_rate); }
   void set_phase(float p) {  // rem_euclid(1.0) :105-107
     float r = std::fmod(p, 1.0f);
@@ -298,10 +333,22 @@ struct Lfo {  // :50-253  (Random / SmoothRandom use SmallRng::from_os_rng(): no
       case LfoWaveform::RampUp: value = phase * 2.0f - 1.0f; break;
       case LfoWaveform::RampDown: value = 1.0f - phase * 2.0f; break;
       case LfoWaveform::Square: value = (phase < 0.5f) ? 1.0f : -1.0f; break;
-      default: value = 0.0f; break;  // Random shapes: not restated
+      case LfoWaveform::Random: value = sample_hold_value; break;
+      default: {  // SmoothRandom: cosine interpolation between two random values :154-159
+        float p = 1.57079632679489661923f - phase * F32_PI;
+        float t = (1.0f - sine_approx(p)) * 0.5f;
+        value = jitter_current + t * (jitter_target - jitter_current);
+      } break;
     }
-    phase += phase_inc;  // :234-239
-    if (phase >= 1.0f) phase -= 1.0f;
+    phase += phase_inc;  // advance_phase :234-239 / advance_phase_random :241-252
+    if (phase >= 1.0f) {
+      phase -= 1.0f;
+      if (waveform == LfoWaveform::Random || waveform == LfoWaveform::SmoothRandom) {
+        sample_hold_value = rng.random_f32() * 2.0f - 1.0f;
+        jitter_current = jitter_target;
+        jitter_target = rng.random_f32() * 2.0f - 1.0f;
+      }
+    }
     return value;
   }
 };

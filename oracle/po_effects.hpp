@@ -340,6 +340,7 @@ struct DelayEffect : Effect {
   SmoothedParameterValue<> lfo_depth_filter{FloatParameter{fourcc("lfdf"), -1.0f, 1.0f, 0.0f, {}}};
   InterpolatedDelayLine<1> delay_left, delay_right;
   Lfo lfo;
+  SmallRng lfo_seed;  // state the LFO's generator starts from in initialize (pg_effect_init::lfo_rng_state; the reference: from_os_rng)
   SvfCoefficients filter_coefficients;
   SvfFilter filter_left, filter_right;
   DcFilter dc_left, dc_right;
@@ -390,7 +391,7 @@ struct DelayEffect : Effect {
     float c = rclampf(filter_cutoff.target_value(), 20.0f, (float)sr / 2.0f);
     filter_coefficients = SvfCoefficients();
     if (!filter_coefficients.set(to_svf(filter_type.value()), sr, c, FILTER_RESONANCE)) return false;
-    lfo = Lfo(sr, (double)lfo_rate.target_value(), (LfoWaveform)lfo_shape.value());
+    lfo = Lfo(sr, (double)lfo_rate.target_value(), (LfoWaveform)lfo_shape.value(), lfo_seed);  // `Lfo::new` :318-322 with the seeded generator
     dc_left = DcFilter(sr, DcMode::Default);
     dc_right = DcFilter(sr, DcMode::Default);
     feedback_left = 0.0f; feedback_right = 0.0f;

@@ -22,11 +22,11 @@ from ._capi import (  # noqa: F401
 from ._wrap import PhonicError  # noqa: F401
 
 
-def Effect(kind, params=None, reverb_seeds=None, device=0):
+def Effect(kind, params=None, reverb_seeds=None, device=0, lfo_seed=None):
     """A standalone effect instance on the GPU (reference `impl Effect`)."""
     from ._wrap import EffectHandle
 
-    return EffectHandle(_capi.load(), "pg_", kind, params, reverb_seeds, device)
+    return EffectHandle(_capi.load(), "pg_", kind, params, reverb_seeds, device, lfo_seed)
 
 
 def Graph(sample_rate=48000, channels=2, max_frames=4096, device=0):

@@ -34,6 +34,9 @@ class EffectInit(C.Structure):
         ("reverb_fpd_l", C.c_uint32),
         ("reverb_fpd_r", C.c_uint32),
         ("reverb_vib_phase", C.c_double * 16),
+        ("has_lfo_seed", C.c_uint32),
+        ("reserved_lfo", C.c_uint32),
+        ("lfo_rng_state", C.c_uint64 * 4),
     ]
 
 
@@ -70,8 +73,9 @@ class ParamDesc(C.Structure):
     ]
 
 
-def make_init(params=None, reverb_seeds=None):
-    """Build a pg_effect_init. params: dict {fourcc-str: raw value}; reverb_seeds: (fpd_l, fpd_r, [16 phases])."""
+def make_init(params=None, reverb_seeds=None, lfo_seed=None):
+    """Build a pg_effect_init. params: dict {fourcc-str: raw value}; reverb_seeds: (fpd_l, fpd_r, [16 phases]); lfo_seed: the four u64 of the
+    Delay LFO's Xoshiro256++ state (Random / Smooth Random shapes)."""
     init = EffectInit()
     params = params or {}
     assert len(params) <= PG_MAX_INIT_PARAMS
@@ -84,6 +88,10 @@ def make_init(params=None, reverb_seeds=None):
         init.reverb_fpd_l, init.reverb_fpd_r = int(reverb_seeds[0]), int(reverb_seeds[1])
         for i in range(16):
             init.reverb_vib_phase[i] = float(reverb_seeds[2][i])
+    if lfo_seed is not None:
+        init.has_lfo_seed = 1
+        for i in range(4):
+            init.lfo_rng_state[i] = int(lfo_seed[i]) & (2**64 - 1)
     return init
 
 

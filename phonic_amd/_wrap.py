@@ -29,10 +29,10 @@ def _f32p(a):
 class EffectHandle:
     """`dyn Effect` (src/effect.rs:86-215)."""
 
-    def __init__(self, lib, prefix, kind, params=None, reverb_seeds=None, device=0):
+    def __init__(self, lib, prefix, kind, params=None, reverb_seeds=None, device=0, lfo_seed=None):
         self._lib, self._p = lib, prefix
         self.kind = kind
-        init = _capi.make_init(params, reverb_seeds)
+        init = _capi.make_init(params, reverb_seeds, lfo_seed)
         create = getattr(lib, prefix + "effect_create")
         if prefix == "pg_":
             self._h = create(kind, C.byref(init), device)
@@ -128,8 +128,8 @@ class GraphHandle:
             return self._id(self._fn("graph_add_mixer")(self._h))
         return self._id(self._fn("graph_add_mixer_to")(self._h, parent))
 
-    def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None):
-        init = _capi.make_init(params, reverb_seeds)
+    def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None, lfo_seed=None):
+        init = _capi.make_init(params, reverb_seeds, lfo_seed)
         return self._id(self._fn("graph_add_effect")(self._h, mixer_id, kind, C.byref(init)))
 
     def add_voice(self, mixer_id, pcm, src_channels, src_rate, **opts):

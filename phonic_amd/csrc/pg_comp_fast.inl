@@ -87,11 +87,18 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     if (limiter) {
       float* src = a0; float* dst = a1;
       int span = 1;
-      while (span * 2 <= W) {  // after level k: src[i] = max over the 2^k entries ending at i
+      while (span * 2 <= W) {  // after a pass: src[i] = max over the `span` entries ending at i. Up to three doubling levels per pass (eight taps
+        const int lv = span * 8 <= W ? 3 : (span * 4 <= W ? 2 : 1);   // `span` apart): a look-ahead of 960 frames takes 3 passes and barriers, not 9
+        const int taps = 1 << lv;
         __syncthreads();
-        for (int i = tid; i < TOT; i += nt) dst[i] = i >= span ? fmaxf(src[i], src[i - span]) : src[i];
+        for (int i = tid; i < TOT; i += nt) {   // (an index below 0 is clamped to entry 0, which such a window holds anyway; a tap beyond `taps` re-reads entry i)
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int k = i - j * span; v[j] = src[j < taps ? (k > 0 ? k : 0) : i]; }
+          dst[i] = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+        }
         float* t = src; src = dst; dst = t;
-        span *= 2;
+        span <<= lv;
       }
       __syncthreads();
       for (int n = tid; n < N; n += nt) {   // window [i - W + 1, i] = [i - span + 1, i] U [i - W + 1, i - W + span]
@@ -105,38 +112,30 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     }
     __syncthreads();
     PG_STAMP(fc.diag, 27);
-    // 4. envelope follower: the one serial recurrence. Wave 0 walks it 64 frames at a time: the lanes load 64 levels at once, the chain runs on
-    // values broadcast from a register (v_readlane) and every lane keeps the envelope of its own frame — one LDS round trip per 64 frames
-    // instead of one per frame (130 cycles per frame on a lone lane: 133 K of the 200 K cycles a bus limiter spent on a block). Same f32
-    // operations in the same order as EnvelopeFollower::run (envelope.rs:51-60): subtract, multiply, add, the branch as a select.
-    // Meanwhile the other waves stage the input (the output pass overwrites it).
+    // 4. envelope follower: the one serial recurrence, walked by wave 0 as a systolic chain, 64 frames per pass. Lane j holds the level of
+    // frame j; every step each lane takes the envelope of the lane below it (a DPP wavefront shift: lane 0 takes the envelope carried in
+    // from the previous pass) and applies EnvelopeFollower::run (envelope.rs:51-60) with its own level — the same f32 operations in the same
+    // order: compare, subtract, multiply, add. Lane 0 is right from the first step on, lane 1 from the second ... and a lane that is right
+    // stays right (its input no longer changes): after 64 steps every lane holds the envelope of its frame. Five dependent VALU
+    // instructions per frame and no memory access inside the pass (a lone lane walking the block in LDS paid a round trip per frame:
+    // 133 K of the 200 K cycles a bus limiter spent on a block). Meanwhile the other waves stage the input (the output pass overwrites it).
     if (tid < 64) {
-      float cur = c.env_current;
+      float carry = c.env_current;
       const float att = c.env_attack, rel = c.env_release;
       for (int base = 0; base < N; base += 64) {
         const int cnt = N - base < 64 ? N - base : 64;
-        const float mine = tid < cnt ? env[base + tid] : 0.0f;
-        float out = 0.0f;
-        if (cnt == 64) {
-#pragma unroll
-          for (int k = 0; k < 64; ++k) {
-            const float x = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine), k));
-            const float d = cur - x;
-            const float a = x + att * d, r = x + rel * d;
-            cur = x > cur ? a : r;
-            out = tid == k ? cur : out;
-          }
-        } else {
-          for (int k = 0; k < cnt; ++k) {
-            const float x = __shfl(mine, k, 64);
-            const float d = cur - x;
-            const float a = x + att * d, r = x + rel * d;
-            cur = x > cur ? a : r;
-            out = tid == k ? cur : out;
-          }
+        const float x = tid < cnt ? env[base + tid] : 0.0f;
+        float cur = carry;
+#pragma unroll 8
+        for (int t = 0; t < 64; ++t) {
+          const float below = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(carry), (int)__float_as_uint(cur), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+          const float coef = x > below ? att : rel;
+          cur = x + coef * (below - x);
         }
-        if (tid < cnt) env[base + tid] = out;
+        if (tid < cnt) env[base + tid] = cur;
+        carry = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cur), cnt - 1));
       }
+      const float cur = carry;
       if (tid == 0) {
         c.env_current = cur;
         if (makeup_ramps) { PgSmooth m = c.makeup; for (int n = 0; n < N; ++n) a0[n] = sm_next(m); c.makeup = m; }  // makeup_gain.next_value() per frame (a0 is free by now)

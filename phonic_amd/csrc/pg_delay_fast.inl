@@ -142,6 +142,7 @@ DEVO void svf_scan_time_varying(CoefFn coef, PgState2* st, double* buf, int T, d
 
 DEVO bool delay_fast_eligible(const PgFx& fx) {
   const PgDelay& d = fx.u.delay;
+  if (d.lfo.waveform >= 5) return false;  // Random / Smooth Random: the generator is drawn from on phase wraps — the exact serial lane renders those
   if (sm_need_ramp(d.delay_time) || sm_need_ramp(d.feedback) || sm_need_ramp(d.cutoff) || sm_need_ramp(d.drive) || sm_need_ramp(d.wet) ||
       sm_need_ramp(d.width) || sm_need_ramp(d.lfo_rate) || sm_need_ramp(d.d_time) || sm_need_ramp(d.d_feedback) || sm_need_ramp(d.d_filter))
     return false;
@@ -170,6 +171,7 @@ DEVO PgSmooth& delay_ramp_smoother(PgDelay& d, int j) {
 // [-1, 1] up to the parabolic sine's overshoot.
 DEVO bool delay_ramp_eligible(const PgFx& fx) {
   const PgDelay& d = fx.u.delay;
+  if (d.lfo.waveform >= 5) return false;
   const float srf = (float)fx.sample_rate;
   const PgSmooth& t = d.delay_time;
   const float travel = t.kind == SM_SPRING && t.a > 0.0f ? fabsf(t.b) / (t.a * t.comp) : 0.0f;

@@ -69,6 +69,10 @@ struct PgDelay {  // DelayEffect (src/effect/delay.rs:88-116)
   PgState2 flt[2];
   PgDc dc[2];
   float fb[2];
+  // Lfo's random shapes (lfo.rs:56-59): sample & hold value, the two ends of the smooth-random segment, and the generator —
+  // rand ^0.9 SmallRng = Xoshiro256++, its state an explicit input (pg_effect_init::lfo_rng_state)
+  float lfo_sample_hold, lfo_jitter_current, lfo_jitter_target, lfo_pad;
+  uint64_t lfo_rng[4];
 };
 struct PgReverbLine {  // ReverbDelayLine<2> (src/effect/reverb.rs:518-529)
   double* buf;         // [(size+1)][2]

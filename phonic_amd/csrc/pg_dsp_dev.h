@@ -221,6 +221,19 @@ DEV float sine_approx(float x) {  // :9-19
   float y = B * x + C * x * fabsf(x);
   return P * (y * fabsf(y) - y) + y;
 }
+// rand ^0.9 SmallRng on 64-bit targets = Xoshiro256++ (D. Blackman, S. Vigna; public domain reference xoshiro256plusplus.c):
+//   result = rotl(s0 + s3, 23) + s0;  t = s1 << 17;  s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;  s2 ^= t;  s3 = rotl(s3, 45)
+// and `rng.random::<f32>()` (StandardUniform for f32: 24 bits of next_u32, which for this generator is the upper half of next_u64).
+DEV uint64_t xoshiro256pp_next(uint64_t* s) {
+  const uint64_t r = ((s[0] + s[3]) << 23 | (s[0] + s[3]) >> 41) + s[0];
+  const uint64_t t = s[1] << 17;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t;
+  s[3] = (s[3] << 45) | (s[3] >> 19);
+  return r;
+}
+DEV float rng_random_f32(uint64_t* s) { return (float)(uint32_t)(xoshiro256pp_next(s) >> 40) * (1.0f / 16777216.0f); }
+DEV float lfo_random_bipolar(uint64_t* s) { return rng_random_f32(s) * 2.0f - 1.0f; }   // `rng.random::<f32>() * 2.0 - 1.0`  lfo.rs:74-76,90-92,246-249
 DEV float lfo_value(const PgLfo& l) {  // :122-152 (deterministic shapes)
   float ph = l.phase;
   switch (l.waveform) {
@@ -237,6 +250,36 @@ DEV float lfo_run(PgLfo& l) {  // :122-169, :234-239
   l.phase += l.phase_inc;
   if (l.phase >= 1.0f) l.phase -= 1.0f;
   return v;
+}
+// The DelayEffect's Lfo with all seven shapes: Random (sample & hold) and Smooth Random (cosine-interpolated jitter) read their state
+// and draw new values on every phase wrap (lfo.rs:145-152,160-169,241-252)
+DEV float delay_lfo_run(PgDelay& d) {
+  PgLfo& l = d.lfo;
+  if (l.waveform < 5) return lfo_run(l);
+  float v;
+  if (l.waveform == 5) v = d.lfo_sample_hold;
+  else {
+    const float p = 1.57079632679489661923f - l.phase * F32_PI;   // FRAC_PI_2 - phase * PI
+    const float t = (1.0f - sine_approx(p)) * 0.5f;
+    v = d.lfo_jitter_current + t * (d.lfo_jitter_target - d.lfo_jitter_current);
+  }
+  l.phase += l.phase_inc;   // advance_phase_random
+  if (l.phase >= 1.0f) {
+    l.phase -= 1.0f;
+    d.lfo_sample_hold = lfo_random_bipolar(d.lfo_rng);
+    d.lfo_jitter_current = d.lfo_jitter_target;
+    d.lfo_jitter_target = lfo_random_bipolar(d.lfo_rng);
+  }
+  return v;
+}
+// Lfo::reset (lfo.rs:84-94): phase 0; the random shapes draw again
+DEV void delay_lfo_reset(PgDelay& d) {
+  d.lfo.phase = 0.0f;
+  if (d.lfo.waveform >= 5) {
+    d.lfo_sample_hold = lfo_random_bipolar(d.lfo_rng);
+    d.lfo_jitter_current = d.lfo_jitter_target;
+    d.lfo_jitter_target = lfo_random_bipolar(d.lfo_rng);
+  }
 }
 // `steps` iterations of { p += d; if (p >= 1) p -= 1; } (the phase update of Lfo::run, lfo.rs:234-239) in f32, exactly, in
 // O(pieces) instead of O(steps): inside a binade fl(p + d) = p + du with du = d rounded to a multiple of ulp(p) (no tie), and

@@ -129,8 +129,6 @@ int pg_effect_set_parameter(pg_effect* e, uint32_t fourcc, float value, int is_n
   if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[e->kind].name);
   float raw;
   if (!resolve_update(KINDS[e->kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;
-  if (e->kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
-    return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
   e->host.target[pi] = raw;
   if (!e->initialized) { e->host.init_raw[pi] = raw; return PG_OK; }  // before initialize: plain value update
   PgCmd c;

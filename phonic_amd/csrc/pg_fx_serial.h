@@ -161,7 +161,7 @@ DEVN void delay_serial(PgFx& fx, float* sig, int n) {
   float srf = (float)fx.sample_rate;
   for (int f = 0; f + 2 <= n; f += 2) {
     float left_input = sig[f], right_input = sig[f + 1];
-    float lfo_val = lfo_run(d.lfo);
+    float lfo_val = delay_lfo_run(d);
     if (sm_need_ramp(d.lfo_rate)) {
       float rate = sm_next(d.lfo_rate);
       lfo_set_rate(d.lfo, fx.sample_rate, (double)rate);

@@ -107,10 +107,12 @@ int host_fx_from_init(int kind, const pg_effect_init* init, HostFx& h) {
       float v = init->value[i];
       if (p.type == PG_PARAM_FLOAT && !(v >= p.min && v <= p.max)) return set_error(PG_ERR_PARAMETER, "Value out of bounds for '%s'", p.name);
       if (p.type == PG_PARAM_ENUM && !((int)v >= 0 && (int)v < p.n_values)) return set_error(PG_ERR_PARAMETER, "Invalid enum index for '%s'", p.name);
-      if (kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)v >= 5)
-        return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random draw from an OS-seeded RNG in the reference and are not supported");
       h.init_raw[pi] = v;
       h.with_params = true;
+    }
+    if (init->has_lfo_seed && (init->lfo_rng_state[0] | init->lfo_rng_state[1] | init->lfo_rng_state[2] | init->lfo_rng_state[3]) != 0) {
+      h.has_lfo_seed = true;
+      memcpy(h.lfo_rng, init->lfo_rng_state, sizeof h.lfo_rng);
     }
     if (init->has_reverb_seeds) {
       h.has_seeds = true;
@@ -202,6 +204,12 @@ int build_fx_device_state(HostFx& h, uint32_t sr, int device, bool standalone, P
       memset(&d.coef, 0, sizeof d.coef);
       if (!svf_set(d.coef, d.filter_type, sr, clampf(d.cutoff.target, 20.0f, (float)sr / 2.0f), 0.302f)) return set_error(PG_ERR_PARAMETER, "Invalid delay filter");
       d.lfo.phase = 0.0f; d.lfo.phase_inc = (float)((double)d.lfo_rate.target / (double)sr); d.lfo.waveform = d.lfo_shape;
+      // Lfo::new (lfo.rs:70-86): a fresh SmallRng — here the explicit state, else SplitMix64(0x5EED0000) x 4 — and three draws
+      if (h.has_lfo_seed) memcpy(d.lfo_rng, h.lfo_rng, sizeof d.lfo_rng);
+      else { uint64_t z = 0x5EED0000ull; for (int i = 0; i < 4; ++i) { z += 0x9E3779B97F4A7C15ull; uint64_t x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; d.lfo_rng[i] = x ^ (x >> 31); } }
+      d.lfo_sample_hold = lfo_random_bipolar(d.lfo_rng);
+      d.lfo_jitter_current = lfo_random_bipolar(d.lfo_rng);
+      d.lfo_jitter_target = lfo_random_bipolar(d.lfo_rng);
       for (int c = 0; c < 2; ++c) { d.dc[c].x1 = d.dc[c].y1 = 0.0; d.dc[c].r = dc_r(5.0, sr); }
     } break;
     case PG_FX_REVERB: {  // reverb.rs:94-151,391-407

@@ -579,8 +579,6 @@ int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float v
   if (pi < 0) return set_error(PG_ERR_PARAMETER, "Unknown parameter: 0x%08x for effect '%s'", fourcc, KINDS[kind].name);
   float raw;
   if (!resolve_update(KINDS[kind].params[pi], value, is_normalized != 0, raw)) return PG_OK;  // logged + ignored in the reference
-  if (kind == PG_FX_DELAY && pi == P_DELAY_LFO_SHAPE && (int)raw >= 5)
-    return set_error(PG_ERR_PARAMETER, "LFO shapes Random/Smooth Random are not supported (OS-seeded RNG in the reference)");
   pgc::CtrlMsg m;
   memset(&m, 0, sizeof m);
   m.type = pgc::CT_FX_PARAM; m.id = effect_id; m.param = pi; m.value = raw; m.sample_time = sample_time;

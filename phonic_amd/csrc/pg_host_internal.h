@@ -139,6 +139,8 @@ struct HostFx {
   bool has_seeds = false;
   uint32_t fpd_l = 16386, fpd_r = 16386;
   double vib[16] = {0};
+  bool has_lfo_seed = false;     // Delay: explicit Xoshiro256++ state of the LFO's random shapes (pg_effect_init::lfo_rng_state)
+  uint64_t lfo_rng[4] = {0, 0, 0, 0};
   void* d_mem = nullptr;         // delay-line memory owned by this effect
   size_t d_mem_bytes = 0;
   int last_mixer = -1;           // graph effects: the mixer the effect belonged to when it was removed (its late events stay that mixer's events)

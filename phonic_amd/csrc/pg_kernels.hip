@@ -162,7 +162,7 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
         d.write_pos[0] = d.write_pos[1] = 0;
         d.flt[0].ic1eq = d.flt[0].ic2eq = d.flt[1].ic1eq = d.flt[1].ic2eq = 0.0;
         d.dc[0].x1 = d.dc[0].y1 = d.dc[1].x1 = d.dc[1].y1 = 0.0;
-        d.lfo.phase = 0.0f;
+        delay_lfo_reset(d);
         d.fb[0] = d.fb[1] = 0.0f;
       }
     } break;

@@ -108,8 +108,8 @@ class ShardedGraph:
     def add_mixer(self, parent=None):
         return self._id(self._lib.pg_sharded_add_mixer_to(self._h, parent or 0))
 
-    def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None):
-        init = _capi.make_init(params, reverb_seeds)
+    def add_effect(self, mixer_id, kind, params=None, reverb_seeds=None, lfo_seed=None):
+        init = _capi.make_init(params, reverb_seeds, lfo_seed)
         return self._id(self._lib.pg_sharded_add_effect(self._h, mixer_id, kind, C.byref(init)))
 
     def add_voice(self, mixer_id, pcm, src_channels, src_rate, **opts):

@@ -54,6 +54,8 @@ def lib():
         l.po_interp_delay_run.argtypes = [sz, f32, f32, P(f32), sz]
         l.po_effect_reverb_state.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
         l.po_graphs_render_parallel.argtypes = [P(C.c_void_p), C.c_int, C.c_int, P(f32), sz, sz, C.c_uint64]
+        l.po_small_rng_run.argtypes = [P(C.c_uint64), sz, P(C.c_uint64), P(f32)]
+        l.po_small_rng_run.restype = None
         l.po_index_log_begin.argtypes = []
         l.po_index_log_begin.restype = None
         l.po_index_log_end.argtypes = [P(C.c_int32), sz]
@@ -88,8 +90,8 @@ def fp(a):
 
 
 class OracleEffect(EffectHandle):
-    def __init__(self, kind, params=None, reverb_seeds=None):
-        super().__init__(lib(), "po_", kind, params, reverb_seeds)
+    def __init__(self, kind, params=None, reverb_seeds=None, lfo_seed=None):
+        super().__init__(lib(), "po_", kind, params, reverb_seeds, lfo_seed=lfo_seed)
 
     def reverb_state(self):
         ph = (C.c_double * 16)()

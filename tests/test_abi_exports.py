@@ -75,8 +75,11 @@ def test_effect_create_validates_without_device():
     assert b"Unknown parameter" in lib.pg_last_error_message()
     init = _capi.make_init({"room": 2.0})  # out of range -> "Value out of bounds" (smoothed.rs:118-124)
     assert not lib.pg_effect_create(_capi.FX_REVERB, C.byref(init), 0)
-    init = _capi.make_init({"lfos": 5})  # Random LFO shapes: OS-seeded RNG in the reference, unsupported
-    assert not lib.pg_effect_create(_capi.FX_DELAY, C.byref(init), 0)
+    for shape in (5, 6):  # Random / Smooth Random LFO shapes: valid, their generator's state is an explicit input (default seed without one)
+        h = lib.pg_effect_create(_capi.FX_DELAY, C.byref(_capi.make_init({"lfos": shape}, lfo_seed=(1, 2, 3, 4))), 0)
+        assert h
+        lib.pg_effect_destroy(h)
+    assert not lib.pg_effect_create(_capi.FX_DELAY, C.byref(_capi.make_init({"lfos": 7})), 0)   # seven shapes: 0..6
     h = lib.pg_effect_create(_capi.FX_REVERB, C.byref(_capi.make_init({"room": 0.5})), 0)
     assert h
     assert lib.pg_effect_tail(h) > 0  # process_tail from the target values, host side

@@ -36,8 +36,6 @@ def random_params(rng, kind, descs):
             params[fourcc_str(d["fourcc"])] = float(np.float32(v))
         else:  # enum / bool / int: integral raw value
             params[fourcc_str(d["fourcc"])] = float(int(rng.integers(int(lo), int(hi) + 1)))
-    if kind == _capi.FX_DELAY:
-        params.pop("lfos", None)  # Random LFO shapes are rejected (non-deterministic in the reference)
     return params
 
 
@@ -417,8 +415,6 @@ def test_random_standalone_effect_sequences(seed):
         for _ in range(int(rng.choice([0, 0, 1, 1, 2, 4]))):
             d = descs[int(rng.integers(0, len(descs)))]
             name = fourcc_str(d["fourcc"])
-            if kind == _capi.FX_DELAY and name == "lfos":
-                continue
             norm = bool(rng.random() < 0.5)
             if d["type"] == 0:
                 v = float(rng.random()) if norm else float(np.float32(d["min"] + (d["max"] - d["min"]) * rng.random()))

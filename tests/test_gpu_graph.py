@@ -783,6 +783,57 @@ def test_delay_with_lfo_on_time_and_feedback_takes_the_time_parallel_path(shape)
     assert g.deferred_units() == 0
 
 
+@pytest.mark.parametrize("shape", [5, 6])
+def test_delay_with_the_random_lfo_shapes_from_an_explicit_seed(shape):
+    """LfoWaveform::Random (sample & hold) and SmoothRandom (cosine-interpolated jitter), src/utils/dsp/lfo.rs:145-169,241-252: the reference
+    seeds their SmallRng from the OS; with the generator's state as an explicit input (pg_effect_init::lfo_rng_state, Xoshiro256++ = rand 0.9's
+    SmallRng) the device and the oracle draw the same sequence — at construction (three values), on every phase wrap (a 9 Hz LFO wraps ~ 4 times
+    per block), and again on a Reset message. Routed to time, feedback and filter at once; also switched to from a deterministic shape by a
+    parameter event, with the default seed, and on the bus. Random shapes take the exact serial lane (the fast paths decline them)."""
+    seed = (0x0123456789ABCDEF, 0xFEDCBA9876543210, 0x0F1E2D3C4B5A6978, 0x1122334455667788)
+
+    def build(g):
+        m1 = g.add_mixer()
+        d1 = g.add_effect(m1, _capi.FX_DELAY, params={"dlay": 60.0, "fdbk": 0.55, "lfor": 9.0, "lfos": shape, "lfdt": 0.5, "ldfb": -0.4, "lfdf": 0.6}, lfo_seed=seed)
+        g.add_voice(m1, workloads.tone_buffer(5, 44100, 0.3), 2, 44100, volume=0.8, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        m2 = g.add_mixer()
+        d2 = g.add_effect(m2, _capi.FX_DELAY, params={"mode": 1, "dlay": 25.0, "fdbk": 0.4, "lfor": 3.0, "lfos": 1, "lfdt": -0.3})      # default seed, shape set later
+        g.add_effect(m2, _capi.FX_REVERB, params={"room": 0.3}, reverb_seeds=workloads.reverb_seeds(52))
+        g.add_voice(m2, workloads.tone_buffer(13, 48000, 0.3), 2, 48000, volume=0.6, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        d3 = g.add_effect(0, _capi.FX_DELAY, params={"dlay": 15.0, "fdbk": 0.3, "wet_": 0.3, "lfor": 5.0, "lfos": shape, "lfdt": 0.2}, lfo_seed=(7, 8, 9, 10))
+        return {"d1": d1, "d2": d2, "d3": d3}
+
+    def at4(g, ids, pos):
+        g.schedule_param(ids["d2"], "lfos", shape, pos + 333)
+        g.schedule_reset(ids["d1"], pos + 700)
+
+    def at8(g, ids, pos):
+        g.schedule_param(ids["d1"], "lfos", 11 - shape, pos + 10)       # the other random shape: same state, other read-out
+        g.schedule_reset(ids["d3"], pos + 512)
+
+    a, b = both(build, 14, 1024, actions={4: at4, 8: at8}, max_frames=1024)
+    compare(a, b)
+    assert np.abs(a[-2048:]).max() > 1e-3
+    # a different seed gives different audio: the generator is really in the path
+    def build_other(g):
+        m1 = g.add_mixer()
+        g.add_effect(m1, _capi.FX_DELAY, params={"dlay": 60.0, "fdbk": 0.55, "lfor": 9.0, "lfos": shape, "lfdt": 0.5, "ldfb": -0.4, "lfdf": 0.6}, lfo_seed=(1, 2, 3, 4))
+        g.add_voice(m1, workloads.tone_buffer(5, 44100, 0.3), 2, 44100, volume=0.8, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return {}
+    c, d = both(build_other, 6, 1024, max_frames=1024)
+    compare(c, d)
+    from phonic_amd.graph import Graph
+
+    def first_sub_mixer_only(seed_):
+        g = Graph(SR, 2, 1024, 0)
+        m1 = g.add_mixer()
+        g.add_effect(m1, _capi.FX_DELAY, params={"dlay": 60.0, "fdbk": 0.55, "lfor": 9.0, "lfos": shape, "lfdt": 0.5, "ldfb": -0.4, "lfdf": 0.6}, lfo_seed=seed_)
+        g.add_voice(m1, workloads.tone_buffer(5, 44100, 0.3), 2, 44100, volume=0.8, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return g.render(6, 1024)
+    assert np.array_equal(first_sub_mixer_only((1, 2, 3, 4)), c)
+    assert np.abs(first_sub_mixer_only(seed) - c).max() > 1e-3
+
+
 @pytest.mark.parametrize("ftype", [0, 1, 2, 3])
 def test_filter_cutoff_and_q_ramps_take_the_time_parallel_path(ftype):
     """FilterEffect while cutoff and Q ramp (filter.rs:166-192: coefficients recomputed every frame): smoother value sequences laid out

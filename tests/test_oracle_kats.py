@@ -144,6 +144,23 @@ def test_spring_smoothed_value(oracle_lib):  # smoothing.rs:661-727
     assert r["extra"] > 0.0  # velocity
 
 
+# ---- rand ^0.9 SmallRng (third-party, un-vendored): the generator behind the LFO's Random / Smooth Random shapes --------------------
+def test_small_rng_is_xoshiro256plusplus(oracle_lib):
+    """The reference's `SmallRng` on 64-bit targets is Xoshiro256++ (rand 0.9: rngs/small.rs -> xoshiro256plusplus.rs). Known answers of the
+    published reference implementation (xoshiro256plusplus.c, Blackman / Vigna) for the state {1, 2, 3, 4} — the vector rand's own unit
+    test holds — and `random::<f32>()` = the upper 24 bits of next_u32 (= bits 63..40 of next_u64) times 2^-24 (StandardUniform)."""
+    state = (C.c_uint64 * 4)(1, 2, 3, 4)
+    u = (C.c_uint64 * 10)()
+    f = np.zeros(10, np.float32)
+    oracle_lib.po_small_rng_run(state, 10, u, fp(f))
+    expected = [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162, 14011001112246962877,
+                12406186145184390807, 15849039046786891736, 10450023813501588000]
+    assert list(u) == expected
+    assert np.array_equal(f, np.array([(x >> 40) * 2.0**-24 for x in expected], np.float32))
+    # the first step by hand: rotl(s0 + s3, 23) + s0 = (5 << 23) + 1
+    assert expected[0] == (5 << 23) + 1
+
+
 # ---- src/source/file/preloaded.rs:486-533 resampling (Default = cubic) ------------------------
 def test_preloaded_resampling_cubic():
     g = oracle.OracleGraph(sample_rate=48000, channels=1)
