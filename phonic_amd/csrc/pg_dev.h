@@ -279,7 +279,7 @@ struct PgLaunch {
   int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only
   float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
   uint32_t out_stride;    // floats per unit row
-  float* bus;             // bus / external signal for UNIT_BUS and UNIT_EFFECT (in place)
+  float* bus;             // bus / external signal for UNIT_BUS and UNIT_EFFECT (in place); unit slot b of the launch: bus + b * bus_unit_stride
   int32_t* bus_audible;   // input flag for UNIT_BUS (1 = audible input)
   PgSchedEntry* sched;    // [n_classes][2 banks]; nullptr disables the schedule cache
   int32_t sched_bank;     // bank read by this launch; the representatives write bank ^ 1
@@ -310,6 +310,8 @@ struct PgLaunch {
   // chain behind a super-block launch sees every block's own flag. nullptr: not collected (standalone effects, bus launches).
   int32_t* audible_tab;
   uint64_t audible_stride;
+  uint64_t bus_unit_stride;  // floats between the external buffers of consecutive units of the launch (a standalone effect with more than two
+                             // channels runs one stereo unit per channel pair); 0 for the bus
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
 enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take

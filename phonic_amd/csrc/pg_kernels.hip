@@ -373,7 +373,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   if (FAST_ONLY && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
   bool fx0_fresh = FAST_ONLY && unit.n_fx > 0;  // the generic kernel applies commands to the global copy first
   const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
-  float* ext = L.bus + (size_t)chunk * 2 * (size_t)N;  // (a bus launch behind a super-block: block c of the summed bus)
+  float* ext = L.bus + (size_t)slot * L.bus_unit_stride + (size_t)chunk * 2 * (size_t)N;  // (a bus launch behind a super-block: block c of the summed bus)
   if (external) {
     for (int i = tid; i < 2 * N; i += nt) sig[i] = ext[i];
   } else {

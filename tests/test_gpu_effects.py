@@ -326,3 +326,59 @@ def test_parameter_updates_survive_empty_process_calls_and_long_queues():
             e_cpu.process(b[sl])
         check(a, b)
         assert not np.array_equal(a[1024:2048], x[1024:2048])
+
+
+@pytest.mark.parametrize("channels", [1, 3, 6])
+@pytest.mark.parametrize("kind,params,updates", [
+    (_capi.FX_GAIN, {"gain": 0.7, "dcfm": 2}, {1: [("gain", 2.0, False)], 3: [("dcfm", 3, False)]}),
+    (_capi.FX_FILTER, {"type": 0, "cuto": 1800.0, "fltq": 0.9}, {1: [("cuto", 6000.0, False)], 2: [("fltq", 2.5, False), ("type", 3, False)]}),
+    (_capi.FX_EQ5, {"gan1": 4.0, "gan3": -6.0}, {1: [("gan2", 9.0, False), ("frq4", 5000.0, False)], 3: [("bw_3", 0.7, False)]}),
+    (_capi.FX_DISTORTION, {"type": 0, "driv": 1.5, "mix ": 0.6}, {1: [("driv", 3.0, False)], 2: [("mix ", 1.0, False)], 4: [("type", 4, False)]}),
+])
+def test_channel_counts_other_than_stereo(kind, params, updates, channels):
+    """Filter, Eq5, Gain and Distortion process ANY channel count in the reference (filter.rs:144-201, eq5.rs:297-326, gain.rs:143-166,
+    distortion.rs:326-361): channels are independent, the smoothers step once per frame. Mono, three and six channels (an odd count leaves a
+    half-filled channel pair), each channel with its own signal, parameter ramps that start mid-run, ragged and empty blocks — against the oracle's
+    N-channel loops. The stereo-only effects keep the reference's error for anything but two channels (e.g. reverb.rs:399-403)."""
+    import phonic_amd
+
+    sizes = [256, 1, 0, 511, 1024, 300]
+    rng = np.random.default_rng(100 * kind + channels)
+    x = (0.3 * rng.standard_normal(sum(sizes) * channels)).astype(np.float32)
+    for c in range(channels):
+        x[c::channels] *= np.float32(0.4 + 0.3 * c)          # (and a DC offset on one channel: the Gain's DC filter has something to remove)
+    x[0::channels] += np.float32(0.05)
+    e_gpu, e_cpu = phonic_amd.Effect(kind, params), oracle.OracleEffect(kind, params)
+    outs = []
+    for e in (e_gpu, e_cpu):
+        e.initialize(SR, channels, 1024)
+        y, off = x.copy(), 0
+        for blk, n in enumerate(sizes):
+            for (id4, val, norm) in updates.get(blk, []):
+                e.set_parameter(id4, val, norm)
+            e.process(y[off:off + n * channels])
+            off += n * channels
+        outs.append(y)
+    check(outs[0], outs[1])
+    assert not np.array_equal(outs[0], x)
+    for c in range(1, channels):
+        assert not np.array_equal(outs[0][c::channels], outs[0][0::channels])         # every channel carries its own audio
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        e_gpu.process(np.zeros(channels * 1024 + channels, np.float32))                 # more than max_frames
+    assert ei.value.code == _capi.PG_ERR_PARAMETER
+    if channels > 1:
+        with pytest.raises(phonic_amd.PhonicError):
+            e_gpu.process(np.zeros(channels + 1, np.float32))                           # not a whole number of frames
+
+
+def test_stereo_only_effects_reject_other_channel_counts():
+    import phonic_amd
+
+    for kind in (_capi.FX_PANNING, _capi.FX_DELAY, _capi.FX_REVERB, _capi.FX_CHORUS, _capi.FX_COMPRESSOR, _capi.FX_GATE):
+        for ch in (1, 3):
+            with pytest.raises(phonic_amd.PhonicError) as ei:
+                phonic_amd.Effect(kind).initialize(SR, ch, 1024)
+            assert ei.value.code == _capi.PG_ERR_PARAMETER and "only supports stereo I/O" in str(ei.value)
+    for kind in (_capi.FX_GAIN, _capi.FX_FILTER, _capi.FX_EQ5, _capi.FX_DISTORTION):
+        with pytest.raises(phonic_amd.PhonicError):
+            phonic_amd.Effect(kind).initialize(SR, 0, 1024)
