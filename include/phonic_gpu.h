@@ -213,6 +213,25 @@ int pg_graph_move_effect(pg_graph* g, int effect_id, int mixer_id, int movement,
 int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels,
                        uint32_t src_rate, const pg_voice_options* opt);
 
+/* Player::play_synth_source / any `dyn Source` (MixerMessage::AddSource{source: Box<dyn Source>}, src/source/mixed.rs:117-123;
+ * SynthSourceImpl, src/source/synth/common.rs:194-263; streamed files): a source whose samples the HOST produces. The voice is a ring
+ * of `capacity_frames` frames (>= 1024) in device memory at the source's own `rate` and channel count (1 or 2); the host keeps it filled
+ * with what it pulls from its source (pg_graph_feed_voice), the device reads it where a file voice reads its preloaded buffer, behind
+ * the same adapter chain: ResampledSource when `rate` is not the mixer's (src/source/converted.rs:15-45, 512-frame staging), mono ->
+ * stereo, volume, panning, start time (`opt`: volume, panning, start_time are used). A short ring read is a source that delivered
+ * less (the rest of the block is silent); the voice ends when the host has ended the stream and everything fed has been played, or
+ * at a stop. Device ring and pinned staging ring are reserved here: feed and write allocate nothing. Returns a voice id >= 0 (valid
+ * for set_voice_volume / _panning / stop_voice like any other). Units holding such a voice render on the exact serial kernel. */
+int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt);
+/* The next n_frames frames of the host's source (interleaved). Owner thread, before the write that should play them; they reach the
+ * device on that write's stream. PG_ERR_QUEUE_FULL (nothing taken) when fed - consumed + n_frames would exceed the capacity, with
+ * `consumed` as last reported by pg_graph_stream_voice_consumed. */
+int pg_graph_feed_voice(pg_graph* g, int voice_id, const float* frames, size_t n_frames);
+/* Source::is_exhausted (src/source.rs:88-93): nothing more will be fed. */
+int pg_graph_end_stream_voice(pg_graph* g, int voice_id);
+/* Frames of the stream the device has read so far (waits for the graph's work; negative on failure): frees that much ring for feeds. */
+int64_t pg_graph_stream_voice_consumed(pg_graph* g, int voice_id);
+
 /* EffectHandle::set_parameter((id, update), sample_time) (src/player/handles/effect.rs:67-95) */
 int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized,
                             uint64_t sample_time);
@@ -250,12 +269,19 @@ size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64
  * call's start — and from every main-mixer event that falls inside the call — in steps of max_frames, exactly as MixedSource::write counts
  * them; a caller that wants the chunk grid of a block-by-block pull puts its events on call boundaries or pulls block by block.
  * (pg_graph_write with a host buffer hands the graph at most n_blocks x max_frames frames per call and loops over longer buffers.) */
+/* A unit that leaves the steady state while a super-block launch is in flight (the host only launches them for graphs it knows to be
+ * steady: this is a consistency violation, PG_DEVERR_SUPER_DEFERRED) would miss its later blocks: the kernels mirror that flag to the host
+ * and the NEXT write*() call disables the graph (returns 0 from then on, pg_last_error_message names the flag) — wrong audio is never
+ * handed out twice; pg_graph_device_errors reports the flag at any time. */
 int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks);
 /* Process-wide counters of the library's own HIP calls: out[0] = allocations (hipMalloc / hipHostMalloc), out[1] = releases, out[2] = host
  * waits for a stream (hipStreamSynchronize), out[3] = blocking copies / fills. The reference runs its audio callback under
  * assert_no_alloc (src/output/cpal.rs:712-715); with these counters a test asserts the same of pg_graph_write*: on a built graph it
  * allocates nothing and frees nothing, and on a caller's stream it never blocks the host. */
 void pg_debug_hip_calls(uint64_t out[4]);
+/* Test hook: the nth launch round from now (process-wide, any graph) fails the way a HIP launch failure does — the graph it hits becomes
+ * silent for good: write returns 0, like the reference's GuardedSource after a panic (src/source/guarded.rs:87-107). 0 disarms. */
+void pg_debug_fail_launch_round(int nth);
 /* Sticky consistency flags raised by the kernels (0 = none; see PG_DEVERR_* in phonic_amd/csrc/pg_dev.h): conditions the host-side
  * routing of units to kernel variants must make impossible. Synchronises the graph's own stream. Negative pg_status on failure. */
 int pg_graph_device_errors(pg_graph* g);

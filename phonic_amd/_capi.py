@@ -289,6 +289,16 @@ def load():
     lib.pg_sharded_write.argtypes = [vp, P(C.c_float), C.c_size_t, C.c_uint64]
     lib.pg_sharded_write_device.restype = C.c_size_t
     lib.pg_sharded_write_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64]
+    lib.pg_graph_add_stream_voice.restype = C.c_int
+    lib.pg_graph_add_stream_voice.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, P(VoiceOptions)]
+    lib.pg_graph_feed_voice.restype = C.c_int
+    lib.pg_graph_feed_voice.argtypes = [vp, C.c_int, P(C.c_float), C.c_size_t]
+    lib.pg_graph_end_stream_voice.restype = C.c_int
+    lib.pg_graph_end_stream_voice.argtypes = [vp, C.c_int]
+    lib.pg_graph_stream_voice_consumed.restype = C.c_int64
+    lib.pg_graph_stream_voice_consumed.argtypes = [vp, C.c_int]
+    lib.pg_debug_fail_launch_round.restype = None
+    lib.pg_debug_fail_launch_round.argtypes = [C.c_int]
     lib.pg_debug_hip_calls.restype = None
     lib.pg_debug_hip_calls.argtypes = [P(C.c_uint64)]
     lib.pg_graph_device_errors.restype = C.c_int

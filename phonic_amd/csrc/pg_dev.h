@@ -186,6 +186,11 @@ struct PgVoice {
   uint32_t in_start, in_end, out_start, out_end;  // TempBuffer ranges (samples)
   float* stage_in;   // device memory: 512 * channels floats each
   float* stage_out;
+  // Host-fed source (pg_graph_add_stream_voice): `pcm` is a device ring of stream_cap frames that the host fills (pg_graph_feed_voice),
+  // playback_pos counts the frames read; stream_fed = frames fed so far, bit 63 = the host has ended the stream
+  int32_t stream_on;
+  uint32_t stream_cap;
+  uint64_t stream_fed;
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.

@@ -29,6 +29,8 @@ hipError_t pg_stream_sync(hipStream_t s) { g_n_sync++; return hipStreamSynchroni
 hipError_t pg_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { g_n_blocking_copy++; return hipMemcpy(d, s, n, k); }
 hipError_t pg_memset(void* d, int v, size_t n) { g_n_blocking_copy++; return hipMemset(d, v, n); }
 
+// Test hook (pg_debug_fail_launch_round): the n-th launch round from now fails as if a HIP launch had — exercises the sticky failed state
+static std::atomic<int> g_fail_round_countdown{0};
 static int graph_fail(pg_graph* g, int code) { g->failed = true; return code; }
 
 // Calls that change the graph (add_* / remove_* / move_* / mode switches) are not real-time calls: they first wait for everything the
@@ -110,7 +112,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     if (!mx.children.empty()) { u.static_defer = 1; u.staged = 0; }  // sums its sub-mixers' rows first: exact serial kernel
-    for (int v : mx.voices) if (g->voices[v].outer) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging: exact serial kernel
+    for (int v : mx.voices) if (g->voices[v].outer || g->voices[v].stream) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging / host-fed ring: exact serial kernel
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
@@ -142,7 +144,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
     u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
-    u.static_defer = g->voices[v].outer ? 1 : 0;
+    u.static_defer = (g->voices[v].outer || g->voices[v].stream) ? 1 : 0;
     u.voice0 = g->voices[v].dev_index;
     vidx.push_back(g->voices[v].dev_index);
     g->order.push_back(slot);
@@ -272,7 +274,8 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   (void)pg_memset(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int));
   if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
-    *g->h_feedback = ~0ull;  // nothing reported yet
+    g->h_feedback[0] = ~0ull;  // nothing reported yet
+    g->h_feedback[1] = 0; g->h_feedback[2] = 0;  // [1] status word (graph_enqueue_status), [2] consistency flags the kernels mirror here
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
   g->mixers.emplace_back();
@@ -288,7 +291,7 @@ void pg_graph_destroy(pg_graph* g) {
   (void)hipSetDevice(g->device);
   (void)pg_stream_sync(g->stream);
   if (g->last_stream && g->last_stream != g->stream) (void)pg_stream_sync(g->last_stream);
-  for (auto& v : g->voices) { if (v.d_pcm) (void)pg_free(v.d_pcm); if (v.d_stage) (void)pg_free(v.d_stage); }
+  for (auto& v : g->voices) { if (v.d_pcm) (void)pg_free(v.d_pcm); if (v.d_stage) (void)pg_free(v.d_stage); if (v.h_ring) (void)pg_host_free(v.h_ring); }
   for (auto& f : g->fx) if (f->d_mem) (void)pg_free(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
   g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release(); g->d_topo.release();
@@ -541,7 +544,7 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   int rc = g->d_voices.push(v, &dev_index);
   if (rc) return -graph_fail(g, rc);
   int id = (int)g->voices.size();
-  g->voices.push_back(HostVoice{mixer_id, dev_index, opt->start_time, d_pcm, d_stage, inner_rate != g->sample_rate});
+  { HostVoice hv; hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_pcm; hv.d_stage = d_stage; hv.outer = inner_rate != g->sample_rate; g->voices.push_back(hv); }
   g->source_unit_of_voice.push_back(-1);
   // AddSource: sort by start time, insert BEFORE equal start times (mixed.rs:324-329)
   HostMixer& mx = g->mixers[mixer_id];
@@ -559,6 +562,118 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   g->topo_dirty = true;
   if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
   return id;
+}
+
+// ---- host-fed sources ------------------------------------------------------------------------------------------------------------
+// The mixer takes any `Box<dyn Source>` (MixerMessage::AddSource, src/source/mixed.rs:117-123): synth sources (SynthSourceImpl,
+// src/source/synth/common.rs:194-263), streamed files, generators. Such a source lives on the host; to sit inside a GPU (sub-)mixer
+// its output has to reach the device. A stream voice is the device half: a ring of `capacity_frames` frames in device memory that the
+// host fills with what it pulled from its source (pg_graph_feed_voice, at the source's own rate and channel count), read by
+// stream_source_write where a file voice reads its preloaded buffer; behind it the same adapter chain as for any source —
+// ResampledSource when the rate is not the mixer's (src/source/converted.rs:15-45), mono -> stereo, AmplifiedSource, PannedSource
+// (src/player.rs:540-558). All memory (device ring, pinned staging ring) is reserved here; feed and write allocate nothing.
+int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt) {
+  if (mixer_id < 0 || mixer_id >= (int)g->mixers.size() || g->mixers[mixer_id].removed) return -set_error(PG_ERR_NOT_FOUND, "Mixer with id %d not found", mixer_id);
+  if (rate == 0) return -set_error(PG_ERR_PARAMETER, "source sample rate must be > 0");
+  if (channels != 1 && channels != 2) return -set_error(PG_ERR_PARAMETER, "only mono and stereo sources are supported");
+  if (capacity_frames < 1024 || capacity_frames > (1u << 30)) return -set_error(PG_ERR_PARAMETER, "ring capacity must be in 1024..=2^30 frames");
+  drain_control_messages(g);
+  pg_voice_options def;
+  if (!opt) { pg_voice_options_default(&def); opt = &def; }
+  if (opt->volume < 0.0f || opt->panning < -1.0f || opt->panning > 1.0f) return -set_error(PG_ERR_PARAMETER, "invalid volume or panning");
+  if (graph_quiesce(g)) return -graph_fail(g, PG_ERR_DEVICE);
+  PgVoice v;
+  memset(&v, 0, sizeof v);
+  const size_t ring_floats = capacity_frames * channels;
+  void* d_ring = nullptr;
+  float* h_ring = nullptr;
+  if (pg_malloc(&d_ring, ring_floats * sizeof(float)) != hipSuccess || pg_memset(d_ring, 0, ring_floats * sizeof(float)) != hipSuccess ||
+      pg_host_malloc((void**)&h_ring, ring_floats * sizeof(float), hipHostMallocDefault) != hipSuccess)
+    return -graph_fail(g, set_error(PG_ERR_DEVICE, "ring allocation failed"));
+  v.pcm = (const float*)d_ring;
+  v.channels = channels; v.src_rate = rate; v.out_rate = rate; v.ratio = 1.0f;
+  v.stream_on = 1; v.stream_cap = (uint32_t)capacity_frames; v.stream_fed = 0;
+  v.fader_state = 0; v.fader_current = 1.0f; v.fader_target = 1.0f; v.fader_inertia = 1.0f;
+  ParamSpec exp_spec = {0, PG_PARAM_FLOAT, 0, 0, 0, 0, 0, 0, 0, "", S_EXP, 0};
+  v.volume = make_smooth(exp_spec, opt->volume, g->sample_rate);
+  v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
+  v.start_time = opt->start_time;
+  v.active = 1;
+  v.current_speed = 1.0; v.target_speed = 1.0;
+  v.sched_class = -1;
+  void* d_stage = nullptr;
+  if (rate != g->sample_rate) {  // ConvertedSource::new -> ResampledSource::new(source, mixer rate, Default)  (converted.rs:15-45, resampled.rs:44-98)
+    v.outer_on = 1;
+    v.outer_ratio = (float)((double)rate / (double)g->sample_rate);
+    const size_t stage_floats = 2 * 512 * (size_t)channels;
+    if (pg_malloc(&d_stage, stage_floats * sizeof(float)) != hipSuccess || pg_memset(d_stage, 0, stage_floats * sizeof(float)) != hipSuccess)
+      return -graph_fail(g, set_error(PG_ERR_DEVICE, "hipMalloc(staging) failed"));
+    v.stage_in = (float*)d_stage; v.stage_out = v.stage_in + 512 * channels;
+  }
+  int dev_index = -1;
+  int rc = g->d_voices.push(v, &dev_index);
+  if (rc) return -graph_fail(g, rc);
+  const int id = (int)g->voices.size();
+  HostVoice hv;
+  hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_ring; hv.d_stage = d_stage; hv.outer = rate != g->sample_rate;
+  hv.stream = true; hv.h_ring = h_ring; hv.channels = channels; hv.cap_frames = capacity_frames;
+  g->voices.push_back(hv);
+  g->stream_voices.push_back(id);
+  g->source_unit_of_voice.push_back(-1);
+  HostMixer& mx = g->mixers[mixer_id];
+  size_t pos = 0;
+  while (pos < mx.voices.size() && g->voices[mx.voices[pos]].start_time < opt->start_time) ++pos;
+  mx.voices.insert(mx.voices.begin() + pos, id);
+  if (mixer_id == 0) {
+    int slot = new_unit(g, UNIT_SOURCE);
+    if (slot < 0) return -graph_fail(g, PG_ERR_DEVICE);
+    g->source_unit_of_voice[id] = slot;
+    g->main_active_voices += 1;
+    g->ever_had_main_voice = true;
+  }
+  if (!g->voice_alive_tab.append(1)) return -set_error(PG_ERR_STATE, "too many voices");
+  g->topo_dirty = true;
+  if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
+  return id;
+}
+static HostVoice* stream_voice(pg_graph* g, int voice_id) {
+  if (voice_id < 0 || voice_id >= (int)g->voices.size() || !g->voices[voice_id].stream) { set_error(PG_ERR_NOT_FOUND, "Source with id %d is not a host-fed source", voice_id); return nullptr; }
+  return &g->voices[voice_id];
+}
+// The next `n_frames` frames of the host's source (interleaved, the voice's channel count) -> the pinned staging ring; they travel to the
+// device ring at the top of the next write, on that write's stream. Owner thread only. PG_ERR_QUEUE_FULL (nothing taken) when the ring
+// has no room for all of them: room = capacity - (fed - consumed), `consumed` as last reported by pg_graph_stream_voice_consumed.
+int pg_graph_feed_voice(pg_graph* g, int voice_id, const float* frames, size_t n_frames) {
+  HostVoice* hv = stream_voice(g, voice_id);
+  if (!hv) return PG_ERR_NOT_FOUND;
+  if (hv->ended) return set_error(PG_ERR_STATE, "the stream has been ended");
+  if (n_frames == 0) return PG_OK;
+  if (!frames) return set_error(PG_ERR_PARAMETER, "no frames");
+  if (hv->fed - hv->consumed_known + n_frames > hv->cap_frames) return set_error(PG_ERR_QUEUE_FULL, "the source's ring is full");
+  const size_t C = hv->channels, w0 = (size_t)(hv->fed % hv->cap_frames), first = std::min(n_frames, hv->cap_frames - w0);
+  memcpy(hv->h_ring + w0 * C, frames, first * C * sizeof(float));
+  if (first < n_frames) memcpy(hv->h_ring, frames + first * C, (n_frames - first) * C * sizeof(float));
+  hv->fed += n_frames;
+  return PG_OK;
+}
+// The host's source is exhausted (Source::is_exhausted, src/source.rs:88-93): the voice ends when everything fed has been played.
+int pg_graph_end_stream_voice(pg_graph* g, int voice_id) {
+  HostVoice* hv = stream_voice(g, voice_id);
+  if (!hv) return PG_ERR_NOT_FOUND;
+  hv->ended = true;
+  return PG_OK;
+}
+// Frames of the fed stream the device has read so far (waits for the graph's stream; -1 on failure). Frees that much room for feeds.
+int64_t pg_graph_stream_voice_consumed(pg_graph* g, int voice_id) {
+  HostVoice* hv = stream_voice(g, voice_id);
+  if (!hv) return -1;
+  (void)hipSetDevice(g->device);
+  if (pg_stream_sync(g->stream) != hipSuccess || (g->last_stream && g->last_stream != g->stream && pg_stream_sync(g->last_stream) != hipSuccess)) return -1;
+  if (graph_flush_blocking(g)) return -1;
+  uint64_t rd = 0;
+  if (pg_memcpy(&rd, (const char*)(g->d_voices.d + hv->dev_index) + offsetof(PgVoice, playback_pos), 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  hv->consumed_known = rd;
+  return (int64_t)rd;
 }
 
 // ---- control calls: any thread, concurrently with write() ------------------------------------------------------------------
@@ -691,6 +806,7 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
   g->topo_dirty = true;
   return graph_reserve(g);  // the per-unit output table grows here, never inside write
 }
+void pg_debug_fail_launch_round(int nth) { g_fail_round_countdown.store(nth > 0 ? nth : 0); }
 void pg_debug_hip_calls(uint64_t out[4]) {
   out[0] = g_n_alloc.load(); out[1] = g_n_free.load(); out[2] = g_n_sync.load(); out[3] = g_n_blocking_copy.load();
 }
@@ -824,11 +940,14 @@ static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream
   return PG_OK;
 }
 
+
 // One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
 // n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok(). The `audible` word of block c of the round goes to
 // d_audible[audible_slot + c] (the bus chain's audible_input; in defer_bus mode the caller reads the words of a whole write call).
 static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1,
                         int audible_slot = 0) {
+  if (g_fail_round_countdown.load(std::memory_order_relaxed) > 0 && g_fail_round_countdown.fetch_sub(1) == 1)
+    return set_error(PG_ERR_DEVICE, "injected device failure (pg_debug_fail_launch_round)");
   const PgCmd* d_cmds = nullptr;
   if (!cmds.empty()) { int rc = stage_commands(g, cmds, stream, &d_cmds); if (rc) return rc; }
   PgLaunch L;
@@ -921,6 +1040,30 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
 }  // extern "C"
 
 // MixedSource::write of the main mixer (src/source/mixed.rs:659-719)
+// What the host fed since the last write -> the device rings (one or two copies per voice from its pinned ring), then the voice's
+// `stream_fed` word; asynchronous on the write's stream, in front of the kernels that read them.
+__global__ void pg_store_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
+static int flush_stream_feeds(pg_graph* g, hipStream_t stream) {
+  for (int id : g->stream_voices) {
+    HostVoice& hv = g->voices[id];
+    if (hv.mixer < 0 || (hv.sent == hv.fed && hv.ended == hv.ended_sent)) continue;
+    const size_t C = hv.channels;
+    uint64_t a = hv.sent;
+    while (a < hv.fed) {
+      const size_t off = (size_t)(a % hv.cap_frames), n = (size_t)std::min<uint64_t>(hv.fed - a, hv.cap_frames - off);
+      HIP_TRY(hipMemcpyAsync((float*)hv.d_pcm + off * C, hv.h_ring + off * C, n * C * sizeof(float), hipMemcpyHostToDevice, stream));
+      a += n;
+    }
+    // the new count travels BY VALUE (a kernel argument): a word in pinned memory could be overwritten by the next feed before an earlier
+    // write's copy of it has run, and tell the device about frames whose data is still on its way
+    hipLaunchKernelGGL(pg_store_u64_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long*)((char*)(g->d_voices.d + hv.dev_index) + offsetof(PgVoice, stream_fed)),
+                       (unsigned long long)(hv.fed | (hv.ended ? (1ull << 63) : 0ull)));
+    HIP_TRY(hipGetLastError());
+    hv.sent = hv.fed; hv.ended_sent = hv.ended;
+  }
+  return PG_OK;
+}
+
 // `begin`: this call opens a write of the main mixer (process_messages first, mixed.rs:659-661). The sharded handle renders one write
 // as several calls — one per run of frames between two main-mixer events of ANY shard — and opens it itself (graph_begin_write on
 // every shard, then begin = false), so that all shards cut their rounds at the same frames as the one main mixer would.
@@ -956,6 +1099,13 @@ void graph_collect_status(pg_graph* g) {
 
 size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin) {
   if (g->failed) return 0;
+  // a consistency flag the kernels mirrored into the mapped feedback block (a unit left unrendered inside a super-block launch): what was
+  // handed out since is not trustworthy — the graph goes silent like a GuardedSource whose source panicked (src/source/guarded.rs:87-107)
+  if (g->h_feedback && *(volatile unsigned long long*)(g->h_feedback + 2) != 0) {
+    g->failed = true;
+    set_error(PG_ERR_DEVICE, "kernel consistency flag %llu raised (see pg_graph_device_errors): the graph is disabled", *(volatile unsigned long long*)(g->h_feedback + 2));
+    return 0;
+  }
   if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   (void)hipSetDevice(g->device);
   // a caller that moves from one stream to another without a graph mutation in between: the tables and rings are ordered per stream
@@ -963,6 +1113,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   g->last_stream = stream;
   if (begin) graph_begin_write(g, pos);
   if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
+  if (!g->stream_voices.empty() && flush_stream_feeds(g, stream)) { g->failed = true; return 0; }
   if (graph_is_empty(g)) return 0;
   const uint64_t frames = n_samples / 2;
   uint64_t done = 0;

@@ -100,11 +100,18 @@ struct DeviceVec {
 
 // Table rebuilt from the host mirror at every topology change: capacity is reserved by the mutating calls (reserve: may allocate),
 // the contents travel with ONE asynchronous copy from pinned staging inside write (upload_async: never allocates).
+// A rebuild can also happen inside write WITHOUT a mutating call (and its wait) in front of it — a control message switched a Gain's DC
+// filter on, stop_all_voices dropped sources (round-2 advisor finding) — so an upload may follow the previous one while that one's
+// asynchronous copy has not run yet: the pinned staging alternates between two halves, and a half is only rewritten once the event
+// recorded behind its last copy has passed (waited for in the rare case it has not).
 template <class T>
 struct DeviceTable {
   T* d = nullptr;
-  T* h = nullptr;  // pinned staging, same capacity
+  T* h = nullptr;  // pinned staging: two halves of `cap` elements
   size_t n = 0, cap = 0;
+  int turn = 0;
+  hipEvent_t copied[2] = {nullptr, nullptr};
+  bool in_flight[2] = {false, false};
   int reserve(size_t want) {
     if (want <= cap) return PG_OK;
     size_t ncap = std::max<size_t>(want, cap ? cap * 2 : 64);
@@ -112,20 +119,31 @@ struct DeviceTable {
     if (h) (void)pg_host_free(h);
     d = nullptr; h = nullptr; cap = 0;
     HIP_TRY(pg_malloc((void**)&d, ncap * sizeof(T)));
-    HIP_TRY(pg_host_malloc((void**)&h, ncap * sizeof(T), hipHostMallocDefault));
+    HIP_TRY(pg_host_malloc((void**)&h, 2 * ncap * sizeof(T), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) { if (!copied[i]) HIP_TRY(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming)); in_flight[i] = false; }  // (the mutating call drained the streams)
     cap = ncap;
     return PG_OK;
   }
   int upload_async(const std::vector<T>& v, hipStream_t s) {
     if (v.size() > cap) return set_error(PG_ERR_STATE, "device table capacity was not reserved by the mutating call");
     if (!v.empty()) {
-      memcpy(h, v.data(), v.size() * sizeof(T));
-      HIP_TRY(hipMemcpyAsync(d, h, v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+      T* half = h + (size_t)turn * cap;
+      if (in_flight[turn] && hipEventQuery(copied[turn]) != hipSuccess) HIP_TRY(hipEventSynchronize(copied[turn]));
+      memcpy(half, v.data(), v.size() * sizeof(T));
+      HIP_TRY(hipMemcpyAsync(d, half, v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipEventRecord(copied[turn], s));
+      in_flight[turn] = true;
+      turn ^= 1;
     }
     n = v.size();
     return PG_OK;
   }
-  void release() { if (d) (void)pg_free(d); if (h) (void)pg_host_free(h); d = nullptr; h = nullptr; n = cap = 0; }
+  void release() {
+    if (d) (void)pg_free(d);
+    if (h) (void)pg_host_free(h);
+    for (int i = 0; i < 2; ++i) { if (copied[i]) (void)hipEventDestroy(copied[i]); copied[i] = nullptr; in_flight[i] = false; }
+    d = nullptr; h = nullptr; n = cap = 0;
+  }
 };
 
 static inline size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
@@ -161,7 +179,16 @@ struct Event {  // MixerEvent (src/source/mixed.rs:47-109) resolved to a device 
   int mixer;  // owning mixer (0 = main)
 };
 
-struct HostVoice { int mixer; int dev_index; uint64_t start_time; void* d_pcm; void* d_stage; bool outer; };
+struct HostVoice {
+  int mixer; int dev_index; uint64_t start_time; void* d_pcm; void* d_stage; bool outer;
+  // host-fed source (pg_graph_add_stream_voice): pinned ring + word the feeds are staged in, device ring = d_pcm
+  bool stream = false, ended = false, ended_sent = false;
+  float* h_ring = nullptr;         // pinned: [cap_frames * channels] floats
+  uint32_t channels = 0;
+  size_t cap_frames = 0;
+  uint64_t fed = 0, sent = 0;      // frames accepted from the host / frames whose copy to the device ring has been enqueued
+  uint64_t consumed_known = 0;     // frames the device is known to have read (pg_graph_stream_voice_consumed): bounds what may be overwritten
+};
 struct HostMixer {
   int unit_slot = -1;              // sub-mixer unit; for the main mixer: the bus unit
   std::vector<int> voices;         // voice ids in playing order (sorted by start time, insert-before-equal)
@@ -211,6 +238,7 @@ struct pg_graph {
   // host mirrors
   std::vector<HostMixer> mixers;        // [0] = main
   std::vector<HostVoice> voices;
+  std::vector<int> stream_voices;       // ids of the host-fed voices (their feeds are flushed at the top of every write)
   std::vector<std::unique_ptr<HostFx>> fx;
   std::vector<int> fx_mixer;            // effect id -> mixer id
   std::vector<int> source_unit_of_voice;  // main-mixer voices: unit slot

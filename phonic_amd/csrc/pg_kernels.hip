@@ -23,6 +23,14 @@
 
 using namespace pgd;
 
+// A unit wanted the generic kernel inside a super-block launch: its later blocks stay unrendered. The sticky device word keeps the flag
+// for pg_graph_device_errors; the copy in the host-mapped feedback block lets the next write see it WITHOUT a synchronisation of its own and
+// fail the graph (GuardedSource semantics) instead of handing out wrong audio silently.
+__device__ __forceinline__ void pg_raise_super_deferred(const PgLaunch& L) {
+  if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED);
+  if (L.host_feedback) { *(volatile unsigned long long*)(L.host_feedback + 2) = (unsigned long long)PG_DEVERR_SUPER_DEFERRED; __threadfence_system(); }
+}
+
 // ---- parameter updates (Effect::process_parameter_update of each effect), lane 0 --------------------
 // Returns 1 when the whole workgroup must flush state afterwards (compressor look-ahead line re-created).
 // aux: time-constant coefficients the HOST computed for this update (pg_host.hip: fx_param_aux) — exp(-1 / (t * fs)) sits within 1e-5 of one, where a
@@ -354,7 +362,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       int ok = !(unit.static_defer || unit.maybe_ramping);
       for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
       unit.deferred = ok ? 0 : 1;
-      if (!ok && L.n_chunks > 1) { if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED); }  // nobody renders the later blocks of this unit
+      if (!ok && L.n_chunks > 1) pg_raise_super_deferred(L);  // nobody renders the later blocks of this unit
       else if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
       ctl[5] = ok;
     }
@@ -649,7 +657,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     int ok = !(unit.static_defer || unit.maybe_ramping);
     for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;
     unit.deferred = ok ? 0 : 1;
-    if (!ok && L.n_chunks > 1) { if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED); }
+    if (!ok && L.n_chunks > 1) pg_raise_super_deferred(L);
     else if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
     ctl[5] = ok;
   }

@@ -543,6 +543,34 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
   return wf;
 }
 
+// Source::write of a host-fed source (any `dyn Source` the host pulls itself — a synth, a streamed file — src/source.rs:80-110,
+// src/source/synth/common.rs:194-263): the next frames of the device ring the host keeps filled, as many as are there (a short read is a
+// source that delivered less); exhausted once the host ended the stream and everything fed has been read. A stop ends it at once (the host's
+// own source fades before it ends its stream). `frames` frames of the source's channel layout into `out`; returns frames written.
+DEVO int stream_source_write(PgVoice* v, float* out, int frames, int pending_stop) {
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int C = (int)v->channels;
+  __syncthreads();
+  if (tid == 0 && pending_stop) v->finished = 1;
+  __syncthreads();
+  if (v->finished) return 0;
+  const uint64_t fed = v->stream_fed & 0x7fffffffffffffffull, rd = v->playback_pos;
+  const int ended = (int)(v->stream_fed >> 63);
+  const uint64_t avail = fed > rd ? fed - rd : 0;
+  const int n = (uint64_t)frames < avail ? frames : (int)avail;
+  const uint32_t cap = v->stream_cap, r0 = (uint32_t)(rd % (uint64_t)cap);
+  for (int i = tid; i < n * C; i += nt) {
+    const int f = C == 2 ? (i >> 1) : i, c = C == 2 ? (i & 1) : 0;
+    uint32_t p = r0 + (uint32_t)f;
+    if (p >= cap) p -= cap;
+    out[i] = v->pcm[(size_t)p * C + c];
+  }
+  __syncthreads();
+  if (tid == 0) { v->playback_pos = rd + (uint64_t)n; if (ended && rd + (uint64_t)n >= fed) v->finished = 1; }
+  __syncthreads();
+  return n;
+}
+
 // CubicInterpolator::process for ONE channel of interleaved staging buffers (cubic.rs:36-114): the exact serial recurrence, one lane.
 DEVO void outer_cubic_channel(PgVoice* v, int ch, int C, const float* in, int in_samples, float* out, int out_samples, int* consumed_samples, int* produced_samples) {
   const int num_in = in_samples / C, num_out = out_samples / C;
@@ -611,7 +639,8 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
         if (tid == 0) { v->in_start = 0; v->in_end = (uint32_t)cap; v->outer_pending_stop = 0; }
         __syncthreads();
         int post_on;
-        (void)file_source_write<true>(v, v->stage_in, 512, stop, S, nullptr, false, &post_on);
+        if (v->stream_on) (void)stream_source_write(v, v->stage_in, 512, stop);
+        else (void)file_source_write<true>(v, v->stage_in, 512, stop, S, nullptr, false, &post_on);
         __threadfence_block();
         __syncthreads();
       }
@@ -652,6 +681,8 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   int wf;
   if (GLIDE && v->outer_on) {  // (units holding such a voice always render on the generic kernel)
     wf = resampled_source_write(v, out, frames, pending_stop, S);
+  } else if (GLIDE && v->stream_on) {  // (likewise)
+    wf = stream_source_write(v, out, frames, pending_stop);
   } else {
     int post_on;
     wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on);

@@ -21,6 +21,28 @@ class Graph(GraphHandle):
         returns when the block is complete."""
         return self._lib.pg_graph_write_device(self._h, C.c_void_p(d_out_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0))
 
+    # -- host-fed sources (any `dyn Source` the host pulls itself) -------------------------------------
+    def add_stream_voice(self, mixer_id, channels, rate, capacity_frames, **opts):
+        o = _capi.default_voice_options(**opts)
+        v = self._id(self._lib.pg_graph_add_stream_voice(self._h, mixer_id, channels, rate, capacity_frames, C.byref(o)))
+        if not hasattr(self, "_stream_channels"):
+            self._stream_channels = {}
+        self._stream_channels[v] = channels
+        return v
+
+    def feed_voice(self, voice, frames):
+        """Interleaved float32 frames of the host's source; raises SendError (PG_ERR_QUEUE_FULL) when the ring has no room for all of them."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        ch = self._stream_channels.get(voice) if hasattr(self, "_stream_channels") else None
+        n = frames.size // (ch or 1)
+        self._check(self._lib.pg_graph_feed_voice(self._h, voice, frames.ctypes.data_as(C.POINTER(C.c_float)), n))
+
+    def end_stream_voice(self, voice):
+        self._check(self._lib.pg_graph_end_stream_voice(self._h, voice))
+
+    def stream_voice_consumed(self, voice):
+        return self._id(self._lib.pg_graph_stream_voice_consumed(self._h, voice))
+
     def set_max_blocks_per_launch(self, n_blocks):
         """Offline rendering: let one write call render up to `n_blocks` blocks of max_frames per launch sequence (steady state only)."""
         self._check(self._lib.pg_graph_set_max_blocks_per_launch(self._h, int(n_blocks)))

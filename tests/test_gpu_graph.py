@@ -1778,3 +1778,46 @@ def test_reverb_room_size_ramp_hands_the_rest_of_the_block_back_to_the_time_para
     compare(outs[0], outs[1])
     assert np.abs(outs[0][-2048:]).max() > 1e-3
     assert gg.device_errors() == 0 and gg.deferred_units() == 0
+
+
+def test_device_failure_makes_the_graph_silent_for_good():
+    """SURVEY §8b error convention: `write` is infallible in the reference — a panic inside it is caught once by GuardedSource, which returns 0
+    from then on (src/source/guarded.rs:87-107). Here a device failure inside write plays the panic's part: the failing call returns 0, the handle
+    stays failed (every later write returns 0 at once, nothing is launched), pg_last_error_message names the cause, and the control calls are
+    still accepted (a handle may outlive its source). Injected with pg_debug_fail_launch_round; the sharded handle fails as a whole when one
+    of its shards does; other graphs of the process are untouched."""
+    from phonic_amd.graph import Graph, ShardedGraph, hip_calls
+
+    lib = _capi.load()
+    N = 512
+
+    def build(g):
+        m = g.add_mixer()
+        fx = g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(9))
+        v = g.add_voice(m, workloads.tone_buffer(2, 44100, 0.2), 2, 44100, volume=0.5, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        return fx, v
+
+    g, healthy = Graph(SR, 2, N, 0), Graph(SR, 2, N, 0)
+    fx, v = build(g)
+    build(healthy)
+    out = np.zeros(2 * N, np.float32)
+    assert g.write(out, 0) == 2 * N and healthy.write(out, 0) == 2 * N
+    lib.pg_debug_fail_launch_round(2)
+    assert g.write(out, N) == 2 * N                          # the first round from now still runs
+    out[:] = 3.0
+    assert g.write(out, 2 * N) == 0                          # the second fails: 0, like a panicked GuardedSource
+    assert b"injected device failure" in lib.pg_last_error_message()
+    launches_before = hip_calls()
+    for b in range(3, 6):
+        assert g.write(out, b * N) == 0                      # ... and stays silent
+    assert hip_calls() == launches_before
+    g.schedule_param(fx, "room", 0.3, 10 * N)                 # handles keep working (messages are queued, never applied)
+    g.set_voice_volume(v, 0.1, 10 * N)
+    assert healthy.write(out, N) == 2 * N and np.abs(out).max() > 1e-4      # another graph is not affected
+    s = ShardedGraph([0, 0], SR, 2, N)
+    for _ in range(2):
+        build(s)
+    assert s.write(out, 0) == 2 * N
+    lib.pg_debug_fail_launch_round(2)                         # the second shard's round of the next write
+    assert s.write(out, N) == 0 and s.write(out, 2 * N) == 0
+    lib.pg_debug_fail_launch_round(0)

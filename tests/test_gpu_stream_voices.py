@@ -1,0 +1,154 @@
+"""Host-fed sources (pg_graph_add_stream_voice / pg_graph_feed_voice): any `dyn Source` the host pulls itself — a synth, a streamed file
+(MixerMessage::AddSource, src/source/mixed.rs:117-123; src/source/synth/common.rs:194-263) — inside a GPU mixer. The device reads the
+fed ring where a file voice reads its preloaded buffer, behind the same adapters (ResampledSource, mono -> stereo, volume, panning), so
+a fed voice must equal a preloaded voice holding the same PCM BIT FOR BIT; the preloaded path is the one held against the oracle."""
+import numpy as np
+import pytest
+
+import workloads
+from phonic_amd import _capi
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def graph(max_frames=1024):
+    from phonic_amd.graph import Graph
+
+    return Graph(SR, 2, max_frames, 0)
+
+
+def pcm_for(i, rate, seconds, channels):
+    return workloads.tone_buffer(i, rate, seconds, channels=channels)      # incl. the decoder's extra zero frame
+
+
+@pytest.mark.parametrize("channels,rate", [(2, 48000), (1, 48000), (2, 44100), (1, 32000), (2, 96000)])
+@pytest.mark.parametrize("feed", ["all_at_once", "just_in_time"])
+def test_fed_voice_equals_the_preloaded_voice_bit_for_bit(channels, rate, feed):
+    """A source in a sub-mixer (behind a Filter) and one on the main mixer, at the mixer's rate (plain ring reads) and at other rates (the
+    ResampledSource of src/source/converted.rs:15-45 pulls 512-frame chunks from the ring as it pulls them from a file source), mono and
+    stereo, ragged block sizes, a volume and a panning event, a late start time. Fed in one piece up front, or piecewise ahead of every
+    write. The comparison voice is preloaded with the same PCM and `source_rate` = its own rate (no embedded resampling: the same adapter chain)."""
+    sizes = [1024, 333, 1, 700, 1024, 64, 1024, 1024, 511, 1024] * 2
+    seconds = 0.25
+    bufs = [pcm_for(4, rate, seconds, channels), pcm_for(17, rate, seconds * 0.8, channels)]
+
+    def build(g, fed):
+        m = g.add_mixer()
+        g.add_effect(m, _capi.FX_FILTER, params={"cuto": 3000.0})
+        vs = []
+        for k, (mixer, start) in enumerate(((m, 0), (0, 1500))):
+            if fed:
+                vs.append(g.add_stream_voice(mixer, channels, rate, 65536, volume=0.7, panning=0.2 - 0.5 * k, start_time=start))
+            else:
+                vs.append(g.add_voice(mixer, bufs[k], channels, rate, volume=0.7, panning=0.2 - 0.5 * k, start_time=start, source_rate=rate, fade_out_seconds=-1.0))
+        return vs
+
+    outs = []
+    for fed in (True, False):
+        g = graph()
+        vs = build(g, fed)
+        cursor = [0, 0]
+        if fed and feed == "all_at_once":
+            for k in range(2):
+                g.feed_voice(vs[k], bufs[k])
+                g.end_stream_voice(vs[k])
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            if fed and feed == "just_in_time":
+                # ahead of every write: what n output frames can consume at this rate, the resampler's 512-frame read-ahead and a margin
+                want = int(np.ceil(n * rate / SR)) + 512 + 8
+                for k in range(2):
+                    total = bufs[k].size // channels
+                    have = cursor[k] - g.stream_voice_consumed(vs[k]) if cursor[k] else 0
+                    take = max(0, min(total - cursor[k], want - have))
+                    if take:
+                        g.feed_voice(vs[k], bufs[k][cursor[k] * channels:(cursor[k] + take) * channels])
+                        cursor[k] += take
+                        if cursor[k] == total:
+                            g.end_stream_voice(vs[k])
+            if b == 3:
+                g.set_voice_volume(vs[0], 0.3, pos + 100)
+                g.set_voice_panning(vs[1], -0.8, pos + 50)
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) in (0, 2 * n)
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+        assert g.device_errors() == 0
+    assert np.array_equal(outs[0], outs[1]), int(np.count_nonzero(outs[0] != outs[1]))
+    assert np.abs(outs[0]).max() > 1e-2
+    if rate == SR:    # (behind a ResampledSource an ended source leaves a stale input tail that the reference keeps resampling: never silent — and equal here too)
+        assert np.abs(outs[0][-2048:]).max() == 0.0
+
+
+def test_stream_voice_underrun_ring_full_stop_and_end():
+    """A short ring read is a source that delivered less: the rest of the block is silent and the voice carries on with the next feed; the ring
+    refuses a feed it has no room for (PG_ERR_QUEUE_FULL, nothing taken) until the device's progress has been collected; stop_voice ends the
+    stream voice; once ended and played out the main mixer has nothing left and write returns 0 (src/source/mixed.rs:664-670,715)."""
+    import phonic_amd
+
+    g = graph()
+    v = g.add_stream_voice(0, 2, SR, 2048)
+    tone = pcm_for(3, SR, 0.2, 2)[:-2]
+    out = np.zeros(2048, np.float32)
+    g.feed_voice(v, tone[:2 * 300])
+    assert g.write(out, 0) == 2048
+    assert np.array_equal(out[:600], tone[:600]) and np.all(out[600:] == 0.0)           # 300 frames were there, the rest of the block is silent
+    g.feed_voice(v, tone[2 * 300:2 * 1324])
+    assert g.write(out, 1024) == 2048
+    assert np.array_equal(out, tone[600:600 + 2048])                                      # ... and the voice carries on where it was
+    assert g.stream_voice_consumed(v) == 1324
+    g.feed_voice(v, tone[2 * 1324:2 * (1324 + 2048)])                                      # exactly the capacity
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        g.feed_voice(v, tone[:2])
+    assert ei.value.code == _capi.PG_ERR_QUEUE_FULL
+    assert g.write(out, 2048) == 2048 and np.array_equal(out, tone[2 * 1324:2 * 1324 + 2048])
+    with pytest.raises(phonic_amd.PhonicError):
+        g.feed_voice(v, tone[:2 * 1100])                                                    # still full: the host has not collected the progress
+    assert g.stream_voice_consumed(v) == 2348
+    g.feed_voice(v, tone[:2 * 1000])                                                        # room again (1024 frames were read)
+    g.stop_voice(v, 3072 + 10)
+    assert g.write(out, 3072) == 2048
+    assert np.array_equal(out[:20], tone[2 * 2348:2 * 2348 + 20]) and np.all(out[20:] == 0.0)     # stopped 10 frames into the block
+    assert not g.is_voice_playing(v)
+    assert g.write(out, 4096) == 0                                                          # nothing left to play
+    # a voice that is ended plays out what was fed, then the mixer is empty
+    v2 = g.add_stream_voice(0, 1, SR, 4096, start_time=5120)
+    g.feed_voice(v2, tone[0:1000:2].copy())
+    g.end_stream_voice(v2)
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        g.feed_voice(v2, tone[:10])
+    assert ei.value.code == _capi.PG_ERR_STATE
+    assert g.write(out, 5120) == 2048
+    assert np.array_equal(out[0:1000:2], tone[0:1000:2]) and np.array_equal(out[1:1000:2], tone[0:1000:2]) and np.all(out[1000:] == 0.0)
+    assert g.write(out, 6144) == 0
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        g.feed_voice(9999, tone[:2])
+    assert ei.value.code == _capi.PG_ERR_NOT_FOUND
+
+
+def test_feed_and_write_allocate_nothing():
+    """The rings are reserved by add_stream_voice; feeding copies into pinned memory, the write moves it with asynchronous copies on the caller's
+    stream: no allocation, no release, no host wait, no blocking copy (pg_debug_hip_calls)."""
+    import torch
+    from phonic_amd.graph import hip_calls
+
+    g = graph()
+    m = g.add_mixer()
+    g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(1))
+    v = g.add_stream_voice(m, 2, 44100, 1 << 16)
+    v2 = g.add_stream_voice(0, 1, SR, 1 << 16)
+    tone = pcm_for(6, 44100, 1.0, 2)
+    stream = torch.cuda.Stream()
+    bus = torch.zeros(2048, device="cuda:0")
+    g.feed_voice(v, tone[:2 * 4096]); g.feed_voice(v2, tone[:4096:2].copy())
+    assert g.write_device(bus.data_ptr(), 2048, 0, stream.cuda_stream) == 2048        # (the first write after a change uploads the topology)
+    before = hip_calls()
+    for b in range(1, 9):
+        g.feed_voice(v, tone[2 * 4096 * b // 4:2 * 4096 * (b + 1) // 4] if b < 3 else tone[:2 * 900])
+        g.feed_voice(v2, tone[:2000:2].copy())
+        assert g.write_device(bus.data_ptr(), 2048, b * 1024, stream.cuda_stream) == 2048
+    assert hip_calls() == before
+    stream.synchronize()
+    assert float(bus.abs().max()) > 1e-3 and g.device_errors() == 0
