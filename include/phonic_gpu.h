@@ -282,6 +282,9 @@ void pg_debug_hip_calls(uint64_t out[4]);
 /* Test hook: the nth launch round from now (process-wide, any graph) fails the way a HIP launch failure does — the graph it hits becomes
  * silent for good: write returns 0, like the reference's GuardedSource after a panic (src/source/guarded.rs:87-107). 0 disarms. */
 void pg_debug_fail_launch_round(int nth);
+/* Build check hook (tools/check_kernel_resources.py): dynamic LDS bytes of the staged single launch (which 0) / of a fast unit kernel for the
+ * effect kinds of kind_mask (which 1) at n_frames frames per block. */
+size_t pg_debug_lds_bytes(int which, uint32_t n_frames, uint32_t kind_mask);
 /* Sticky consistency flags raised by the kernels (0 = none; see PG_DEVERR_* in phonic_amd/csrc/pg_dev.h): conditions the host-side
  * routing of units to kernel variants must make impossible. Synchronises the graph's own stream. Negative pg_status on failure. */
 int pg_graph_device_errors(pg_graph* g);

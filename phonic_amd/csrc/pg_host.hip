@@ -806,6 +806,11 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
   g->topo_dirty = true;
   return graph_reserve(g);  // the per-unit output table grows here, never inside write
 }
+// dynamic LDS of the launches whose occupancy is budgeted (tools/check_kernel_resources.py): which 0 = the staged single launch, 1 = a fast unit
+// kernel for the effect kinds of `kind_mask`
+size_t pg_debug_lds_bytes(int which, uint32_t n_frames, uint32_t kind_mask) {
+  return which == 0 ? pg_stage_lds_bytes(0, n_frames) : pg_unit_lds_bytes(n_frames, pg_fast_scratch_bytes(kind_mask));
+}
 void pg_debug_fail_launch_round(int nth) { g_fail_round_countdown.store(nth > 0 ? nth : 0); }
 void pg_debug_hip_calls(uint64_t out[4]) {
   out[0] = g_n_alloc.load(); out[1] = g_n_free.load(); out[2] = g_n_sync.load(); out[3] = g_n_blocking_copy.load();

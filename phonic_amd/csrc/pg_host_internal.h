@@ -26,6 +26,8 @@ using namespace pgh;
 
 // ---- kernels' launchers (pg_kernels.hip) ----------------------------------------------------------------
 size_t pg_fast_scratch_bytes(uint32_t kind_mask);
+size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0);
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames);
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,

@@ -1031,7 +1031,7 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
   if (kind_mask & (1u << 8)) up(FAST_SCRATCH_GATE_BYTES);
   return need;
 }
-size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0) {
+size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes) {
   if (n_frames < PG_MIN_ROW_FRAMES) n_frames = PG_MIN_ROW_FRAMES;
   size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
   size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
