@@ -255,6 +255,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     int P = frames - p0 < 1024 ? frames - p0 : 1024;
     float* sp = sig + 2 * p0;
     __syncthreads();
+    PG_STAMP(fc.diag, 24);
     // 0. LFO phases (lfo.run() once per frame and oscillator, chorus.rs:353-354): one lane per oscillator lists the exact pieces; the piece
     // of the signal ends where the shorter of the two lists ends (a full table: only at phase increments far above the 10 Hz the rate allows)
     for (int pass = 0; pass < 2; ++pass) {
@@ -271,11 +272,13 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       P = covered;  // (second pass: both lists describe exactly P frames)
     }
     if (tid == 0 || tid == 64) c.osc[tid >> 6].phase = __uint_as_float((uint32_t)pctl[4 + (tid >> 6)]);
+    PG_STAMP(fc.diag, 25);
     // 1. pre-filter over the piece (svf.rs:211-222)
     for (int s = tid; s < 2 * P; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sp[s];
     __syncthreads();
     rev_biquad_scan(*lco, c.flt, buf, P, xchg);
     __syncthreads();
+    PG_STAMP(fc.diag, 26);
     // 2. chunks
     int done = 0;
     while (done < P) {
@@ -304,6 +307,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
         buf[bi] = (double)(float)buf[bi] + (double)out * (double)feedback;   // what this frame writes into the line
       }
       __syncthreads();
+      PG_STAMP(fc.diag, 27 + (done > 0 ? 2 : 0));
       for (int s = tid; s < 2 * T; s += nt) {
         const int nn = done + (s >> 1), ch = s & 1;
         ((gdouble*)c.line[ch])[(wp0[ch] + (uint32_t)(s >> 1)) & mask] = buf[REV_IDX(nn, ch)];
@@ -312,6 +316,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       __syncthreads();
       if (tid == 0) { c.write_pos[0] = (wp0[0] + (uint32_t)T) & mask; c.write_pos[1] = (wp0[1] + (uint32_t)T) & mask; }
       __syncthreads();
+      PG_STAMP(fc.diag, 28 + (done > 0 ? 2 : 0));
       done += T;
     }
     p0 += P;

@@ -30,6 +30,17 @@ def test_header_symbols_are_exported():
     assert not missing, missing
 
 
+def test_integration_md_declares_every_entry_point():
+    """INTEGRATION.md §2 claims one `pub fn` per entry point of the header (several were missing): the Rust `extern "C"` block
+    and the header must name exactly the same functions."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("\n}\n```")]
+    rust = set(re.findall(r"pub fn (pg_[a-z0-9_]+)\(", block))
+    header = set(declared_symbols())
+    assert rust == header, (sorted(header - rust), sorted(rust - header))
+
+
 def test_effect_descriptors_match_reference_constants():
     lib = _capi.load()
     names = [lib.pg_effect_kind_name(k).decode() for k in range(10)]
