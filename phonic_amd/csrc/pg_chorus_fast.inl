@@ -286,25 +286,42 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       if (T > t_max) T = t_max;
       const uint32_t wp0[2] = {c.write_pos[0], c.write_pos[1]};
       __syncthreads();
-      for (int s = tid; s < 2 * T; s += nt) {
-        const int nn = done + (s >> 1), ch = s & 1;
-        PgLfo l; l.phase = chorus_phase_at(rec + ch * CHORUS_PIECE_CAP, pctl[2 * ch], nn); l.phase_inc = 0.0f; l.waveform = c.osc[ch].waveform;
-        const float lfo = lfo_value(l);
-        const float delay_pos = 2.0f + delay_in_samples + (1.0f + lfo) * depth_in_samples;
-        const gdouble* line = (const gdouble*)c.line[ch];
-        const uint32_t wp = (wp0[ch] + (uint32_t)(s >> 1)) & mask;
-        const double read_pos = (double)wp - (double)delay_pos;
-        const double read_pos_floor = floor(read_pos);
-        const double fraction = read_pos - read_pos_floor;
-        const long long index1 = (long long)read_pos_floor;
-        const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
-        const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
-        if (fc.idx_log) fc.idx_log[(p0 + nn) * 2 + ch] = (int32_t)i1;  // test hook: read_idx1 (dsp/delay.rs:120-133)
-        const double v1 = line[i1], v2 = line[i2];
-        const float out = (float)(v1 + (v2 - v1) * fraction);
-        o32[2 * nn + ch] = out;
-        const int bi = REV_IDX(nn, ch);
-        buf[bi] = (double)(float)buf[bi] + (double)out * (double)feedback;   // what this frame writes into the line
+      // two (frame, channel) items per lane and trip: the four line taps of both are in flight together (a trip's loads used to wait for the
+      // previous trip's LDS stores: 4.5 dependent HBM round trips per chunk on a kernel that is a latency chain, profiles/r03_c3_stamps.txt)
+      for (int s0 = tid; s0 < 2 * T; s0 += 2 * nt) {
+        double v1[2], v2[2], fraction[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int s = s0 + k * nt;
+          v1[k] = 0.0; v2[k] = 0.0; fraction[k] = 0.0;
+          if (s < 2 * T) {
+            const int nn = done + (s >> 1), ch = s & 1;
+            PgLfo l; l.phase = chorus_phase_at(rec + ch * CHORUS_PIECE_CAP, pctl[2 * ch], nn); l.phase_inc = 0.0f; l.waveform = c.osc[ch].waveform;
+            const float lfo = lfo_value(l);
+            const float delay_pos = 2.0f + delay_in_samples + (1.0f + lfo) * depth_in_samples;
+            const gdouble* line = (const gdouble*)c.line[ch];
+            const uint32_t wp = (wp0[ch] + (uint32_t)(s >> 1)) & mask;
+            const double read_pos = (double)wp - (double)delay_pos;
+            const double read_pos_floor = floor(read_pos);
+            fraction[k] = read_pos - read_pos_floor;
+            const long long index1 = (long long)read_pos_floor;
+            const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+            const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+            if (fc.idx_log) fc.idx_log[(p0 + nn) * 2 + ch] = (int32_t)i1;  // test hook: read_idx1 (dsp/delay.rs:120-133)
+            v1[k] = line[i1]; v2[k] = line[i2];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int s = s0 + k * nt;
+          if (s < 2 * T) {
+            const int nn = done + (s >> 1), ch = s & 1;
+            const float out = (float)(v1[k] + (v2[k] - v1[k]) * fraction[k]);
+            o32[2 * nn + ch] = out;
+            const int bi = REV_IDX(nn, ch);
+            buf[bi] = (double)(float)buf[bi] + (double)out * (double)feedback;   // what this frame writes into the line
+          }
+        }
       }
       __syncthreads();
       PG_STAMP(fc.diag, 27 + (done > 0 ? 2 : 0));

@@ -281,7 +281,8 @@ struct PgLaunch {
   uint32_t sample_rate;
   int32_t fast;           // 1: time-parallel paths enabled
   int32_t wide;           // fast kernel variant: 0 = lean (Gain/Panning/Reverb), 1 = all fast-capable kinds, 2 = all but Reverb / Compressor (four workgroups per CU)
-  int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only
+  int32_t mode;           // 0: generic kernel, all units; 1: fast kernel (defers ineligible units); 2: generic kernel, deferred units only;
+                          // 3: generic kernel, the bus chain behind a super-block as a pipeline: workgroup f = effect f of unit `unit_base`
   float* unit_out;        // [n_units][out_stride] per-unit output (sub-mixer / source results)
   uint32_t out_stride;    // floats per unit row
   float* bus;             // bus / external signal for UNIT_BUS and UNIT_EFFECT (in place); unit slot b of the launch: bus + b * bus_unit_stride
@@ -315,6 +316,9 @@ struct PgLaunch {
   // chain behind a super-block launch sees every block's own flag. nullptr: not collected (standalone effects, bus launches).
   int32_t* audible_tab;
   uint64_t audible_stride;
+  unsigned long long* bus_progress;  // mode 3 (pipelined bus chain): [n_fx] words (round << 32 | any effect active << 31 | blocks done), device memory
+  const int2* slot_fx;    // [n_units] per launch slot: device indices of the unit's first two effects (-1: none) — with slot_info the fast kernels
+                          // request unit record, first voice and the first two effect states side by side instead of one after the other
   uint64_t bus_unit_stride;  // floats between the external buffers of consecutive units of the launch (a standalone effect with more than two
                              // channels runs one stereo unit per channel pair); 0 for the bus
 };

@@ -160,6 +160,12 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
       info.push_back(make_int4(slot, u.voice0, u.n_fx > 0 ? fidx[u.fx_off + u.n_fx - 1] : 0, (u.n_voices & 0xffffff) | (u.staged << 24)));
     }
     if ((rc = g->d_slot_info.upload_async(info, stream))) return rc;
+    std::vector<int2> sfx;
+    for (int slot : g->order) {
+      const PgUnit& u = topo[slot];
+      sfx.push_back(make_int2(u.n_fx > 0 ? fidx[u.fx_off] : -1, u.n_fx > 1 ? fidx[u.fx_off + 1] : -1));
+    }
+    if ((rc = g->d_slot_fx.upload_async(sfx, stream))) return rc;
   }
   g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
   for (Level& lv : g->levels) {
@@ -193,7 +199,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
 static int graph_reserve(pg_graph* g) {
   int rc;
   const size_t n_units = g->h_units.size(), n_voices = g->voices.size(), n_fx = g->fx.size(), n_mixers = g->mixers.size();
-  if ((rc = g->d_topo.reserve(n_units)) || (rc = g->d_order.reserve(n_units)) || (rc = g->d_slot_info.reserve(n_units)) ||
+  if ((rc = g->d_topo.reserve(n_units)) || (rc = g->d_order.reserve(n_units)) || (rc = g->d_slot_info.reserve(n_units)) || (rc = g->d_slot_fx.reserve(n_units)) ||
       (rc = g->d_voice_index.reserve(n_voices)) || (rc = g->d_fx_index.reserve(n_fx)) || (rc = g->d_child_rows.reserve(n_mixers)))
     return rc;
   if (!g->d_cmd_ring) {
@@ -272,12 +278,14 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     return nullptr;
   }
   (void)pg_memset(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int));
+  if (pg_malloc((void**)&g->d_bus_progress, PG_BUS_PIPELINE_MAX * 8) == hipSuccess) (void)pg_memset(g->d_bus_progress, 0xff, PG_BUS_PIPELINE_MAX * 8); else g->d_bus_progress = nullptr;
   if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     g->h_feedback[0] = ~0ull;  // nothing reported yet
     g->h_feedback[1] = 0; g->h_feedback[2] = 0;  // [1] status word (graph_enqueue_status), [2] consistency flags the kernels mirror here
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
+  { const char* e = getenv("PHONIC_BUS_PIPELINE"); if (e && e[0] == '0') g->bus_pipeline = false; }
   g->mixers.emplace_back();
   g->mixers[0].depth = 0;
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
@@ -294,7 +302,7 @@ void pg_graph_destroy(pg_graph* g) {
   for (auto& v : g->voices) { if (v.d_pcm) (void)pg_free(v.d_pcm); if (v.d_stage) (void)pg_free(v.d_stage); if (v.h_ring) (void)pg_host_free(v.h_ring); }
   for (auto& f : g->fx) if (f->d_mem) (void)pg_free(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_sched.release(); g->d_slot_info.release(); g->d_child_rows.release(); g->d_topo.release();
+  g->d_sched.release(); g->d_slot_info.release(); g->d_slot_fx.release(); g->d_child_rows.release(); g->d_topo.release();
   if (g->d_cmd_ring) (void)pg_free(g->d_cmd_ring);
   if (g->d_cmd_overflow) (void)pg_free(g->d_cmd_overflow);
   if (g->h_cmd_ring) (void)pg_host_free(g->h_cmd_ring);
@@ -306,6 +314,7 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->d_bus) (void)pg_free(g->d_bus);
   if (g->d_audible) (void)pg_free(g->d_audible);
   if (g->d_error) (void)pg_free(g->d_error);
+  if (g->d_bus_progress) (void)pg_free(g->d_bus_progress);
   if (g->h_pinned) (void)pg_host_free(g->h_pinned);
   if (g->h_feedback) (void)pg_host_free(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -946,6 +955,17 @@ static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream
 }
 
 
+// A bus launch that walks several blocks with a chain of two or more effects and nothing to apply: one workgroup per effect, pipelined over
+// the blocks (pg_bus_pipeline). The progress words carry the launch's round number, so they never need clearing.
+static void bus_pipeline_setup(pg_graph* g, PgLaunch& B) {
+  const size_t n_fx = g->mixers[0].fx.size();
+  if (B.n_chunks > 1 && B.n_cmds == 0 && n_fx >= 2 && n_fx <= PG_BUS_PIPELINE_MAX && g->d_bus_progress && g->bus_pipeline) {
+    B.mode = 3; B.n_units = (int)n_fx; B.bus_progress = g->d_bus_progress;
+    B.round = ++g->bus_epoch;  // (the words of an earlier launch never match; 0xffffffff is what the words are created with)
+    if (B.round == 0xffffffffu) B.round = g->bus_epoch = 1;
+  }
+}
+
 // One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
 // n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok(). The `audible` word of block c of the round goes to
 // d_audible[audible_slot + c] (the bus chain's audible_input; in defer_bus mode the caller reads the words of a whole write call).
@@ -990,7 +1010,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
     L.unit_out = g->d_unit_out + (size_t)lv.off * g->stride;
     L.audible_tab = g->d_audible_tab + lv.off; L.audible_stride = g->unit_out_rows;
-    L.slot_info = g->d_slot_info.d + lv.off;
+    L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off;
     if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
     g->defer_phase++;
     const bool timed_here = timed && li == timed_level;
@@ -1037,6 +1057,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     PgLaunch B = L;  // (n_chunks rides along: the generic kernel walks the summed blocks of a super-block in order)
     B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
     B.bus = d_dst; B.bus_audible = g->d_audible + audible_slot; B.audible_tab = nullptr;
+    bus_pipeline_setup(g, B);
     HIP_TRY(pg_launch_units(B, stream));
   }
   return PG_OK;
@@ -1311,6 +1332,7 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
     B.n_chunks = (int)k;
     B.bus = d_bus + done * 2;
     B.bus_audible = bus_audible ? bus_audible + std::min<uint64_t>(done / g->max_frames, (uint64_t)PG_AUDIBLE_SLOTS - k) : nullptr;
+    bus_pipeline_setup(g, B);
     HIP_TRY(pg_launch_units(B, s));
     done += (uint64_t)n * k;
   }

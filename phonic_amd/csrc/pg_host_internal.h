@@ -35,6 +35,7 @@ hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, fl
 
 // ---- errors ---------------------------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);  // records the thread's last error message (pg_last_error_message) and returns `code`
+#define PG_BUS_PIPELINE_MAX 16  // effects of a bus chain the pipelined launch takes (one workgroup each); longer chains stay one workgroup
 #define PG_AUDIBLE_SLOTS 64  // >= the largest pg_graph_set_max_blocks_per_launch
 #define PG_CMD_RING 65536   // commands in flight between two points at which the host knows the stream drained (2 MB device + 2 MB pinned)
 #define PG_CTRL_RING 65536  // control messages waiting for the next write (the reference: 4096 per mixer; here one ring per graph)
@@ -226,6 +227,7 @@ struct pg_graph {
   int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceTable<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
+  DeviceTable<int2> d_slot_fx;    // per launch slot: {first effect, second effect} (device indices, -1: none)
   DeviceTable<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
   DeviceTable<PgUnit> d_topo;     // topology fields of every unit, patched into d_units by pg_patch_units_kernel
   std::vector<Level> levels;    // deepest first
@@ -237,6 +239,9 @@ struct pg_graph {
   size_t max_blocks = 1;        // blocks of max_frames one launch sequence may render (pg_graph_set_max_blocks_per_launch); sizes d_unit_out
   size_t unit_out_blocks = 0;   // ... as allocated
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
+  unsigned long long* d_bus_progress = nullptr;  // progress words of the pipelined bus chain (pg_bus_pipeline)
+  uint32_t bus_epoch = 0;       // launch number of the pipelined bus chain, carried by its progress words
+  bool bus_pipeline = true;     // PHONIC_BUS_PIPELINE=0 (read at create): the bus chain behind a super-block stays one workgroup
   // host mirrors
   std::vector<HostMixer> mixers;        // [0] = main
   std::vector<HostVoice> voices;

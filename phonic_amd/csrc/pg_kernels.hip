@@ -328,9 +328,29 @@ __device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* 
 template <bool FAST_ONLY, int KMASK>
 __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, const int chunk = 0) {
   if (slot >= L.n_units) return;
-  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
-  PgUnit& unit = L.units[u];
   const int tid = pg_tid(), nt = blockDim.x;
+  // Fast kernels: ONE trip names the unit, its first voice and its first two effects (slot_info / slot_fx, written by the host with the
+  // topology); their records are then requested together — the unit record, the voice's state (one dword per lane) and the effect states (one
+  // qword per lane each) used to be three dependent trips to L2 at the head of a kernel that is a latency chain.
+  const bool tables = FAST_ONLY && L.slot_info != nullptr && L.slot_fx != nullptr;
+  int4 si = make_int4(0, 0, 0, 0);
+  int2 sf = make_int2(-1, -1);
+  if (tables) {
+    si = L.slot_info[slot]; sf = L.slot_fx[slot];
+    si.x = __builtin_amdgcn_readfirstlane(si.x); si.y = __builtin_amdgcn_readfirstlane(si.y); si.w = __builtin_amdgcn_readfirstlane(si.w);
+    sf.x = __builtin_amdgcn_readfirstlane(sf.x); sf.y = __builtin_amdgcn_readfirstlane(sf.y);
+  }
+  const int u = tables ? si.x : (L.unit_order ? L.unit_order[slot] : L.unit_base + slot);
+  PgUnit& unit = L.units[u];
+  uint32_t voice_word = 0;
+  unsigned long long fx0_word = 0, fx1_word = 0;
+  const int n_fx_words = (int)(sizeof(PgFx) / 4);
+  static_assert(sizeof(PgFx) % 8 == 0 && sizeof(PgFx) / 8 <= 256, "PgFx must fit one qword per lane of the workgroup");
+  if (tables) {
+    if ((si.w & 0xffffff) > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
+    if (sf.x >= 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[sf.x])[tid];
+    if (sf.y >= 0 && tid < n_fx_words / 2) fx1_word = ((const unsigned long long*)&L.fx[sf.y])[tid];
+  }
   const int N = (int)L.n_frames;
   // The two signal rows hold at least PG_MIN_ROW_FRAMES frames: the ramp paths lay their per-frame parameter sequences out in `tmp`, eight to ten
   // sequences of at least eight frames (delay_ramp_fast, chorus_ramp_fast) — with rows sized by a launch of a handful of frames they would
@@ -373,13 +393,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     __syncthreads();
     if (!ctl[5]) return;
   }
-  // Prefetch the first effect's state block (one dword per lane, ~1 KB): the HBM round trip completes under the source
-  // stage; the words are parked in a register until the chain stages them in LDS.
-  unsigned long long fx0_word = 0;
-  const int n_fx_words = (int)(sizeof(PgFx) / 4);
-  static_assert(sizeof(PgFx) % 8 == 0 && sizeof(PgFx) / 8 <= 256, "PgFx must fit one qword per lane of the workgroup");
-  if (FAST_ONLY && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
+  // The first effects' state blocks (one qword per lane, ~1 KB each) are in flight since the head of the kernel (or requested here when the
+  // launch carries no slot tables): the HBM round trips complete under the source stage; the words wait in registers until the chain stages
+  // them in LDS.
+  if (FAST_ONLY && !tables && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
   bool fx0_fresh = FAST_ONLY && unit.n_fx > 0;  // the generic kernel applies commands to the global copy first
+  bool fx1_fresh = tables && sf.y >= 0 && unit.n_fx > 1;
   const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
   float* ext = L.bus + (size_t)slot * L.bus_unit_stride + (size_t)chunk * 2 * (size_t)N;  // (a bus launch behind a super-block: block c of the summed bus)
   if (external) {
@@ -453,7 +472,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       }
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
-        audible_input |= voice_process<!FAST_ONLY>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank);
+        audible_input |= voice_process<!FAST_ONLY>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word);
       }
     }
     PG_STAMP(L.diag, 1);
@@ -468,6 +487,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           PgFx& gfx = L.fx[L.fx_index[unit.fx_off + fi]];
           __syncthreads();
           if (fi == 0 && fx0_fresh) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; fx0_fresh = false; }
+          else if (fi == 1 && fx1_fresh) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx1_word; fx1_fresh = false; }
           else for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
           __syncthreads();
           PgFx& fx = *lfx;
@@ -546,13 +566,77 @@ __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(P
 // Chains without Reverb and Compressor (C3: Filter -> Chorus per voice): those two carry the large register footprints and LDS arenas.
 // Without them the same body compiles for four workgroups per CU (128 VGPRs) and its arena fits 40 KB.
 #define PG_KMASK_MID (PG_KMASK_ALL & ~((1 << 5) | (1 << 7)))
-__global__ void __launch_bounds__(256, 4) pg_unit_kernel_fast_mid(PgLaunch L) {
+#ifndef PG_MID_WAVES
+#define PG_MID_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, PG_MID_WAVES) pg_unit_kernel_fast_mid(PgLaunch L) {
   pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, 0);
   for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, c); }
 }
+// The main mixer's effect chain behind a super-block launch as a PIPELINE over the blocks: workgroup f runs effect f of the chain over the
+// summed blocks 0, 1, 2 ... in order and hands block c on to workgroup f + 1 through the bus buffer itself (in place) and a progress word —
+// effect f works on block c while effect f + 1 works on block c - 1. A lone workgroup running the whole chain is a pure latency chain (C2: Eq5
+// 50 K + Reverb 96 K cycles per block, tools/diag_bus.py); the chain's stages are independent state machines, so its time per block becomes
+// the slowest effect's instead of their sum. Per block every effect takes EffectProcessor::process's decisions with the same inputs as in the
+// serial order (mixed.rs:627-655): audible_input of the block (L.bus_audible[c]) and whether an earlier effect of the chain was active on
+// it (travels with the progress word); MixedSource's shortcut `effects_bypassed && input_bypassed -> skip the chain` changes nothing an
+// effect would not decide for itself (a bypassed processor with silent input stays bypassed, effect.rs:88-101) and is kept as state only.
+// Workgroup f waits for workgroup f - 1 only: lower block indices are dispatched first, so the producer of a waiting workgroup is resident.
+template <int KMASK>
+__device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
+  const int f = (int)blockIdx.x, n_stages = (int)gridDim.x;
+  PgUnit& unit = L.units[L.unit_base];
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int N = (int)L.n_frames;
+  const int NA = N < PG_MIN_ROW_FRAMES ? PG_MIN_ROW_FRAMES : N;
+  float* sig = (float*)pg_smem;
+  float* tmp = sig + 2 * NA;
+  char* scratch = (char*)(tmp + 2 * NA);
+  scratch += (sizeof(PgVoice) + 15) & ~15ull;
+  PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
+  int* ctl = (int*)scratch;                        scratch += 128;
+  float* red = (float*)scratch;                    scratch += 64;
+  FastCtx fc;
+  fc.tmp = tmp; fc.tmp_floats = 2 * NA; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = nullptr; fc.err = L.error_word; fc.idx_log = nullptr;
+  PgFx& gfx = L.fx[L.fx_index[unit.fx_off + f]];
+  for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];  // the effect's state stays in LDS over all blocks
+  __syncthreads();
+  const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
+  int any_active = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    int active_before = 0;
+    if (f > 0) {
+      if (tid == 0) {
+        unsigned long long w;
+        do { w = __hip_atomic_load(&L.bus_progress[f - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(w >> 32) != L.round || (int)(w & 0x7fffffffull) <= c);
+        ctl[6] = (int)((w >> 31) & 1ull);
+      }
+      __syncthreads();
+      __threadfence();  // the producer's stores of block c are visible (the L1 is invalidated behind the acquire)
+      active_before = ctl[6];
+    }
+    float* blk = L.bus + (size_t)c * 2 * (size_t)N;
+    for (int i = tid; i < 2 * N; i += nt) sig[i] = __builtin_nontemporal_load(blk + i);
+    __syncthreads();
+    const bool audible_input = L.bus_audible ? (L.bus_audible[c] != 0) : true;
+    const bool input_bypassed = !audible_input && !active_before;
+    const bool is_active = fx_processor_process<false, KMASK>(*lfx, sig, 2 * N, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+    __syncthreads();
+    if (is_active) for (int i = tid; i < 2 * N; i += nt) blk[i] = sig[i];
+    any_active = (active_before || is_active) ? 1 : 0;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&L.bus_progress[f], ((unsigned long long)L.round << 32) | ((unsigned long long)any_active << 31) | (unsigned long long)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
+  if (f == n_stages - 1 && tid == 0) unit.effects_bypassed = any_active ? 0 : 1;  // of the last block, as the serial order leaves it
+}
+
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
 // walks its share of the units, so the launch that finds nothing deferred costs 256 workgroup starts instead of n_units.
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
+  if (L.mode == 3) { pg_bus_pipeline<PG_KMASK_ALL>(L); return; }
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
     const int n = *L.defer_count;
     if (blockIdx.x == 0 && pg_tid() == 0) {
@@ -1090,7 +1174,7 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0
   if (L.mode == 1 && L.wide == 2) hipExtLaunchKernelGGL(pg_unit_kernel_fast_mid, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else if (L.mode == 1) hipExtLaunchKernelGGL(pg_unit_kernel_fast, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
-  else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
+  else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);  // (mode 3: n_units = stages of the bus pipeline)
   return hipGetLastError();
 }
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,

@@ -184,7 +184,14 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       uint64_t remaining_in = lr_end > pp ? lr_end - pp : 0;
       uint64_t want = (uint64_t)(out_frames - written) * C;
       int nsm = (int)(remaining_in < want ? remaining_in : want);
-      if (P.on && acc) { for (int i = tid; i < nsm; i += nt) acc[written * C + i] = acc[written * C + i] + src_post(P, v->pcm[pp + i], i & 1); }
+      if (P.on && acc && C == 1) {  // a steady mono file at the mixer's rate: ChannelMappedSource's duplication (buffer.rs:209-217), gain and panning
+        for (int i = tid; i < nsm; i += nt) {   // per output sample, added straight into the mixer's block — the same multiplications in the same order
+          const float x = v->pcm[pp + i];      // as the separate passes (five LDS passes less per block)
+          float* a2 = acc + 2 * (written + i);
+          a2[0] = a2[0] + src_post(P, x, 0);
+          a2[1] = a2[1] + src_post(P, x, 1);
+        }
+      } else if (P.on && acc) { for (int i = tid; i < nsm; i += nt) acc[written * C + i] = acc[written * C + i] + src_post(P, v->pcm[pp + i], i & 1); }
       else if (P.on) { for (int i = tid; i < nsm; i += nt) out[written * C + i] = src_post(P, v->pcm[pp + i], i & 1); }
       else for (int i = tid; i < nsm; i += nt) out[written * C + i] = v->pcm[pp + i];
       __syncthreads();
@@ -486,7 +493,9 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
   __syncthreads();
   if (v->finished) return 0;
   SrcPost P;
-  P.on = (allow_post && C == 2 && v->fader_state != 1 && !sm_need_ramp(v->volume) && !sm_need_ramp(v->panning)) ? 1 : 0;
+  // (mono: only the whole-buffer copy branch of a file at the mixer's rate folds the mapping in, and only straight into the mixer's block)
+  const bool mono_fused = C == 1 && acc != nullptr && fabsf(v->ratio - 1.0f) < 0.000001f && !(GLIDE && v->current_speed != v->target_speed);
+  P.on = (allow_post && (C == 2 || mono_fused) && v->fader_state != 1 && !sm_need_ramp(v->volume) && !sm_need_ramp(v->panning)) ? 1 : 0;
   P.fs = v->fader_target; P.use_f = P.fs != 1.0f;
   P.gain = v->volume.target; P.use_g = fabsf(1.0f - P.gain) > 0.000001f;
   P.use_p = fabsf(v->panning.target) > 0.000001f; P.pl = 1.0f; P.pr = 1.0f;
@@ -686,7 +695,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   } else {
     int post_on;
     wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on);
-    if (post_on) { *added = acc ? 1 : 0; return wf * C; }
+    if (post_on) { *added = acc ? 1 : 0; return wf * 2; }  // (stereo samples: a fused mono voice has been mapped to both channels on the way)
   }
   __syncthreads();
   // ChannelMappedSource: mono -> stereo (buffer.rs:209-217)
