@@ -310,7 +310,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       if constexpr ((KMASK >> 10) & 1) return delay_ramp_fast(fx, sig, n, fc); else return false;
     } else return false;
     case 5: if constexpr ((KMASK >> 5) & 1) {
-      if (reverb_fast(fx, sig, n, fc)) return true;
+      if (reverb_fast<((KMASK >> 11) & 1) ? 2 : 1>(fx, sig, n, fc)) return true;  // (bit 11: the generic kernel — two sub-chunks per trip)
       if constexpr ((KMASK >> 10) & 1) return reverb_wet_ramp_fast(fx, sig, n, fc); else return false;
     } else return false;
     case 6: if constexpr ((KMASK >> 6) & 1) {

@@ -550,6 +550,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 // keeps the hot loop free of spills; the wide one adds Filter, Eq5 and Distortion. The host picks by the kinds present.
 #define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
 #define PG_KMASK_ALL 0x7ff  // bits 0..9: effect kinds; bit 10: the ramp paths (FilterEffect cutoff / Q)
+#define PG_KMASK_GENERIC 0xfff  // ... bit 11: the generic kernel's lone workgroups (two reverb sub-chunks per trip: registers to spare, latency to hide)
 #define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
 // leading effects of the wide staged kernel: every kind with a time-parallel path whose LDS needs fit stage 1's arena (no Chorus)
 #define PG_KMASK_LEADING ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 9))
@@ -636,7 +637,7 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
 // walks its share of the units, so the launch that finds nothing deferred costs 256 workgroup starts instead of n_units.
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
-  if (L.mode == 3) { pg_bus_pipeline<PG_KMASK_ALL>(L); return; }
+  if (L.mode == 3) { pg_bus_pipeline<PG_KMASK_GENERIC>(L); return; }
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
     const int n = *L.defer_count;
     if (blockIdx.x == 0 && pg_tid() == 0) {
@@ -645,7 +646,7 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
       if (L.host_feedback) { *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n; __threadfence_system(); }
     }
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-      pg_unit_body<false, PG_KMASK_ALL>(L, L.defer_list[i]);
+      pg_unit_body<false, PG_KMASK_GENERIC>(L, L.defer_list[i]);
       __syncthreads();
     }
     return;
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
   for (int slot = (int)blockIdx.x; slot < L.n_units; slot += (int)gridDim.x) {
     for (int c = 0; c < n_chunks; ++c) {
-      pg_unit_body<false, PG_KMASK_ALL>(L, slot, c);
+      pg_unit_body<false, PG_KMASK_GENERIC>(L, slot, c);
       __syncthreads();
     }
   }

@@ -478,6 +478,7 @@ DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const 
 // idx_log (test hook, nullptr in the kernels that matter for speed): slot ((frame * 8 + line) * 2 + channel) receives `read_1` of that
 // frame's ReverbDelayLine::get (reverb.rs:563-570) — the index stream SURVEY §8c asks to be compared separately from the samples.
 // wet_seq (nullptr in the steady-state kernels): the wet gain of every frame of the piece while its smoother moves (reverb_wet_ramp_fast).
+template <int ITEMS = 1>
 DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, int* ctl, unsigned long long* diag, int32_t* idx_log = nullptr,
                   const float* wet_seq = nullptr) {
   const int tid = pg_tid(), nt = blockDim.x;
@@ -536,18 +537,25 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
     __syncthreads();
     PG_STAMP(diag, 4);
     // ---- sub-chunks of nt/2 frames ----
-    for (int base = 0; base < T; base += nt / 2) {
+    // ITEMS consecutive 128-frame sub-chunks per trip (each with its own anchor): every lane carries ITEMS (frame, channel) items through the
+    // reads -> barrier -> writes sequence. 1 in the kernels that share a CU four ways (128 VGPRs); 2 in the generic kernel, whose lone
+    // workgroups (the main mixer's chain, units on the exact lane) are latency chains with registers to spare: half the dependent round trips.
+    for (int base = 0; base < T; base += ITEMS * (nt / 2)) {
 #pragma clang fp contract(fast)  // the only place mul+add pairs may fuse: measured faster, error ~1e-16 relative (the parity gate is 1e-5 RMS)
       int lane_frame = tid >> 1;
       asm volatile("" : "+v"(lane_frame));  // keeps per-lane ring addresses from being hoisted out of the loop into 36 long-lived VGPRs
       int ch = tid & 1;
       asm volatile("" : "+v"(ch));
-      const int n = base + lane_frame;
-      const bool active = n < T;
-      double sv[8];   // values the eight lines are `set` to (allpass tap + feedback), reverb.rs:275-282,588-594
-      double apw[4];  // values written into the four allpass rings
-      double o_prev = 0.0;
+      double sv[ITEMS][8];   // values the eight lines are `set` to (allpass tap + feedback), reverb.rs:275-282,588-594
+      double apw[ITEMS][4];  // values written into the four allpass rings
+      double o_prev[ITEMS];
       PG_LAP_DECL(lap_t);
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+      const int sub_base = base + it * (nt / 2);
+      const int n = sub_base + lane_frame;
+      const bool active = n < T;
+      o_prev[it] = 0.0;
       if (active) {
         // Order matters for latency: first everything that only needs the (known) vibrato phases — the 16 line taps of
         // the previous frame's `get` — and the 4 allpass taps go out to HBM; the f64 sin of the front end and the allpass
@@ -560,11 +568,11 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
           // sin(phase_n) ~= sin(pb + j*d): pb = the sub-chunk's exact anchor phase, j*d = tabulated rotation. The reference's
           // accumulator advances by du = d rounded to the accumulator's ulp; the neglected j*(du - d) is <= 64 * 2^-52 * |p|
           // (< 3e-14 in the tap position), far below the 1-ulp spread between libm implementations of sin itself.
-          const int n_anchor = base + REV_VTAB_HALF < T ? base + REV_VTAB_HALF : T;
+          const int n_anchor = sub_base + REV_VTAB_HALF < T ? sub_base + REV_VTAB_HALF : T;
           const int js = n - n_anchor;                      // in [-64, 63]
           const int jb = js < 0 ? -js : js;
           const unsigned long long st_sign = js < 0 ? 0x8000000000000000ull : 0ull;  // sin(-x) = -sin(x)
-          const double* anb = anch + (size_t)(base / (nt / 2)) * 16 * 2;
+          const double* anb = anch + (size_t)(sub_base / (nt / 2)) * 16 * 2;
           // The rotation operands of line i + 1 are fetched from LDS before line i is evaluated (two register sets): one
           // exposed LDS round trip per sub-chunk instead of one per line.
           double q_ct[2], q_st[2], q_a0[2], q_a1[2];
@@ -598,7 +606,7 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const double bb = v - (dl[i] * 0.5);
-          apw[i] = bb;
+          apw[it][i] = bb;
           v = bb * 0.5 + dl[i];   // == buf*0.5 + new_delayed (delay >= 1)
           apo[i] = v;
         }
@@ -616,27 +624,32 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
           F[2] = (g[2] - (g[0] + g[1] + g[3])) * regen; F[3] = (g[3] - (g[0] + g[1] + g[2])) * regen;
           F[4] = (g[4] - (g[5] + g[6] + g[7])) * regen; F[5] = (g[5] - (g[4] + g[6] + g[7])) * regen;   // reverb.rs:307-310
           F[6] = (g[6] - (g[4] + g[5] + g[7])) * regen; F[7] = (g[7] - (g[4] + g[5] + g[6])) * regen;
-          o_prev = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;                        // reverb.rs:321-329
+          o_prev[it] = (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7]) / 8.0;                    // reverb.rs:321-329
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) F[i] = r.line[i].feedback[ch];  // handed over from the previous chunk
         }
         // set(): a<-l, b<-k, c<-j, d<-i, e<-i, f<-j, g<-k, h<-l  (reverb.rs:275-282)
-        sv[0] = apo[3] + F[0]; sv[1] = apo[2] + F[1]; sv[2] = apo[1] + F[2]; sv[3] = apo[0] + F[3];
-        sv[4] = apo[0] + F[4]; sv[5] = apo[1] + F[5]; sv[6] = apo[2] + F[6]; sv[7] = apo[3] + F[7];
+        sv[it][0] = apo[3] + F[0]; sv[it][1] = apo[2] + F[1]; sv[it][2] = apo[1] + F[2]; sv[it][3] = apo[0] + F[3];
+        sv[it][4] = apo[0] + F[4]; sv[it][5] = apo[1] + F[5]; sv[it][6] = apo[2] + F[6]; sv[it][7] = apo[3] + F[7];
+      }
       }
       PG_LAP(diag, 52, lap_t);
-      __syncthreads();  // every read of this sub-chunk has been issued and consumed
+      __syncthreads();  // every read of these sub-chunks has been issued and consumed
       PG_LAP(diag, 53, lap_t);
-      if (active) {
-        if (n >= 1) bufA[REV_IDX(done + n - 1, ch)] = o_prev;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const RevRingN a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[i]; }
+      for (int it = 0; it < ITEMS; ++it) {
+        const int n = base + it * (nt / 2) + lane_frame;
+        if (n < T) {
+          if (n >= 1) bufA[REV_IDX(done + n - 1, ch)] = o_prev[it];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const RevRingN ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[i]; }
+          for (int i = 0; i < 4; ++i) { const RevRingN a = D[8 + i]; *ring_ptr(a, ring_at(a, n), ch) = apw[it][i]; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const RevRingN ld = D[i]; *ring_ptr(ld, ring_at(ld, n), ch) = sv[it][i]; }
+        }
       }
       PG_LAP(diag, 54, lap_t);
-      // no barrier here: the next sub-chunk only reads ring positions that are written by its own or later items, and LDS
+      // no barrier here: the next trip only reads ring positions that are written by its own or later items, and LDS
       // slots >= its first frame, so its reads cannot collide with these writes
     }
     __syncthreads();
@@ -701,6 +714,7 @@ DEVO void rev_tail_impl(PgReverb& r, float* s0, int T, const RevLds& m, const Re
 }
 DEVO void rev_tail(PgReverb& r, float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) { rev_tail_impl<false>(r, s0, T, m, b, diag); }
 
+template <int ITEMS = 1>
 DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgReverb& r = fx.u.reverb;
   // per-frame delay sizes / coefficients while a smoother moves, or a ring position still above a ring end the room left behind when it
@@ -717,7 +731,7 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     const int T = frames - done < REV_T_CAP ? frames - done : REV_T_CAP;
     float* s0 = sig + 2 * done;
     rev_front(r, s0, T, m, b, fc.diag);
-    rev_mid(r, T, m, b, fc.ctl, fc.diag, fc.idx_log ? fc.idx_log + (size_t)done * 16 : nullptr);
+    rev_mid<ITEMS>(r, T, m, b, fc.ctl, fc.diag, fc.idx_log ? fc.idx_log + (size_t)done * 16 : nullptr);
     rev_tail(r, s0, T, m, b, fc.diag);
   }
   return true;
