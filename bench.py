@@ -343,7 +343,7 @@ def main():
             t = torch.tensor([d0], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank runs the same number of legs
             d0 = float(t.item())
-        n = args.repeats if args.repeats > 0 else max(5, min(2001, int(seconds / max(d0, 1e-6)) | 1))
+        n = args.repeats if args.repeats > 0 else max(5, min(2001, int(1.2 * seconds / max(d0, 1e-6)) | 1))   # (+20 %: the first leg runs slower than the rest)
         legs = [first] + [leg(args.steps, per_call) for _ in range(n - 1)]
         dts = [l[0] for l in legs]
         if dist_on:

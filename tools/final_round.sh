@@ -8,6 +8,10 @@ python bench.py --workload c5 --scaling strong --total-voices 8192 --steps 32 --
 for w in c2 c3 c4 c5; do python bench.py --workload $w --steps 64 --warmup 16 --no-cpu-baseline > $O/${R}_${w}_bench.json 2>> $O/bench.err; done
 for v in 2048 4096; do python bench.py --voices $v --steps 64 --warmup 32 --repeats 3 --no-cpu-baseline > $O/${R}_headline_${v}v_bench.json 2>> $O/bench.err; done
 python bench.py --superblock 1 --steps 100 --warmup 20 --no-cpu-baseline > $O/${R}_headline_single_block_launches_bench.json 2>> $O/bench.err
+# kernel traces of the two bus-chain workloads (the bus kernel is their dominant one) and the ring-stream micro-benchmark (what the memory system
+# gives the mid stage's access stream without its arithmetic)
+for w in c2 c4; do bash tools/ktrace.sh --workload $w --repeats 3 --steps 64 --warmup 32 > $O/${R}_${w}_kernel_trace.txt 2>&1; done
+( cd tools/ringstream && for v in 0 1 2 3 4 5; do ./ringstream.bin 1024 16 $v 4; done; ./ringstream.bin 1024 16 0 2; ./ringstream.bin 1024 16 0 5; ./ringstream.bin 4096 8 0 4 ) > $O/${R}_ringstream.jsonl 2>&1
 bash tools/c3_round.sh c3tmp > /dev/null 2>&1
 cp gpurun_out/c3tmp/c3_rocprofv3_kernel_stats.csv $O/${R}_c3_rocprofv3_kernel_stats.csv
 cp gpurun_out/c3tmp/c3_pmc_util.csv $O/${R}_c3_pmc_util.csv
