@@ -334,6 +334,11 @@ int pg_sharded_add_mixer_to(pg_sharded_graph* s, int parent_mixer_id);          
 int pg_sharded_add_effect(pg_sharded_graph* s, int mixer_id, int kind, const pg_effect_init* init);
 int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, size_t n_frames, uint32_t src_channels, uint32_t src_rate,
                          const pg_voice_options* opt);
+/* host-fed sources on the sharded mixer: pg_graph_add_stream_voice / feed_voice / end_stream_voice / stream_voice_consumed on the owning shard */
+int pg_sharded_add_stream_voice(pg_sharded_graph* s, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt);
+int pg_sharded_feed_voice(pg_sharded_graph* s, int voice_id, const float* frames, size_t n_frames);
+int pg_sharded_end_stream_voice(pg_sharded_graph* s, int voice_id);
+int64_t pg_sharded_stream_voice_consumed(pg_sharded_graph* s, int voice_id);
 int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id);
 /* Player::remove_mixer / remove_effect / move_effect (src/player.rs:825-867,942-990; MixerMessage::RemoveMixer / RemoveEffect / MoveEffect,
  * src/source/mixed.rs:422-462): semantics and errors of pg_graph_remove_mixer / _remove_effect / _move_effect. */

@@ -285,6 +285,14 @@ def load():
         fn = getattr(lib, "pg_sharded_" + name)
         fn.restype = C.c_int
         fn.argtypes = [vp] + args
+    lib.pg_sharded_add_stream_voice.restype = C.c_int
+    lib.pg_sharded_add_stream_voice.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, P(VoiceOptions)]
+    lib.pg_sharded_feed_voice.restype = C.c_int
+    lib.pg_sharded_feed_voice.argtypes = [vp, C.c_int, P(C.c_float), C.c_size_t]
+    lib.pg_sharded_end_stream_voice.restype = C.c_int
+    lib.pg_sharded_end_stream_voice.argtypes = [vp, C.c_int]
+    lib.pg_sharded_stream_voice_consumed.restype = C.c_int64
+    lib.pg_sharded_stream_voice_consumed.argtypes = [vp, C.c_int]
     lib.pg_sharded_write.restype = C.c_size_t
     lib.pg_sharded_write.argtypes = [vp, P(C.c_float), C.c_size_t, C.c_uint64]
     lib.pg_sharded_write_device.restype = C.c_size_t

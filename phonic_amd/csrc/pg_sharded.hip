@@ -231,6 +231,33 @@ int pg_sharded_add_voice(pg_sharded_graph* s, int mixer_id, const float* pcm, si
   if (local > 0xffffff || !s->voice_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many voices");
   return id;
 }
+// host-fed sources (pg_graph_add_stream_voice): placed like any other source, fed through the shard that owns them
+int pg_sharded_add_stream_voice(pg_sharded_graph* s, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt) {
+  int32_t pk;
+  if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;
+  const int shard = mixer_id == 0 ? sharded_least_loaded(s) : shard_of(pk);
+  const int local = pg_graph_add_stream_voice(s->shards[shard], mixer_id == 0 ? 0 : local_of(pk), channels, rate, capacity_frames, opt);
+  if (local < 0) return local;
+  if (mixer_id == 0) s->load[shard] += 1;
+  const int id = (int)s->voice_map.size();
+  if (local > 0xffffff || !s->voice_map.append((int32_t)(((uint32_t)shard << 24) | (uint32_t)local))) return -set_error(PG_ERR_STATE, "too many voices");
+  return id;
+}
+int pg_sharded_feed_voice(pg_sharded_graph* s, int voice_id, const float* frames, size_t n_frames) {
+  if (voice_id < 0 || (size_t)voice_id >= s->voice_map.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  const int32_t pk = s->voice_map.get((size_t)voice_id);
+  return pg_graph_feed_voice(s->shards[shard_of(pk)], local_of(pk), frames, n_frames);
+}
+int pg_sharded_end_stream_voice(pg_sharded_graph* s, int voice_id) {
+  if (voice_id < 0 || (size_t)voice_id >= s->voice_map.size()) return set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id);
+  const int32_t pk = s->voice_map.get((size_t)voice_id);
+  return pg_graph_end_stream_voice(s->shards[shard_of(pk)], local_of(pk));
+}
+int64_t pg_sharded_stream_voice_consumed(pg_sharded_graph* s, int voice_id) {
+  if (voice_id < 0 || (size_t)voice_id >= s->voice_map.size()) { set_error(PG_ERR_NOT_FOUND, "Source with id %d not found", voice_id); return -1; }
+  const int32_t pk = s->voice_map.get((size_t)voice_id);
+  return pg_graph_stream_voice_consumed(s->shards[shard_of(pk)], local_of(pk));
+}
 int pg_sharded_shard_of_mixer(pg_sharded_graph* s, int mixer_id) {
   int32_t pk;
   if (!sharded_mixer(s, mixer_id, pk)) return -PG_ERR_NOT_FOUND;

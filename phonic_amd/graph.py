@@ -139,6 +139,24 @@ class ShardedGraph:
         o = _capi.default_voice_options(**opts)
         return self._id(self._lib.pg_sharded_add_voice(self._h, mixer_id, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.size // src_channels, src_channels, src_rate, C.byref(o)))
 
+    def add_stream_voice(self, mixer_id, channels, rate, capacity_frames, **opts):
+        o = _capi.default_voice_options(**opts)
+        v = self._id(self._lib.pg_sharded_add_stream_voice(self._h, mixer_id, channels, rate, capacity_frames, C.byref(o)))
+        if not hasattr(self, "_stream_channels"):
+            self._stream_channels = {}
+        self._stream_channels[v] = channels
+        return v
+
+    def feed_voice(self, voice, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        self._check(self._lib.pg_sharded_feed_voice(self._h, voice, frames.ctypes.data_as(C.POINTER(C.c_float)), frames.size // self._stream_channels[voice]))
+
+    def end_stream_voice(self, voice):
+        self._check(self._lib.pg_sharded_end_stream_voice(self._h, voice))
+
+    def stream_voice_consumed(self, voice):
+        return self._id(self._lib.pg_sharded_stream_voice_consumed(self._h, voice))
+
     def shard_of_mixer(self, mixer_id):
         return self._id(self._lib.pg_sharded_shard_of_mixer(self._h, mixer_id))
 

