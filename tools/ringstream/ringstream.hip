@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(256, 4) ring_kernel(Voice* voices, int n_block
 int main(int argc, char** argv) {
   const int voices = argc > 1 ? atoi(argv[1]) : 1024, blocks = argc > 2 ? atoi(argv[2]) : 16, variant = argc > 3 ? atoi(argv[3]) : 0;
   const int wg_per_cu = argc > 4 ? atoi(argv[4]) : 4;
+  const int in_phase = argc > 5 ? atoi(argv[5]) : 0;     // 1: every voice at the same ring positions (voices started together, as in bench.py)
+  const int pad = argc > 6 ? atoi(argv[6]) : 0;           // bytes by which voice v's rings are shifted inside its allocation: v * pad (de-phases the physical addresses)
   const int frames = 1024;
   // ring lengths of the reverb at its default room size 0.6: size = 52; lines floor(k * 52) + 1, k = 79 73 71 67 61 59 53 47; allpasses 43 41 37 31
   const uint32_t len[12] = {4109, 3797, 3693, 3485, 3173, 3069, 2757, 2445, 2237, 2133, 1925, 1613};
@@ -149,9 +151,11 @@ int main(int argc, char** argv) {
   std::vector<Voice> h(voices);
   for (int v = 0; v < voices; ++v) {
     double* p = nullptr;
-    CHECK(hipMalloc((void**)&p, per_voice * 8));   // one allocation per effect instance, as in the product
-    CHECK(hipMemset(p, 0, per_voice * 8));
-    for (int i = 0; i < 12; ++i) { h[v].ring[i] = p; p += alloc[i] * 2; h[v].m[i] = len[i]; h[v].pos[i] = (uint32_t)((v * 131 + i * 977) % len[i]); }
+    const size_t shift = ((size_t)v * (size_t)pad) % 65536;
+    CHECK(hipMalloc((void**)&p, per_voice * 8 + 65536));   // one allocation per effect instance, as in the product
+    CHECK(hipMemset(p, 0, per_voice * 8 + 65536));
+    p = (double*)((char*)p + shift);
+    for (int i = 0; i < 12; ++i) { h[v].ring[i] = p; p += alloc[i] * 2; h[v].m[i] = len[i]; h[v].pos[i] = in_phase ? 1u : (uint32_t)((v * 131 + i * 977) % len[i]); }
   }
   int off[12][2];
   for (int i = 0; i < 12; ++i) for (int c = 0; c < 2; ++c) off[i][c] = i < 8 ? (i * 5 + c * 9) % 15 : 0;
@@ -194,7 +198,7 @@ int main(int argc, char** argv) {
   CHECK(hipGetLastError());
   const double rw = variant == 4 || variant == 5 ? 0.5 : 1.0;
   const double bytes = 12.0 * 32.0 * rw * (double)voices * frames * blocks;
-  printf("{\"variant\": %d, \"voices\": %d, \"blocks_per_launch\": %d, \"wg_per_cu\": %d, \"ms_per_block_avg\": %.5f, \"ms_per_block_best\": %.5f, \"algorithmic_GBps_avg\": %.1f, \"algorithmic_GBps_best\": %.1f}\n",
-         variant, voices, blocks, wg_per_cu, sum / reps / blocks, best / blocks, bytes / (sum / reps * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e9);
+  printf("{\"in_phase\": %d, \"pad\": %d, \"variant\": %d, \"voices\": %d, \"blocks_per_launch\": %d, \"wg_per_cu\": %d, \"ms_per_block_avg\": %.5f, \"ms_per_block_best\": %.5f, \"algorithmic_GBps_avg\": %.1f, \"algorithmic_GBps_best\": %.1f}\n",
+         in_phase, pad, variant, voices, blocks, wg_per_cu, sum / reps / blocks, best / blocks, bytes / (sum / reps * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e9);
   return 0;
 }
