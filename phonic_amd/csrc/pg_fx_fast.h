@@ -42,22 +42,18 @@ DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs
                             FastCtx& fc) {
   const int tid = pg_tid(), nt = blockDim.x;
   double* buf = (double*)fc.scratch;
-  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);
-  PgState2* lst = (PgState2*)(xchg + 4);  // [2] per-stage state view for the scan
+  double* xchg = (double*)(fc.scratch + REV_BUF_DOUBLES * 8);   // two hand-over slots, used alternately: consecutive scans need no barrier between them
+  PgState2* lst = (PgState2*)(xchg + 8);  // [n_stages][2] state view for the scans (n_stages <= 5)
   const int frames = n_samples / 2;
   for (int done = 0; done < frames; done += 1024) {
     const int T = frames - done < 1024 ? frames - done : 1024;
     __syncthreads();
     for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
+    if (tid < 2 * n_stages) lst[tid] = st[(tid & 1) * st_stride + (tid >> 1)];
     __syncthreads();
-    for (int k = 0; k < n_stages; ++k) {
-      if (tid < 2) lst[tid] = st[tid * st_stride + k];
-      __syncthreads();
-      rev_biquad_scan_t<true>(coefs[k], lst, buf, T, xchg);
-      __syncthreads();
-      if (tid < 2) st[tid * st_stride + k] = lst[tid];
-    }
+    for (int k = 0; k < n_stages; ++k) rev_biquad_scan_t<true>(coefs[k], lst + 2 * k, buf, T, xchg + 4 * (k & 1));  // (a lane's pass 1 reads what its own pass 2 wrote)
     __syncthreads();
+    if (tid < 2 * n_stages) st[(tid & 1) * st_stride + (tid >> 1)] = lst[tid];
     for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)];
   }
   __syncthreads();

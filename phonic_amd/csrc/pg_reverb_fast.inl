@@ -233,12 +233,31 @@ DEVO Mat2 mat2_mul(const Mat2& x, const Mat2& y) { return Mat2{x.a * y.a + x.b *
 // Time-parallel evaluation of one TPT-SVF biquad (BiquadFilter::process_sample, src/utils/dsp/filters/biquad.rs:314-322)
 // over the chunk, both channels, in place. The filter is linear and its coefficients are constant inside the chunk:
 //   s' = A s + B x,  A = [[2*a1-1, -2*a2], [2*a2, 1-2*a3]],  B = [2*a2, 2*a3]
-// Blocked recurrence: 128 segments of 8 frames per channel (one lane each, channel = wave & 1):
-//   pass 1: zero-state response of each segment (segment 0 starts from the carried state);
-//   scan  : end state of every segment = Kogge-Stone scan of s -> A^8 s + z over the segments (wave shuffles; the upper
-//           wave of a channel is seeded with the lower wave's final state through LDS);
+// Blocked recurrence: 128 segments of 8 frames per channel (one lane each, channel = wave & 1, two waves per channel):
+//   pass 1: zero-state response z of each segment (segment 0 starts from the carried state);
+//   scan  : the state in front of every segment, s_L = sum_{j < L} (A^8)^(L-1-j) z_j, in three levels that stay in registers:
+//           inside a row of 16 lanes four doubling steps over DPP row shifts (zero fill at the row's start); the four row totals of a
+//           wave come by v_readlane and are walked with A^128 (by every lane — the values are uniform); the state entering a row
+//           reaches lane m of the row through (A^8)^m, applied as the binary product of the doubling matrices. Only the hand-over from
+//           a channel's lower wave to its upper wave goes through LDS (the function's one barrier; all four waves scan their rows at
+//           the same time).
+//           (The first version ran a 6-step Kogge-Stone scan over ds_bpermute shuffles in the lower wave and then, seeded with its
+//           result, in the upper wave: ~6 K cycles per filter and block, three filters per reverb block.)
 //   pass 2: each segment re-run from its true start state, writing the outputs.
-// Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative).
+// Same arithmetic as the serial recurrence up to f64 rounding (|error| ~ 1e-16 relative). The caller puts a barrier behind the call
+// (the carried state and `xchg` are rewritten by the next one).
+template <int CTRL>
+DEVO double dpp_zero_f64(double x) {  // the DPP-selected lane's value; 0 where the selection leaves the row
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+DEVO double readlane_f64(double x, int l) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
 template <bool ROUND_F32>
 DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg /* LDS [2][2] */) {
 #pragma clang fp contract(fast)  // mul + add pairs may fuse here (as in the mid stage): the scan reassociates the recurrence anyway, |error| ~ 1e-16 relative
@@ -253,8 +272,9 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
   // again in pass 2 rather than held in 16 registers: the tail stage is an out-of-line function that must fit the caller-saved registers.)
   double* seg_buf = buf + REV_IDX(n0, ch);
   // pass 1
+  const double c1 = st[ch].ic1eq, c2 = st[ch].ic2eq;   // carried state
   double s1 = 0.0, s2 = 0.0;
-  if (seg == 0) { s1 = st[ch].ic1eq; s2 = st[ch].ic2eq; }
+  if (seg == 0) { s1 = c1; s2 = c2; }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < len) {
@@ -265,37 +285,54 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
       s2 = 2.0 * v2 - s2;
     }
   }
-  // powers of the 8-frame transition matrix
-  Mat2 M{2.0 * a1 - 1.0, -2.0 * a2, 2.0 * a2, 1.0 - 2.0 * a3};
-  M = mat2_mul(M, M); M = mat2_mul(M, M); M = mat2_mul(M, M);  // A^8
-  const Mat2 M8 = M;
-  // scan inside the wave
-  auto wave_scan = [&](double& z1, double& z2) {
-    Mat2 P = M8;
+  // powers of the transition matrix: P[k] = (A^8)^(2^k). A = [[p, -q], [q, r]], and that shape is closed under multiplication: b = -c in every
+  // power, a square costs six operations
+  Mat2 P[5];
+  {
+    double pa = 2.0 * a1 - 1.0, pc = 2.0 * a2, pd = 1.0 - 2.0 * a3;
+    auto sq = [&]() { const double tr = pa + pd, c2 = pc * pc; pa = pa * pa - c2; pd = pd * pd - c2; pc = pc * tr; };
+    sq(); sq(); sq();  // A^8
+    P[0] = Mat2{pa, -pc, pc, pd};
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      double y1 = __shfl_up(z1, off, 64), y2 = __shfl_up(z2, off, 64);
-      if (lane >= off) { z1 = z1 + (P.a * y1 + P.b * y2); z2 = z2 + (P.c * y1 + P.d * y2); }
-      if (off < 32) P = mat2_mul(P, P);
+    for (int k = 1; k < 5; ++k) { sq(); P[k] = Mat2{pa, -pc, pc, pd}; }
+  }
+  // rows of 16 lanes: z_L <- sum over the row's lanes j <= L of (A^8)^(L-j) z_j
+  {
+    double y1, y2;
+    y1 = dpp_zero_f64<0x111>(s1); y2 = dpp_zero_f64<0x111>(s2); s1 = s1 + (P[0].a * y1 + P[0].b * y2); s2 = s2 + (P[0].c * y1 + P[0].d * y2);   // row_shr:1
+    y1 = dpp_zero_f64<0x112>(s1); y2 = dpp_zero_f64<0x112>(s2); s1 = s1 + (P[1].a * y1 + P[1].b * y2); s2 = s2 + (P[1].c * y1 + P[1].d * y2);   // row_shr:2
+    y1 = dpp_zero_f64<0x114>(s1); y2 = dpp_zero_f64<0x114>(s2); s1 = s1 + (P[2].a * y1 + P[2].b * y2); s2 = s2 + (P[2].c * y1 + P[2].d * y2);   // row_shr:4
+    y1 = dpp_zero_f64<0x118>(s1); y2 = dpp_zero_f64<0x118>(s2); s1 = s1 + (P[3].a * y1 + P[3].b * y2); s2 = s2 + (P[3].c * y1 + P[3].d * y2);   // row_shr:8
+  }
+  // the state entering each row of a wave: R[0] = what the wave starts from, R[r + 1] = A^128 R[r] + (total of row r)
+  const int row = lane >> 4;
+  const double t1[4] = {readlane_f64(s1, 15), readlane_f64(s1, 31), readlane_f64(s1, 47), readlane_f64(s1, 63)};
+  const double t2[4] = {readlane_f64(s2, 15), readlane_f64(s2, 31), readlane_f64(s2, 47), readlane_f64(s2, 63)};
+  double r1 = 0.0, r2 = 0.0;    // entry state of this lane's row
+  auto walk = [&](double w1, double w2) {   // returns nothing; leaves the wave's final state in (w1, w2) through the last lambda argument copy
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (row == r) { r1 = w1; r2 = w2; }
+      const double n1 = t1[r] + (P[4].a * w1 + P[4].b * w2), n2 = t2[r] + (P[4].c * w1 + P[4].d * w2);
+      w1 = n1; w2 = n2;
     }
+    if (half == 0 && lane == 0) { xchg[ch * 2] = w1; xchg[ch * 2 + 1] = w2; }
   };
-  if (half == 0) {
-    wave_scan(s1, s2);
-    if (lane == 63) { xchg[ch * 2] = s1; xchg[ch * 2 + 1] = s2; }
-  }
+  if (half == 0) walk(0.0, 0.0);
   __syncthreads();
-  double e1 = s1, e2 = s2;  // end state of this lane's segment (valid for full segments below the chunk end)
-  if (half == 1) {
-    if (lane == 0) { double x1 = xchg[ch * 2], x2 = xchg[ch * 2 + 1]; s1 = s1 + (M8.a * x1 + M8.b * x2); s2 = s2 + (M8.c * x1 + M8.d * x2); }
-    wave_scan(s1, s2);
-    e1 = s1; e2 = s2;
+  if (half == 1) walk(xchg[ch * 2], xchg[ch * 2 + 1]);
+  // start state of the segment: the row-local part (the scan value of the lane below) + (A^8)^(lane in row) applied to the row's entry state
+  double b1 = dpp_zero_f64<0x111>(s1), b2 = dpp_zero_f64<0x111>(s2);
+  {
+    const int m = lane & 15;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double q1 = P[k].a * r1 + P[k].b * r2, q2 = P[k].c * r1 + P[k].d * r2;
+      if (m & (1 << k)) { r1 = q1; r2 = q2; }
+    }
+    b1 = b1 + r1; b2 = b2 + r2;
   }
-  // start state of each segment = end state of the previous one
-  double b1 = __shfl_up(e1, 1, 64), b2 = __shfl_up(e2, 1, 64);
-  if (lane == 0) {
-    if (half == 0) { b1 = st[ch].ic1eq; b2 = st[ch].ic2eq; }
-    else { b1 = xchg[ch * 2]; b2 = xchg[ch * 2 + 1]; }
-  }
+  if (seg == 0) { b1 = c1; b2 = c2; }
   // pass 2
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -310,8 +347,7 @@ DEVO void rev_biquad_scan_t(const PgBiquadCoef& c, PgState2* st, double* buf, in
       seg_buf[2 * k] = ROUND_F32 ? (double)(float)y : y;  // `as f32` between cascaded stages (eq5.rs:318-320)
     }
   }
-  __syncthreads();  // all lanes have read the carried state
-  if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }
+  if (len > 0 && n0 + len == T) { st[ch].ic1eq = b1; st[ch].ic2eq = b2; }   // (every lane read the carried state before the barrier)
 }
 
 DEVO void rev_biquad_scan(const PgBiquadCoef& c, PgState2* st, double* buf, int T, double* xchg) { rev_biquad_scan_t<false>(c, st, buf, T, xchg); }
