@@ -32,33 +32,40 @@ DEVO void dc_scan(PgDc* dc /*[2]*/, double* buf, int T, double* xchg /* LDS [4] 
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (k < len) { y = (x[k] - xp) + r * y; xp = x[k]; }
   }
-  double r2 = r * r, r4 = r2 * r2;
-  const double r8 = r4 * r4;
-  auto wave_scan = [&](double& z) {
-    double P = r8;
+  // the scan of rev_biquad_scan_t with a scalar transition: rows of 16 lanes by DPP shifts, row totals by readlane, the row's entry state
+  // through r^(8 m) for lane m of the row
+  const double y_carried = (seg == 0) ? dc[ch].y1 : 0.0;
+  const double q1 = (r * r) * (r * r) * ((r * r) * (r * r)), q2 = q1 * q1, q4 = q2 * q2, q8 = q4 * q4, q16 = q8 * q8;
+  y = y + q1 * dpp_zero_f64<0x111>(y);
+  y = y + q2 * dpp_zero_f64<0x112>(y);
+  y = y + q4 * dpp_zero_f64<0x114>(y);
+  y = y + q8 * dpp_zero_f64<0x118>(y);
+  const int row = lane >> 4;
+  const double t[4] = {readlane_f64(y, 15), readlane_f64(y, 31), readlane_f64(y, 47), readlane_f64(y, 63)};
+  double rs = 0.0;  // the state entering this lane's row
+  auto walk = [&](double w) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double zp = __shfl_up(z, off, 64);
-      if (lane >= off) z = z + P * zp;
-      P = P * P;
-    }
+    for (int k = 0; k < 4; ++k) { if (row == k) rs = w; w = t[k] + q16 * w; }
+    if (half == 0 && lane == 0) xchg[ch] = w;
   };
-  if (half == 0) { wave_scan(y); if (lane == 63) xchg[ch] = y; }
+  if (half == 0) walk(0.0);
   __syncthreads();  // also: every lane has read its inputs before pass 2 overwrites the buffer
-  double e = y;
-  if (half == 1) {
-    if (lane == 0) y = y + r8 * xchg[ch];
-    wave_scan(y);
-    e = y;
+  if (half == 1) walk(xchg[ch]);
+  double ys = dpp_zero_f64<0x111>(y);  // start state of the segment = end state of the previous one
+  {
+    const int m = lane & 15;
+    if (m & 1) rs = rs * q1;
+    if (m & 2) rs = rs * q2;
+    if (m & 4) rs = rs * q4;
+    if (m & 8) rs = rs * q8;
+    ys = ys + rs;
   }
-  double ys = __shfl_up(e, 1, 64);  // start state of the segment = end state of the previous one
-  if (lane == 0) ys = (half == 0) ? dc[ch].y1 : xchg[ch];
-  // pass 2
+  if (seg == 0) ys = y_carried;
+  // pass 2 (the caller puts a barrier behind the call: the carried state is rewritten here)
   {
     double xp = x_in;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (k < len) { ys = (x[k] - xp) + r * ys; xp = x[k]; buf[REV_IDX(n0 + k, ch)] = ys; }
-    __syncthreads();
     if (len > 0 && n0 + len == T) { dc[ch].y1 = ys; dc[ch].x1 = xp; }
   }
 }
