@@ -626,6 +626,73 @@ DEVO void outer_cubic_channel(PgVoice* v, int ch, int C, const float* in, int in
   *consumed_samples = num_consumed * C; *produced_samples = num_produced * C;
 }
 
+// The same resampler call for all channels at once. The channels' accumulators are equal bit for bit (one ratio, the same input and output
+// counts per call), so lane 0 replays the schedule once — the f32 `sub_pos` recurrence and the consumed count of every output frame, no
+// sample touched — and every lane evaluates Hermite outputs from the staged input (window position c = the history's four frames followed
+// by the consumed input frames, as in src_write_buffer). The one-lane-per-channel walk above pays a dependent global read per input frame:
+// 0.55 ms per 1024-frame block of a ResampledSource-backed voice. Returns false (nothing done) when the channels' states differ.
+DEVO bool outer_cubic_parallel(PgVoice* v, int C, const float* in, int in_samples, float* out, int out_samples, const SrcScratch& S) {
+  const int tid = pg_tid(), nt = blockDim.x;
+  const int num_in = in_samples / C, num_out = out_samples / C;
+  if (C > 2 || num_out > SRC_OUT_CAP) return false;
+  if (C == 2 && (__float_as_uint(v->outer_sub_pos[0]) != __float_as_uint(v->outer_sub_pos[1]) || v->outer_init[0] != v->outer_init[1])) return false;
+  __syncthreads();
+  if (tid == 0) {
+    int num_consumed = 0, num_produced = 0;
+    const float ratio = v->outer_ratio;
+    float sub_pos = v->outer_sub_pos[0];
+    int initialized = v->outer_init[0];
+    if (!initialized && num_in >= 3) { initialized = 1; num_consumed = 3; }  // cubic.rs:61-69
+    if (ratio < 1.0f) {  // cubic.rs:72-90
+      while (num_produced < num_out) {
+        if (sub_pos >= 1.0f) {
+          if (num_consumed >= num_in) break;
+          num_consumed += 1;
+          sub_pos -= 1.0f;
+        }
+        S.sched_c[num_produced] = (uint16_t)num_consumed;
+        S.sched_f[num_produced] = sub_pos;
+        num_produced += 1;
+        sub_pos += ratio;
+      }
+    } else {  // cubic.rs:92-111
+      bool brk = false;
+      while (num_produced < num_out && !brk) {
+        while (sub_pos < ratio) {
+          if (num_consumed >= num_in) { brk = true; break; }
+          num_consumed += 1;
+          sub_pos += 1.0f;
+        }
+        if (brk) break;
+        sub_pos -= ratio;
+        S.sched_c[num_produced] = (uint16_t)num_consumed;
+        S.sched_f[num_produced] = 1.0f - sub_pos;
+        num_produced += 1;
+      }
+    }
+    S.ctl[0] = num_consumed * C; S.ctl[1] = num_produced * C;
+    S.ctl[2] = initialized; S.ctl[3] = (int)__float_as_uint(sub_pos);
+  }
+  __syncthreads();
+  const int consumed = S.ctl[0] / C, produced = S.ctl[1] / C;
+  // window element at position p of channel ch: the history (oldest first) in front of the consumed input frames
+  auto W = [&](int p, int ch) -> float { return p < 4 ? v->outer_input[ch][3 - p] : in[(p - 4) * C + ch]; };
+  for (int i = tid; i < produced * C; i += nt) {
+    const int k = C == 2 ? (i >> 1) : i, ch = C == 2 ? (i & 1) : 0;
+    const int c = S.sched_c[k];
+    out[i] = cubic_interp(W(c, ch), W(c + 1, ch), W(c + 2, ch), W(c + 3, ch), S.sched_f[k]);
+  }
+  float h[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (tid < C) for (int j = 0; j < 4; ++j) h[j] = W(consumed + 3 - j, tid);   // newest first
+  __syncthreads();
+  if (tid < C) {
+    for (int j = 0; j < 4; ++j) v->outer_input[tid][j] = h[j];
+    v->outer_sub_pos[tid] = __uint_as_float((uint32_t)S.ctl[3]);
+    v->outer_init[tid] = S.ctl[2];
+  }
+  return true;
+}
+
 // ResampledSource::write (src/source/resampled.rs:101-152) around the file source: the voice's PreloadedFileSource runs at
 // `out_rate` != the mixer's rate (pg_voice_options::source_rate), ConvertedSource puts a cubic ResampledSource behind it
 // (converted.rs:15-45). Two TempBuffers of 512 frames (buffer.rs:499-610) in device memory, ranges in samples; the input range is NOT
@@ -655,7 +722,7 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
       }
       // resampler.process(input_buffer.get(), output_buffer.get_mut()): channels are independent recurrences, one lane each;
       // (consumed, written) of the LAST channel count (cubic.rs:179-186)
-      if (tid < C) {
+      if (!outer_cubic_parallel(v, C, v->stage_in + v->in_start, (int)(v->in_end - v->in_start), v->stage_out, cap, S) && tid < C) {
         int consumed, produced;
         outer_cubic_channel(v, tid, C, v->stage_in + v->in_start, (int)(v->in_end - v->in_start), v->stage_out, cap, &consumed, &produced);
         if (tid == C - 1) { S.ctl[0] = consumed; S.ctl[1] = produced; }
