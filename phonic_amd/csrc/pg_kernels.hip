@@ -459,7 +459,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[chunk] != 0) : true);
     } else {
       audible_input = false;
-      if (!FAST_ONLY && unit.n_children > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
+      // (not in the four-per-CU kernel, whose registers are spoken for: the host sends graphs with nested mixers to the wide kernel instead)
+      if (!(FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) && unit.n_children > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
         const int k = seg_idx < PG_MAX_CALLS - 1 ? seg_idx : PG_MAX_CALLS - 1;
         for (int c = 0; c < unit.n_children; ++c) {
           const int2 cr = L.child_rows[unit.child_off + c];
@@ -567,6 +568,7 @@ __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(P
 // Chains without Reverb and Compressor (C3: Filter -> Chorus per voice): those two carry the large register footprints and LDS arenas.
 // Without them the same body compiles for four workgroups per CU (128 VGPRs) and its arena fits 40 KB.
 #define PG_KMASK_MID (PG_KMASK_ALL & ~((1 << 5) | (1 << 7)))
+static_assert(PG_KMASK_MID == (0x7ff & ~((1 << 5) | (1 << 7))), "pg_unit_body's test for the four-per-CU kernel");
 #ifndef PG_MID_WAVES
 #define PG_MID_WAVES 4
 #endif
