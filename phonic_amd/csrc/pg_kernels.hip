@@ -944,16 +944,17 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch
   if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags);
 }
 // One launch per round; the workgroup runs the three stages of its unit's block back to back (chunk buffer and effect state stay in
-// LDS). PG_STAGE_OUTLINE: bit k set = stage k+1 is an out-of-line call (own register allocation, but a callee that needs more than the
-// 80 caller-saved VGPRs saves the callee-saved ones it uses to scratch — ~12 KB per wave and call, real HBM traffic; -enable-ipra
-// does not remove those saves for a `tail call`ed function) ; clear = inlined into the kernel function.
-// Measured on one box (ms per headline block): 7 (all calls) 0.166, 2 0.157, 5 0.155, 0 (all inline) 0.152, 4 (tail only) 0.149.
-// (The tail stage fits the caller-saved registers: its call costs nothing.)
-// The launch structure lives in LDS (written by one lane from the scalar registers the arguments arrive in) so that the
+// LDS). PG_STAGE_OUTLINE: bit 2 set = the tail stage is an out-of-line call (own register allocation); clear = inlined into the kernel
+// function. A callee that needs more than the 80 caller-saved VGPRs saves the callee-saved ones it uses to scratch, and scratch is real
+// HBM traffic at 1024 workgroups: fifteen registers = 15 MB written and 15 MB read back per 1024-voice block (-enable-ipra does not remove
+// those saves). The tail once fitted the caller-saved set and its call was free; it no longer does (FETCH_SIZE / WRITE_SIZE showed
+// 496 MB per block against 444 algorithmic), and inlined the kernel still allocates 125 VGPRs without a spill:
+// all inline 0.0916 ms per headline block against 0.0939 with the call, same box, interleaved (C5: -0.6 %).
+// The launch structure lives in LDS (written by one lane from the scalar registers the arguments arrive in) so that an
 // out-of-line stage can take it by pointer. (The kernarg segment is not addressable from a callee: llvm.amdgcn.kernarg.segment.ptr
 // lowers to NULL outside kernels.)
 #ifndef PG_STAGE_OUTLINE
-#define PG_STAGE_OUTLINE 4
+#define PG_STAGE_OUTLINE 0
 #endif
 typedef __attribute__((address_space(3))) char* PgLdsPtr;
 #if PG_STAGE_OUTLINE & 4
