@@ -112,7 +112,10 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     }
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     if (!mx.children.empty()) u.staged = 0;  // sums its sub-mixers' rows first (previous level): not a staged unit; the fast kernels take it in steady state
-    for (int v : mx.voices) if (g->voices[v].outer || g->voices[v].stream) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging / host-fed ring: exact serial kernel
+    for (int v : mx.voices) {
+      if (g->voices[v].outer) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging: exact serial kernel
+      else if (g->voices[v].stream) u.staged = 0;                     // host-fed ring: the fast kernels read it, the staged ones do not carry the code
+    }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
     for (int v : mx.voices) vidx.push_back(g->voices[v].dev_index);
@@ -144,7 +147,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
     u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
-    u.static_defer = (g->voices[v].outer || g->voices[v].stream) ? 1 : 0;
+    u.static_defer = g->voices[v].outer ? 1 : 0;
     u.voice0 = g->voices[v].dev_index;
     vidx.push_back(g->voices[v].dev_index);
     g->order.push_back(slot);

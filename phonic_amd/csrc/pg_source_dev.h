@@ -757,7 +757,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   int wf;
   if (GLIDE && v->outer_on) {  // (units holding such a voice always render on the generic kernel)
     wf = resampled_source_write(v, out, frames, pending_stop, S);
-  } else if (GLIDE && v->stream_on) {  // (likewise)
+  } else if (v->stream_on) {  // a host-fed ring: every kernel
     wf = stream_source_write(v, out, frames, pending_stop);
   } else {
     int post_on;

@@ -128,6 +128,44 @@ def test_stream_voice_underrun_ring_full_stop_and_end():
     assert ei.value.code == _capi.PG_ERR_NOT_FOUND
 
 
+def test_fed_voices_in_super_block_launches_equal_single_block_launches():
+    """Host-fed voices are rendered by the fast kernels in steady state (the ring read is a copy), so a write of several blocks takes them through
+    one super-block launch: the result must equal block-by-block launches bit for bit — voices that end inside the call, one that underruns
+    (fed less than the call consumes, not ended), one that starts inside it, and a reverb unit next to them."""
+    def render(max_blocks):
+        g = graph()
+        g.set_max_blocks_per_launch(max_blocks)
+        rng = np.random.default_rng(5)
+        vs = []
+        for i in range(12):
+            m = g.add_mixer()
+            if i % 3 == 0:
+                g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            elif i % 3 == 1:
+                g.add_effect(m, _capi.FX_FILTER, params={"cuto": 2500.0})
+            ch = 1 if i % 4 == 3 else 2
+            v = g.add_stream_voice(m, ch, SR, 32768, volume=0.5, panning=-0.4 + 0.07 * i, start_time=0 if i != 5 else 3000)
+            frames = int(rng.integers(2000, 20000))
+            g.feed_voice(v, pcm_for(i, SR, 0.5, ch)[: frames * ch])
+            if i != 7:
+                g.end_stream_voice(v)       # voice 7 underruns and stays
+            vs.append(v)
+        out = np.zeros(8 * 1024 * 2, np.float32)
+        chunks = []
+        for k in range(3):                   # the first call settles into the steady state, the later ones are super-block launches
+            assert g.write(out, k * 8 * 1024) == out.size
+            chunks.append(out.copy())
+        consumed = [g.stream_voice_consumed(v) for v in vs]
+        g.close()
+        return np.concatenate(chunks), consumed
+
+    a, ca = render(8)
+    b, cb = render(1)
+    assert np.abs(a).max() > 1e-3
+    assert np.array_equal(a, b)
+    assert ca == cb
+
+
 def test_feed_and_write_allocate_nothing():
     """The rings are reserved by add_stream_voice; feeding copies into pinned memory, the write moves it with asynchronous copies on the caller's
     stream: no allocation, no release, no host wait, no blocking copy (pg_debug_hip_calls)."""

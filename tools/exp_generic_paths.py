@@ -35,6 +35,12 @@ def build(kind, g):
             g.add_effect(m, _capi.FX_REVERB, reverb_seeds=seeds)
             g.add_voice(m, workloads.tone_buffer(i, 44100, 2.0), 2, 44100, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER,
                         source_rate=32000)
+        elif kind == "stream":          # the same PCM fed by the host into a device ring (pg_graph_add_stream_voice): 2 s up front, not looped
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=seeds)
+            pcm = workloads.tone_buffer(i, 48000, 2.0)
+            sv = g.add_stream_voice(m, 2, 48000, len(pcm) // 2, volume=vol, panning=pan)
+            g.feed_voice(sv, pcm)
         elif kind == "nested":          # the reverb sits on a parent mixer, the voice on a sub-mixer of it
             parent = g.add_mixer()
             g.add_effect(parent, _capi.FX_REVERB, reverb_seeds=seeds)
@@ -65,6 +71,6 @@ def run(kind, per_call):
     g.close()
 
 
-for kind in ("headline", "resampled", "nested"):
+for kind in ("headline", "stream", "resampled", "nested"):
     for per_call in (1, 16):
         run(kind, per_call)
