@@ -308,6 +308,34 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           pp += (uint64_t)c * C;  // num_in > piece >= c: the loop end cannot be reached
           produced = piece;
           linear = 1;
+        } else if (ratio >= 1.0f && ratio <= 4.0f && initialized && sub_pos >= 0.0f) {
+          // The same for ratio >= 1 (cubic.rs:92-111; a sampler's notes above the file's pitch): an output frame pushes input frames while
+          // sub_pos < ratio — at most K = ceil(ratio) of them, since sub_pos >= 0 — then steps back by ratio. With more than piece * K input
+          // frames in front of the loop end the `consumed >= num_in` exit is dead and the K conditional pushes are straight-line code: the
+          // same comparisons, additions of 1.0f and the subtraction in the same order (the general loop below pays two branches and an LDS
+          // store per pushed frame).
+          const int K = (int)ceilf(ratio);
+          if (num_in > (uint64_t)piece * (uint64_t)K + (uint64_t)K) {
+            float sp = sub_pos;
+            int cc = c;
+            asm volatile("" : "+v"(sp), "+v"(cc));
+            bool short_of = false;
+            for (int k = 0; k < piece; ++k) {
+              for (int j = 0; j < K; ++j) { const bool lt = sp < ratio; cc += lt ? 1 : 0; sp = lt ? sp + 1.0f : sp; }
+              short_of |= sp < ratio;
+              sp -= ratio;
+              S.sched_c[k] = (uint16_t)cc;
+              S.sched_f[k] = 1.0f - sp;
+            }
+            if (!short_of) {  // (always: K pushes reach ratio from any sub_pos >= 0; the general loop takes over otherwise)
+              sub_pos = sp;
+              c = cc;
+              S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
+              pp += (uint64_t)c * C;
+              produced = piece;
+              linear = 1;
+            }
+          }
         }
       }
       S.ctl[2] = linear;

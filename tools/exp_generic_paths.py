@@ -35,6 +35,11 @@ def build(kind, g):
             g.add_effect(m, _capi.FX_REVERB, reverb_seeds=seeds)
             g.add_voice(m, workloads.tone_buffer(i, 44100, 2.0), 2, 44100, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER,
                         source_rate=32000)
+        elif kind.startswith("pitch"):  # a sampler's notes: the headline layout at another playback speed (pitchNN = speed N.N; ratio = 0.919 * speed)
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=seeds)
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 2.0), 2, 44100, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER,
+                        speed=float(kind[5:]) / 10.0)
         elif kind == "stream":          # the same PCM fed by the host into a device ring (pg_graph_add_stream_voice): 2 s up front, not looped
             m = g.add_mixer()
             g.add_effect(m, _capi.FX_REVERB, reverb_seeds=seeds)
@@ -71,6 +76,7 @@ def run(kind, per_call):
     g.close()
 
 
-for kind in ("headline", "stream", "resampled", "nested"):
+KINDS = sys.argv[2].split(",") if len(sys.argv) > 2 else ("headline", "stream", "resampled", "nested")
+for kind in KINDS:
     for per_call in (1, 16):
         run(kind, per_call)
