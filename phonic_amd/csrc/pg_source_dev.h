@@ -161,6 +161,92 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
   return false;
 }
 
+// The same idea for ratio in [1, 2) (cubic.rs:92-111: voices played up to an octave above the file's pitch). Per output frame the reference
+// runs  while sub_pos < ratio { push an input frame; sub_pos += 1 };  sub_pos -= ratio;  and interpolates at 1 - sub_pos. In units of
+// u = 2^-23 (the ulp of the ratio and of every value in [1, 2)) the loop-top state S is an integer in [0, ONE], ONE = 2^23: the first push is
+// exact; a second one (taken iff S + ONE < R, i.e. S + D < ONE with D = 2 ONE - R) lands in [2, 3) where the ulp is 2u — an odd value is a tie
+// and goes to the multiple of four: rho of the schedule above, on S — and the subtraction is exact. So
+//     S' = S + D + rho(S)   (two pushes)      or      S' = S + D - ONE   (one push),
+// the unrounded sequence is X_j = (S_0 + j D) mod ONE in closed form, the true one X_j + d_j with d_{j+1} = d_j + rho(X_j + d_j) on the steps
+// that push twice: the same 4-entry increment tables, the same scan, the same restart where a decision of the rounded sequence differs from
+// the closed form's. Consumed frames after output j: 2 (j + 1) - floor((S_0 + (j + 1) D) / ONE). Model and check against the serial
+// recurrence: tests/host/resampler_schedule_model.py (parallel_up), tests/test_host_models.py.
+DEVO bool sched_parallel_up(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
+  const int tid = pg_tid(), lane = tid & 63, wave = tid >> 6;
+  const int ONE = 1 << 23;
+  const int R = (int)(ratio * 8388608.0f);  // exact: ratio in [1, 2)
+  const int D = 2 * ONE - R;                // in (0, ONE]
+  int* s_viol = scr;          // first output whose push count differs from the closed form's
+  int* s_start = scr + 1;     // restart: output, its exact loop-top state, frames consumed in front of it (output < 0: give up)
+  int* s_res = scr + 4;       // c_total, sp_out bits
+  SchedTab* s_wave = (SchedTab*)(scr + 8);  // [4 waves] wave totals
+  if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * 8388608.0f); s_start[2] = 0; }
+  for (int iter = 0; iter < 16; ++iter) {
+    __syncthreads();
+    const int k0 = s_start[0], S = s_start[1], cc0 = s_start[2];
+    if (k0 < 0) break;
+    if (tid == 0) *s_viol = 0x7fffffff;
+    int X0[4]; int nowrap[4];
+    SchedTab T[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * tid + e, j = k - k0;
+      const int x0 = (int)(((unsigned)S + (unsigned)(j > 0 ? j : 0) * (unsigned)D) & (unsigned)(ONE - 1));  // the low 23 bits of a 32-bit product suffice
+      X0[e] = x0;
+      nowrap[e] = x0 + D < ONE;
+      T[e] = (j >= 0 && k < piece && nowrap[e]) ? schedtab_step(x0) : 0ull;
+    }
+    SchedTab incl = schedtab_compose(schedtab_compose(T[0], T[1]), schedtab_compose(T[2], T[3]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const SchedTab b = __shfl_up(incl, off, 64);
+      if (lane >= off) incl = schedtab_compose(b, incl);
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    SchedTab excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0ull;
+    __syncthreads();
+    int d = 0;  // d at the start output is 0; tables in front of it are identities
+    for (int w = 0; w < wave; ++w) d += schedtab_at(s_wave[w], d);
+    d += schedtab_at(excl, d);
+    int viol = 0x7fffffff;
+    int Se[4], ccb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * tid + e, j = k - k0;
+      const int Sj = X0[e] + d;                       // exact loop-top state while every earlier decision agreed
+      const int dn = d + schedtab_at(T[e], d);
+      const int Sn = Sj + D - (nowrap[e] ? 0 : ONE) + (dn - d);
+      const int jj = j > 0 ? j : 0;
+      const int before = cc0 + 2 * jj - (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)jj * (unsigned)D) >> 23);
+      Se[e] = Sj; ccb[e] = before;
+      d = dn;
+      if (j >= 0 && k < piece) {
+        if (((Sj + D < ONE) != (nowrap[e] != 0) || Sj < 0 || Sj > ONE) && viol == 0x7fffffff) viol = k;
+        const int cc = before + (nowrap[e] ? 2 : 1);
+        oc[k] = (uint16_t)cc;
+        of[k] = (float)(ONE - Sn) * 1.1920928955078125e-07f;
+        if (k == piece - 1) { s_res[0] = cc; s_res[1] = (int)__float_as_uint((float)Sn * 1.1920928955078125e-07f); }
+      }
+    }
+    if (viol != 0x7fffffff) atomicMin(s_viol, viol);
+    __syncthreads();
+    const int kv = *s_viol;
+    if (kv == 0x7fffffff) { c_total = s_res[0]; sp_out = __uint_as_float((uint32_t)s_res[1]); return true; }
+    // restart AT the output whose decision differs: its loop-top state is exact (every earlier decision agreed)
+    __syncthreads();
+    if (kv >= 4 * tid && kv < 4 * tid + 4) {
+      const int e = kv - 4 * tid;
+      const int Sv = e == 0 ? Se[0] : (e == 1 ? Se[1] : (e == 2 ? Se[2] : Se[3]));
+      const int cb = e == 0 ? ccb[0] : (e == 1 ? ccb[1] : (e == 2 ? ccb[2] : ccb[3]));
+      if (Sv < 0 || Sv >= ONE || kv == k0) s_start[0] = -1;   // outside the closed form's range, or no progress: the serial walk takes the piece
+      else { s_start[0] = kv; s_start[1] = Sv; s_start[2] = cb; }
+    }
+  }
+  __syncthreads();
+  return false;
+}
+
 // sample count -> frame count. A 64-bit division is a long software routine on this target; files are mono or stereo.
 DEVO uint64_t div_channels(uint64_t x, int C) { return C == 2 ? (x >> 1) : (C == 1 ? x : x / (uint64_t)C); }
 
@@ -241,6 +327,21 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           for (int k = 0; k < 4; ++k) { const int j = k * nt + tid; win_x[k] = j < bound ? src[j] : 0ull; }
         }
         par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+      } else {
+        const float t23 = sp0 * 8388608.0f;
+        if (ratio >= 1.0f && ratio < 2.0f && v->initialized[0] && num_in0 > 2ull * (uint64_t)piece + 2ull && sp0 >= 0.0f && sp0 < 1.0f && t23 == floorf(t23) && nt == 256) {
+          if (C == 2) {  // (as above: at most two input frames per output)
+            typedef __attribute__((address_space(1))) const unsigned long long gu64;
+            gu64* src = (gu64*)(v->pcm) + (uint64_t)(pp0 / 2);
+            int bound = (int)((float)piece * ratio) + 3;
+            if ((uint64_t)bound > num_in0) bound = (int)num_in0;
+            if (bound > 4 * nt) bound = 4 * nt;
+            win_pref = bound;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int j = k * nt + tid; win_x[k] = j < bound ? src[j] : 0ull; }
+          }
+          par_ok = sched_parallel_up(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+        }
       }
     }
     if (tid == 0) {
