@@ -161,7 +161,7 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
   return false;
 }
 
-// The same idea for ratio in [1, 2) (cubic.rs:92-111: voices played up to an octave above the file's pitch). Per output frame the reference
+// The same idea for ratio in [1, 4) (cubic.rs:92-111: voices played up to two octaves above the file's pitch); written out for [1, 2): Per output frame the reference
 // runs  while sub_pos < ratio { push an input frame; sub_pos += 1 };  sub_pos -= ratio;  and interpolates at 1 - sub_pos. In units of
 // u = 2^-23 (the ulp of the ratio and of every value in [1, 2)) the loop-top state S is an integer in [0, ONE], ONE = 2^23: the first push is
 // exact; a second one (taken iff S + ONE < R, i.e. S + D < ONE with D = 2 ONE - R) lands in [2, 3) where the ulp is 2u — an odd value is a tie
@@ -173,14 +173,20 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
 // recurrence: tests/host/resampler_schedule_model.py (parallel_up), tests/test_host_models.py.
 DEVO bool sched_parallel_up(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
   const int tid = pg_tid(), lane = tid & 63, wave = tid >> 6;
-  const int ONE = 1 << 23;
-  const int R = (int)(ratio * 8388608.0f);  // exact: ratio in [1, 2)
-  const int D = 2 * ONE - R;                // in (0, ONE]
+  // ratio in [1, 2): unit 2^-23, at most K = 2 pushes, the second one rounds (it crosses 2.0). ratio in [2, 4): unit 2^-22 (the ulp of the ratio
+  // and of [2, 4)), K = 3 or 4 pushes; pushes two and three are exact on that grid, a fourth crosses 4.0 and rounds the same way.
+  const int SH = ratio < 2.0f ? 23 : 22;
+  const int ONE = 1 << SH;
+  const float unit = ratio < 2.0f ? 1.1920928955078125e-07f : 2.384185791015625e-07f;
+  const int R = (int)(ratio * (float)ONE);  // exact
+  const int K = R / ONE + 1;                // most pushes per output: 2, 3 or 4
+  const bool rounds = K != 3;
+  const int D = K * ONE - R;                // in (0, ONE]
   int* s_viol = scr;          // first output whose push count differs from the closed form's
   int* s_start = scr + 1;     // restart: output, its exact loop-top state, frames consumed in front of it (output < 0: give up)
   int* s_res = scr + 4;       // c_total, sp_out bits
   SchedTab* s_wave = (SchedTab*)(scr + 8);  // [4 waves] wave totals
-  if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * 8388608.0f); s_start[2] = 0; }
+  if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * (float)ONE); s_start[2] = 0; }
   for (int iter = 0; iter < 16; ++iter) {
     __syncthreads();
     const int k0 = s_start[0], S = s_start[1], cc0 = s_start[2];
@@ -194,7 +200,7 @@ DEVO bool sched_parallel_up(float ratio, float sp0, int piece, uint16_t* oc, flo
       const int x0 = (int)(((unsigned)S + (unsigned)(j > 0 ? j : 0) * (unsigned)D) & (unsigned)(ONE - 1));  // the low 23 bits of a 32-bit product suffice
       X0[e] = x0;
       nowrap[e] = x0 + D < ONE;
-      T[e] = (j >= 0 && k < piece && nowrap[e]) ? schedtab_step(x0) : 0ull;
+      T[e] = (rounds && j >= 0 && k < piece && nowrap[e]) ? schedtab_step(x0) : 0ull;
     }
     SchedTab incl = schedtab_compose(schedtab_compose(T[0], T[1]), schedtab_compose(T[2], T[3]));
 #pragma unroll
@@ -218,15 +224,15 @@ DEVO bool sched_parallel_up(float ratio, float sp0, int piece, uint16_t* oc, flo
       const int dn = d + schedtab_at(T[e], d);
       const int Sn = Sj + D - (nowrap[e] ? 0 : ONE) + (dn - d);
       const int jj = j > 0 ? j : 0;
-      const int before = cc0 + 2 * jj - (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)jj * (unsigned)D) >> 23);
+      const int before = cc0 + K * jj - (int)(((unsigned long long)(unsigned)S + (unsigned long long)(unsigned)jj * (unsigned)D) >> SH);
       Se[e] = Sj; ccb[e] = before;
       d = dn;
       if (j >= 0 && k < piece) {
         if (((Sj + D < ONE) != (nowrap[e] != 0) || Sj < 0 || Sj > ONE) && viol == 0x7fffffff) viol = k;
-        const int cc = before + (nowrap[e] ? 2 : 1);
+        const int cc = before + (nowrap[e] ? K : K - 1);
         oc[k] = (uint16_t)cc;
-        of[k] = (float)(ONE - Sn) * 1.1920928955078125e-07f;
-        if (k == piece - 1) { s_res[0] = cc; s_res[1] = (int)__float_as_uint((float)Sn * 1.1920928955078125e-07f); }
+        of[k] = (float)(ONE - Sn) * unit;
+        if (k == piece - 1) { s_res[0] = cc; s_res[1] = (int)__float_as_uint((float)Sn * unit); }
       }
     }
     if (viol != 0x7fffffff) atomicMin(s_viol, viol);
@@ -328,9 +334,9 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         }
         par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
       } else {
-        const float t23 = sp0 * 8388608.0f;
-        if (ratio >= 1.0f && ratio < 2.0f && v->initialized[0] && num_in0 > 2ull * (uint64_t)piece + 2ull && sp0 >= 0.0f && sp0 < 1.0f && t23 == floorf(t23) && nt == 256) {
-          if (C == 2) {  // (as above: at most two input frames per output)
+        const float t23 = sp0 * (ratio < 2.0f ? 8388608.0f : 4194304.0f);
+        if (ratio >= 1.0f && ratio < 4.0f && v->initialized[0] && num_in0 > 4ull * (uint64_t)piece + 4ull && sp0 >= 0.0f && sp0 < 1.0f && t23 == floorf(t23) && nt == 256) {
+          if (C == 2) {  // (as above: at most ceil(ratio) input frames per output — the piece is capped for that)
             typedef __attribute__((address_space(1))) const unsigned long long gu64;
             gu64* src = (gu64*)(v->pcm) + (uint64_t)(pp0 / 2);
             int bound = (int)((float)piece * ratio) + 3;

@@ -59,16 +59,20 @@ def serial_up(sp0, ratio, n):
         oc[k] = cc; of[k] = np.float32(one - sp)
     return oc, of, sp
 def parallel_up(sp0, ratio, n):
+    """ratio in [1, 2): unit 2^-23, K = 2 pushes at most, the second one rounds. ratio in [2, 4): unit 2^-22, K = 3 or 4; only a fourth push rounds."""
+    SH = 23 if np.float32(ratio) < 2 else 22
+    ONE = 1 << SH
     S0 = float(np.float32(sp0)) * ONE; R = float(np.float32(ratio)) * ONE
-    if S0 != int(S0) or R != int(R) or not (0 <= S0 < ONE) or not (ONE <= R < 2 * ONE): return None
-    S0 = int(S0); R = int(R); D = 2 * ONE - R
+    if S0 != int(S0) or R != int(R) or not (0 <= S0 < ONE) or not (ONE <= R < 4 * ONE): return None
+    S0 = int(S0); R = int(R); K = R // ONE + 1; D = K * ONE - R
+    rounds = K != 3
     j = np.arange(n + 1, dtype=np.int64)
     X0 = (S0 + j * D) % ONE                 # unrounded loop-top state of output j
-    nowrap0 = X0 + D < ONE                  # two pushes
+    nowrap0 = X0 + D < ONE                  # K pushes (else K - 1)
     T = np.zeros((n + 1, 4), np.int64)      # step j: delta_{j+1} = delta_j + T_j[delta_j & 3]
     for m in range(4):
         x = (X0 + m) & 3
-        T[:, m] = np.where(nowrap0 & ((x & 1) == 1), x - 2, 0)
+        T[:, m] = np.where(nowrap0 & ((x & 1) == 1) & rounds, x - 2, 0)
     d = 0; delta = np.zeros(n + 2, np.int64)
     for kk in range(n + 1):
         d = d + T[kk, d & 3]; delta[kk + 1] = d
@@ -76,5 +80,5 @@ def parallel_up(sp0, ratio, n):
     ok = np.all((S[:n] + D < ONE) == nowrap0[:n]) and np.all(S >= 0) and np.all(S <= ONE)
     if not ok: return None
     wraps = (S0 + (j[1:]) * D) // ONE       # wraps among the first j+1 steps
-    cc = 2 * j[1:] - wraps
+    cc = K * j[1:] - wraps
     return cc[:n], ((ONE - S[1:n + 1]).astype(np.float64) / ONE).astype(np.float32), np.float32(S[n] / ONE)

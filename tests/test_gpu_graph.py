@@ -345,9 +345,9 @@ def test_staged_pipeline_tail_bypass_and_parameter_handover():
 
 @pytest.mark.parametrize("rate,block,n_blocks", [(44100, 1024, 400), (32000, 1000, 60), (40000, 777, 80), (16000, 1024, 40), (22050, 512, 60), (47999, 1024, 60),
                                                  (88200, 1024, 300), (64000, 1000, 120), (50000, 777, 120), (48001, 1024, 120), (70000, 1024, 200), (96000, 512, 60),
-                                                 (130000, 1024, 40)])
+                                                 (130000, 1024, 120), (150000, 1024, 120), (176400, 1000, 120), (100000, 640, 60), (191999, 1024, 60)])
 def test_resampler_schedule_bit_exact_over_many_blocks(rate, block, n_blocks):
-    """The f32 sub_pos schedule has several device implementations — the exact time-parallel ones (ratio in [0.5, 1) and in [1, 2): closed
+    """The f32 sub_pos schedule has several device implementations — the exact time-parallel ones (ratio in [0.5, 1) and in [1, 4): closed
     form + rounding-table scan, restarted where a decision differs, which happens in ~0.6 % of the blocks, hence 300-400 blocks at 44.1 and
     88.2 kHz), the schedule cache (ratio < 0.5, two voices of one class), the straight-line serial walks and the general serial replay (near
     the loop end of the 0.11 s file, every few blocks). All must equal the reference's serial recurrence bit for bit: a single unit-gain
