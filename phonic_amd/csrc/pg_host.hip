@@ -113,8 +113,8 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     if (!mx.children.empty()) u.staged = 0;  // sums its sub-mixers' rows first (previous level): not a staged unit; the fast kernels take it in steady state
     for (int v : mx.voices) {
-      if (g->voices[v].outer) { u.static_defer = 1; u.staged = 0; }  // ResampledSource staging: exact serial kernel
-      else if (g->voices[v].stream) u.staged = 0;                     // host-fed ring: the fast kernels read it, the staged ones do not carry the code
+      if (g->voices[v].outer || g->voices[v].stream) u.staged = 0;  // ResampledSource staging / host-fed ring: the fast kernels render them, the staged ones do not carry the code
+      if (g->voices[v].outer) g->any_outer = true;
     }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
     u.voice0 = mx.voices.empty() ? 0 : g->voices[mx.voices[0]].dev_index;
@@ -147,7 +147,8 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     int slot = g->source_unit_of_voice[v];
     PgUnit& u = topo[slot];
     u.voice_off = (int)vidx.size(); u.n_voices = 1; u.n_fx = 0; u.fx_off = 0;
-    u.static_defer = g->voices[v].outer ? 1 : 0;
+    u.static_defer = 0;
+    if (g->voices[v].outer) g->any_outer = true;
     u.voice0 = g->voices[v].dev_index;
     vidx.push_back(g->voices[v].dev_index);
     g->order.push_back(slot);
@@ -847,7 +848,7 @@ const char* pg_graph_dominant_kernel(pg_graph* g) {
     if (n_lean > 0 && g->n_staged_wide > 0) return "pg_stage_fused_kernel + pg_stage_fused_wide_kernel";
     return g->n_staged_wide > 0 ? "pg_stage_fused_wide_kernel" : "pg_stage_fused_kernel";
   }
-  return g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || g->levels.size() > 1) ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast_mid") : "pg_unit_kernel_fast";
+  return g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || g->levels.size() > 1 || g->any_outer) ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast_mid") : "pg_unit_kernel_fast";
 }
 int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) {
   g->timing_period = every_n_rounds < 0 ? 0 : every_n_rounds;
@@ -1024,7 +1025,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
     hipEvent_t e0 = timed_here ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed_here ? g->ev_pool[g->ev_used].second : nullptr;
     if (g->fast) {
       // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
-      L.mode = 1; L.wide = g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || nested) ? 1 : 2) : 0;  // (2: the four-per-CU kernel; it does not sum nested mixers)
+      L.mode = 1; L.wide = g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || nested || g->any_outer) ? 1 : 2) : 0;  // (2: the four-per-CU kernel; it neither sums nested mixers nor stages a ResampledSource)
       // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
       const int n_lean = lv.n_staged - lv.n_staged_wide;
       const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;

@@ -473,7 +473,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       }
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
-        audible_input |= voice_process<!FAST_ONLY>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word);
+        audible_input |= voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word);
       }
     }
     PG_STAMP(L.diag, 1);
@@ -757,7 +757,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   bool audible_input = false;
   for (int vi = 0; vi < n_voices; ++vi) {
     PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[voice_off + vi]];
-    audible_input |= voice_process<false>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word);
+    audible_input |= voice_process<false, 0>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word);
   }
   PG_STAMP(L.diag, 1);
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;

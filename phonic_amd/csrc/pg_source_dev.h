@@ -833,6 +833,7 @@ DEVO bool outer_cubic_parallel(PgVoice* v, int C, const float* in, int in_sample
 // (converted.rs:15-45). Two TempBuffers of 512 frames (buffer.rs:499-610) in device memory, ranges in samples; the input range is NOT
 // shrunk to what the source delivered (only resamplers with a required input size pad, :120-127), so an exhausted source leaves a
 // stale tail that is resampled like the reference does. `frames` frames of the file layout into `out`; returns frames written.
+template <bool GLIDE>
 DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S) {
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
@@ -851,7 +852,7 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
         __syncthreads();
         int post_on;
         if (v->stream_on) (void)stream_source_write(v, v->stage_in, 512, stop);
-        else (void)file_source_write<true>(v, v->stage_in, 512, stop, S, nullptr, false, &post_on);
+        else (void)file_source_write<GLIDE>(v, v->stage_in, 512, stop, S, nullptr, false, &post_on);
         __threadfence_block();
         __syncthreads();
       }
@@ -884,15 +885,17 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
 // PreloadedFileSource::write [+ ResampledSource::write] + ChannelMappedSource::write (mapped.rs:61-99) +
 // AmplifiedSource::write (amplified.rs:93-104) + PannedSource::write (panned.rs:93-104).
 // Renders `frames` stereo output frames into `out` (LDS, 2*frames floats); returns stereo samples written.
-template <bool GLIDE>
+// ADAPTERS: 0 = the kernel variant never sees a ResampledSource-backed or host-fed voice (the staged kernels: the host keeps such units out);
+// 1 = host-fed voices only (the four-per-CU fast kernel: a graph with a ResampledSource takes the wide kernel instead); 2 = both.
+template <bool GLIDE, int ADAPTERS>
 DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
   *added = 0;
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
   int wf;
-  if (GLIDE && v->outer_on) {  // (units holding such a voice always render on the generic kernel)
-    wf = resampled_source_write(v, out, frames, pending_stop, S);
-  } else if (v->stream_on) {  // a host-fed ring: every kernel
+  if (ADAPTERS == 2 && v->outer_on) {
+    wf = resampled_source_write<GLIDE>(v, out, frames, pending_stop, S);
+  } else if (ADAPTERS >= 1 && v->stream_on) {  // a host-fed ring
     wf = stream_source_write(v, out, frames, pending_stop);
   } else {
     int post_on;
@@ -942,7 +945,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 
 // MixedSource::process_sources for ONE playing source (src/source/mixed.rs:558-624): renders into `tmp` and adds
 // into `sig`. Returns true when the source produced output.
-template <bool GLIDE>
+template <bool GLIDE, int ADAPTERS = 2>
 DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
                         const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0) {
   SrcScratch S = S0;
@@ -985,7 +988,7 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     if (samples_until_stop < remaining) remaining = samples_until_stop;
     int to_write = (int)(remaining < 8192 ? remaining : 8192);
     int added;
-    int written = voice_write<GLIDE>(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
+    int written = voice_write<GLIDE, ADAPTERS>(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
     if (!added) for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
     __syncthreads();
     total_written += written;
