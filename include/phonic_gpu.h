@@ -221,7 +221,8 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
  * stereo, volume, panning, start time (`opt`: volume, panning, start_time are used). A short ring read is a source that delivered
  * less (the rest of the block is silent); the voice ends when the host has ended the stream and everything fed has been played, or
  * at a stop. Device ring and pinned staging ring are reserved here: feed and write allocate nothing. Returns a voice id >= 0 (valid
- * for set_voice_volume / _panning / stop_voice like any other). Units holding such a voice render on the exact serial kernel. */
+ * for set_voice_volume / _panning / stop_voice like any other). In steady state such a voice is rendered by the same time-parallel kernels
+ * as a file voice (the ring read is a copy), also inside a write of several blocks. */
 int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt);
 /* The next n_frames frames of the host's source (interleaved). Owner thread, before the write that should play them; they reach the
  * device on that write's stream. PG_ERR_QUEUE_FULL (nothing taken) when fed - consumed + n_frames would exceed the capacity, with

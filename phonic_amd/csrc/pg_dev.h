@@ -231,7 +231,7 @@ struct PgUnit {
   uint64_t silence_counter;     // SubMixerProcessor (src/source/mixed/submixer.rs:23)
   int32_t audible;              // result of the last chunk: contributes to the parent's `audible_input`
   int32_t deferred;             // set by the fast kernel when the unit must be rendered by the generic kernel
-  int32_t static_defer;         // host: the chain holds an effect kind without a time-parallel path -> always generic kernel
+  int32_t static_defer;         // host: the chain holds an effect kind without a time-parallel path -> always generic kernel (no stock kind or layout sets it any more)
   int32_t maybe_ramping;        // device: a parameter command was applied and some smoother may still ramp (cleared by the generic
                                 // kernel once every effect of the unit is back in steady state)
   int32_t voice0;               // host: device index of the unit's first voice (skips one dependent load at kernel start)
