@@ -191,6 +191,10 @@ struct PgVoice {
   int32_t stream_on;
   uint32_t stream_cap;
   uint64_t stream_fed;
+  // MixedSource::process_sources marks an exhausted transient source inactive but keeps calling it for the rest of the write; it is removed
+  // when the write ends (mixed.rs:612-616, 715). Only a ResampledSource makes that audible (asked again, it refills its stale input range and
+  // plays on): the end position of the write in which such a voice was marked.
+  uint64_t zombie_end;
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.
@@ -298,6 +302,7 @@ struct PgLaunch {
   unsigned long long* host_feedback;  // pinned host word: the generic kernel reports (round << 32 | units it found deferred)
   uint32_t round;         // launch counter of this round
   int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
+  uint64_t call_end;      // position at which the MixedSource::write call this launch belongs to ends (see PgVoice::zombie_end)
   const float* rows_base; // nested sub-mixers: row 0 of the per-unit output table (unit_out points at this launch's level) ...
   const int2* child_rows; // ... and {row, unit slot} of every nested sub-mixer, indexed by PgUnit::child_off
   // Super-block launch (steady state, no command inside): every workgroup of the fast / staged kernels renders n_chunks consecutive

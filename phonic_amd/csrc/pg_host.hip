@@ -987,6 +987,7 @@ static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipS
   L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
   L.out_stride = g->stride;
   L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
+  L.call_end = g->call_end;
   L.diag = g->d_diag;
   L.n_chunks = n_chunks; L.chunk_stride = (uint64_t)g->unit_out_rows * g->stride; L.error_word = g->d_error;
   L.fast_scratch_bytes = (uint32_t)pg_fast_scratch_bytes(g->fast_kind_mask);
@@ -1141,7 +1142,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   // a caller that moves from one stream to another without a graph mutation in between: the tables and rings are ordered per stream
   if (g->last_stream && g->last_stream != stream) { if (pg_stream_sync(g->last_stream) != hipSuccess) { g->failed = true; return 0; } g->cmds_since_sync = 0; }
   g->last_stream = stream;
-  if (begin) graph_begin_write(g, pos);
+  if (begin) { graph_begin_write(g, pos); g->call_end = pos + n_samples / 2; }
   if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
   if (!g->stream_voices.empty() && flush_stream_feeds(g, stream)) { g->failed = true; return 0; }
   if (graph_is_empty(g)) return 0;

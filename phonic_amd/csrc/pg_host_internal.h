@@ -219,6 +219,7 @@ struct pg_graph {
   bool failed = false;  // sticky: GuardedSource semantics
   int fast = 1;
   bool wide = false;  // some sub-mixer chain holds Filter / Eq5 / Distortion: use the wide fast-kernel variant
+  uint64_t call_end = 0;   // end position of the write call being rendered (the sharded handle sets it for the whole write, across its segments)
   bool any_outer = false;  // some voice sits behind a ResampledSource: the four-per-CU fast kernel does not carry that code (sticky, like `wide`)
   uint32_t fast_kind_mask = 0;  // effect kinds held by the units the fast kernels render: sizes their LDS arena (pg_fast_scratch_bytes)
   int timing_period = 0;   // time every n-th round with a hipEvent pair (0: never, the default); pg_graph_set_timing_period creates the pairs

@@ -471,9 +471,17 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
         }
         __syncthreads();
       }
+      // where the MixedSource::write call that this segment belongs to ends (PgVoice::zombie_end): the whole write for a source of the main
+      // mixer; for a sub-mixer the parent's current chunk — up to its next call boundary (CMD_CALL_SPLIT) or the end of the block
+      uint64_t call_end_pos = L.call_end;
+      if (unit.kind != UNIT_SOURCE) {
+        int split = N;
+        if (!FAST_ONLY) for (int cj = ci; cj < L.n_cmds && L.cmds[cj].unit == u; ++cj) if (L.cmds[cj].type == CMD_CALL_SPLIT && (int)L.cmds[cj].frame > frame0) { split = (int)L.cmds[cj].frame; break; }
+        call_end_pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)split;
+      }
       for (int vi = 0; vi < unit.n_voices; ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
-        audible_input |= voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word);
+        audible_input |= voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos);
       }
     }
     PG_STAMP(L.diag, 1);

@@ -404,6 +404,7 @@ static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_sam
   for (pg_graph* g : s->shards) {
     if (g->failed) { s->failed = true; return 0; }
     graph_begin_write(g, pos);
+    g->call_end = pos + n_samples / 2;   // (one write of the one mixer, whatever segments it is cut into)
     empty &= graph_is_empty(g);
   }
   if (empty) return 0;

@@ -620,7 +620,7 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
       v->fader_state = 1; v->fader_current = from; v->fader_target = 0.0f;
       const float LN100 = 4.605f;
       float samples_duration = (float)v->out_rate * v->fade_out_seconds / LN100;
-      v->fader_inertia = 1.0f - expf(-1.0f / samples_duration);
+      v->fader_inertia = 1.0f - pg_expf_glibc(-1.0f / samples_duration);
     } else {
       v->finished = 1;
     }
@@ -858,7 +858,11 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
       }
       // resampler.process(input_buffer.get(), output_buffer.get_mut()): channels are independent recurrences, one lane each;
       // (consumed, written) of the LAST channel count (cubic.rs:179-186)
+#ifdef PG_NO_OUTER_PARALLEL   // (diagnostic builds: the one-lane-per-channel walk only)
+      if (tid < C) {
+#else
       if (!outer_cubic_parallel(v, C, v->stage_in + v->in_start, (int)(v->in_end - v->in_start), v->stage_out, cap, S) && tid < C) {
+#endif
         int consumed, produced;
         outer_cubic_channel(v, tid, C, v->stage_in + v->in_start, (int)(v->in_end - v->in_start), v->stage_out, cap, &consumed, &produced);
         if (tid == C - 1) { S.ctl[0] = consumed; S.ctl[1] = produced; }
@@ -893,10 +897,20 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
   int wf;
-  if (ADAPTERS == 2 && v->outer_on) {
-    wf = resampled_source_write<GLIDE>(v, out, frames, pending_stop, S);
-  } else if (ADAPTERS >= 1 && v->stream_on) {  // a host-fed ring
-    wf = stream_source_write(v, out, frames, pending_stop);
+  if (ADAPTERS >= 1 && (v->stream_on || (ADAPTERS == 2 && v->outer_on))) {
+    // ChannelMappedSource::write (mapped.rs:61-99) asks its source again, inside the same call, for what a short write left open, until
+    // the block is full or a write returns nothing; only then does the mixer look at is_exhausted. A ResampledSource that broke off because
+    // its source is finished and its resampler had no output for the last input frames starts over on the second request — it refills its
+    // input range (stale) and plays on. With equal channel counts the mapper passes the one call through (:62-64).
+    const bool outer = ADAPTERS == 2 && v->outer_on;
+    wf = 0;
+    int stop = pending_stop;  // (the Stop message is queued once, in front of the call)
+    for (;;) {
+      const int r = outer ? resampled_source_write<GLIDE>(v, out + wf * C, frames - wf, stop, S) : stream_source_write(v, out + wf * C, frames - wf, stop);
+      stop = 0;
+      wf += r;
+      if (C == 2 || r == 0 || wf >= frames) break;
+    }
   } else {
     int post_on;
     wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on);
@@ -947,7 +961,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 // into `sig`. Returns true when the source produced output.
 template <bool GLIDE, int ADAPTERS = 2>
 DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
-                        const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0) {
+                        const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0, uint64_t call_end = 0) {
   SrcScratch S = S0;
   const int tid = pg_tid(), nt = blockDim.x;
   static_assert(sizeof(PgVoice) / 4 <= 256, "one dword per lane");
@@ -961,7 +975,8 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
   __syncthreads();
   S.sched_rd = (sched && lv->sched_class >= 0) ? sched + (size_t)lv->sched_class * 2 + sched_bank : nullptr;
   PG_STAMP(S.diag, 16);
-  if (!lv->active) return false;
+  // (an exhausted ResampledSource-backed voice is still asked for the rest of the write in which it ran out: PgVoice::zombie_end)
+  if (!lv->active && !(ADAPTERS == 2 && pos < lv->zombie_end)) return false;
   const int out_len = frames * 2;
   int total_written = 0;
   if (lv->start_time > pos) {
@@ -996,7 +1011,7 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     // is_transient && is_exhausted (ResampledSource: the source is exhausted AND both staging buffers are empty, resampled.rs:162-164)
     const bool exhausted = lv->outer_on ? (lv->finished && lv->in_start >= lv->in_end && lv->out_start >= lv->out_end) : lv->finished != 0;
     if (exhausted) {
-      if (tid == 0) lv->active = 0;
+      if (tid == 0) { if (ADAPTERS == 2 && lv->active && lv->outer_on) lv->zombie_end = call_end; lv->active = 0; }
       break;
     } else if (written == 0) break;
   }

@@ -335,10 +335,11 @@ def test_random_nested_graph_matches_oracle(seed):
 
 
 def make_voice_plan(seed):
-    """Random file sources on the main mixer and on one plain sub-mixer: rates on both sides of the mixer's (resampler ratios from 0.17 to 2),
+    """Random file sources on the main mixer and on one plain sub-mixer: rates on both sides of the mixer's (resampler ratios from 0.17 to 7; some behind a ResampledSource at a third rate),
     mono / stereo, one-shots, finite and endless repeats, loop ranges, start times inside blocks, fade-out lengths, and a schedule of stop /
     volume / panning / speed (immediate and glide) / seek calls at sample times."""
     rng = np.random.default_rng(21000 + seed)
+    rng2 = np.random.default_rng(22000 + seed)
     voices = []
     for _ in range(int(rng.integers(1, 6))):
         rate = int(rng.choice([8000, 11025, 22050, 32000, 44100, 48000, 64000, 96000]))
@@ -357,6 +358,12 @@ def make_voice_plan(seed):
             opt.update(has_repeat=1, repeat=(2 if rng.random() < 0.5 else _capi.PG_REPEAT_FOREVER), has_loop_range=1, loop_start=a, loop_end=int(rng.integers(a + 16, frames + 1)))
         if rng.random() < 0.3:
             opt["speed"] = float(rng.choice([0.5, 0.75, 1.25, 1.5, 2.0]))
+        # (a generator of its own: the draws above stay what they were for every seed) a ResampledSource behind the file source, speeds up to
+        # two octaves above the file's pitch (the resampler schedule's [2, 4) range)
+        if rng2.random() < 0.25:
+            opt["source_rate"] = int(rng2.choice([22050, 32000, 44100, 96000]))
+        if rng2.random() < 0.15:
+            opt["speed"] = float(rng2.choice([2.5, 3.0, 3.5]))
         voices.append(dict(mixer=int(rng.integers(0, 2)), tone=(int(rng.integers(0, 60)), rate, seconds, nch), opt=opt))
     sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000, 1])) for _ in range(12)]
     total = sum(sizes)
@@ -404,7 +411,10 @@ def render_voice_plan(plan, g):
 
 # 9028: two panning events for one source come due in front of the same chunk — the reference's one-slot message queue keeps the last one only,
 # and the first one would have snapped the nearly settled smoother onto its target
-@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24))) + ([] if FUZZ_SEEDS else [9028]))
+# 743, 2600: a ResampledSource-backed mono voice that runs out exactly at an event inside the block (the mixer keeps calling an inactive source until
+# its write ends); 2452: the same inside a sub-mixer whose call ends at a main-mixer event; 2008, 1439: fade-outs at source rates other than 48 kHz
+# (expf of the fader's inertia, one ulp apart between two libms)
+@pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 2 or 24))) + ([] if FUZZ_SEEDS else [9028, 743, 2600, 2452, 2008, 1439]))
 def test_random_voice_features_match_oracle(seed):
     """PreloadedFileSource / FileSourceImpl / VolumeFader / ChannelMapped / Amplified / Panned through MixedSource's source loop, no effects:
     the arithmetic is f32 and identical on both sides (resampler schedule, Hermite taps, fades, smoothed gain and panning), only the order of

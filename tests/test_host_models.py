@@ -43,6 +43,15 @@ def test_device_log10f_restatement_equals_the_host_libm(tmp_path):
     assert "bad 0" in r.stdout
 
 
+def test_device_expf_restatement_equals_the_host_libm(tmp_path):
+    exe = tmp_path / "expf_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-ffp-contract=off", "-fno-builtin", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "phonic_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(HOST, "expf_check.hip"), "-o", str(exe)], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout
+
+
 def test_resampler_schedule_integer_model_equals_serial_recurrence():
     sys.path.insert(0, HOST)
     import resampler_schedule_model as m
