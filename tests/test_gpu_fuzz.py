@@ -42,6 +42,11 @@ def random_params(rng, kind, descs):
 _PLAN_CACHE = {}
 
 
+def outer_rate_of(tone):
+    """One voice in five sits behind a ResampledSource: a function of the tone index, so that every seed's other draws stay what they were."""
+    return {7: 32000, 3: 96000}.get(tone % 10, 0)
+
+
 def make_plan(seed):
     """The random graph of a seed — the first of its draws (salt 0, 1, ...) that is AUDIBLE in the oracle: a plan whose every path ends in a gate that
     never opens or a gain of -120 dB compares silence with silence (round 2 skipped such seeds; now every seed of the suite is a real comparison)."""
@@ -93,7 +98,8 @@ def render_plan(plan, g, split=0, events_at_call_start=False, mutations=True):
             fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
             fx_mixer[fx_ids[-1][0]] = m
         for (ti, rate, vol, pan) in voices:
-            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER,
+                                         source_rate=outer_rate_of(ti)))
     for (k, p, s) in plan["bus"]:
         fx_ids.append((g.add_effect(0, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
         fx_mixer[fx_ids[-1][0]] = 0
@@ -276,7 +282,8 @@ def render_nested_plan(plan, g, mutations=True, events=True):
             fx_ids.append((g.add_effect(m, k, params=p, reverb_seeds=workloads.reverb_seeds(s) if k == _capi.FX_REVERB else None), k))
             fx_mixer[fx_ids[-1][0]] = m
         for (ti, rate, vol, pan) in voices:
-            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER))
+            voice_ids.append(g.add_voice(m, workloads.tone_buffer(ti, rate, 0.12), 2, rate, volume=vol, panning=pan, has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER,
+                                         source_rate=outer_rate_of(ti)))
     chunks, pos = [], 0
     for b, n in enumerate(sizes):
         for (eb, frac, pick, val) in ev_plan:
@@ -579,7 +586,7 @@ def render_topology_plan(plan, g):
                 g.move_effect(e[0], e[2], _capi.MOVE_DIRECTION, a["off"])
             elif w == "add_voice" and len(voices) < 10:
                 m = mixers[pick % len(mixers)]
-                opt = dict(volume=a["vol"], panning=a["pan"], start_time=t)
+                opt = dict(volume=a["vol"], panning=a["pan"], start_time=t, source_rate=outer_rate_of(a["tone"]))
                 if a["loop"]:
                     opt.update(has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
                 v = g.add_voice(m, workloads.tone_buffer(a["tone"], a["rate"], 0.1), 2, a["rate"], **opt)
