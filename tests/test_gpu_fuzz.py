@@ -371,6 +371,8 @@ def make_voice_plan(seed):
             opt["source_rate"] = int(rng2.choice([22050, 32000, 44100, 96000]))
         if rng2.random() < 0.15:
             opt["speed"] = float(rng2.choice([2.5, 3.0, 3.5]))
+        if rng2.random() < 0.2:
+            opt["fade_in_seconds"] = float(rng2.choice([0.005, 0.02, 0.1]))
         voices.append(dict(mixer=int(rng.integers(0, 2)), tone=(int(rng.integers(0, 60)), rate, seconds, nch), opt=opt))
     sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000, 1])) for _ in range(12)]
     total = sum(sizes)
