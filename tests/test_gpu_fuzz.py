@@ -454,18 +454,23 @@ def test_random_standalone_effect_sequences(seed):
     params = random_params(rng, kind, descs) if rng.random() < 0.7 else None
     seeds = workloads.reverb_seeds(int(rng.integers(0, 1000))) if kind == _capi.FX_REVERB else None
     e_gpu, e_cpu = phonic_amd.Effect(kind, params, seeds), oracle.OracleEffect(kind, params, seeds)
+    # (a generator of its own: the other draws stay what they were) the kinds that take any channel count, at 1, 3, 4 or 6 channels half of the time
+    rng3 = np.random.default_rng(32000 + seed)
+    C = 2
+    if kind in (_capi.FX_FILTER, _capi.FX_EQ5, _capi.FX_GAIN, _capi.FX_DISTORTION) and rng3.random() < 0.5:
+        C = int(rng3.choice([1, 3, 4, 6]))
     for e in (e_gpu, e_cpu):
-        e.initialize(SR, 2, 1024)
+        e.initialize(SR, C, 1024)
     sizes = [int(rng.choice([1024, 1024, 512, 700, 64, 333, 1000, 1, 0])) for _ in range(14)]
-    x = workloads.test_signal(sum(sizes) + 1, seed=seed, kind=str(rng.choice(["noise", "burst"])))[: 2 * sum(sizes)].copy()
+    x = workloads.test_signal((C * sum(sizes) + 1) // 2 + 1, seed=seed, kind=str(rng.choice(["noise", "burst"])))[: C * sum(sizes)].copy()
     quiet = int(rng.integers(0, len(sizes)))
     a, b = x.copy(), x.copy()
     pos = 0
     log = []
     for i, n in enumerate(sizes):
         if i == quiet:
-            a[2 * pos:] *= 0.0
-            b[2 * pos:] *= 0.0
+            a[C * pos:] *= 0.0
+            b[C * pos:] *= 0.0
         for _ in range(int(rng.choice([0, 0, 1, 1, 2, 4]))):
             d = descs[int(rng.integers(0, len(descs)))]
             name = fourcc_str(d["fourcc"])
@@ -481,13 +486,13 @@ def test_random_standalone_effect_sequences(seed):
             log.append((i, "reset"))
             e_gpu.reset()
             e_cpu.reset()
-        e_gpu.process(a[2 * pos:2 * (pos + n)])
-        e_cpu.process(b[2 * pos:2 * (pos + n)])
+        e_gpu.process(a[C * pos:C * (pos + n)])
+        e_cpu.process(b[C * pos:C * (pos + n)])
         pos += n
     assert np.isfinite(a).all()
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
-    what = {"kind": _capi.FX_NAMES[kind], "params": params, "sizes": sizes, "quiet from call": quiet, "log": log}
+    what = {"kind": _capi.FX_NAMES[kind], "channels": C, "params": params, "sizes": sizes, "quiet from call": quiet, "log": log}
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (float(np.sqrt(np.mean(d * d))), float(np.abs(d).max()), what)
 
 
