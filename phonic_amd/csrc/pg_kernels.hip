@@ -342,6 +342,15 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   }
   const int u = tables ? si.x : (L.unit_order ? L.unit_order[slot] : L.unit_base + slot);
   PgUnit& unit = L.units[u];
+  // The host-written fields of the unit record, read ONCE (one dword per lane of wave 0's first lanes): every `unit.x` further down would be
+  // another dependent trip to L2 — the record is also written in this body, so the compiler reloads it behind every barrier — on a workgroup
+  // whose block is a latency chain. What decides in front of the first barrier comes out of the register by v_readlane; the rest of the body
+  // reads the copy in LDS (`ur`, visible behind that barrier): no register lives across the body for it.
+  uint32_t unit_w = 0;
+  if ((tid & 63) < (int)(sizeof(PgUnit) / 4)) unit_w = ((const uint32_t*)&unit)[tid & 63];
+#define PG_UF(f) ((int)__builtin_amdgcn_readlane((int)unit_w, (int)(offsetof(PgUnit, f) / 4)))
+#define PG_UL(f) (ur[offsetof(PgUnit, f) / 4])
+  const int u_static_defer = PG_UF(static_defer), u_maybe_ramping = PG_UF(maybe_ramping), u_fx0 = PG_UF(fx0), u_staged = PG_UF(staged), u_n_fx0 = PG_UF(n_fx), u_kind0 = PG_UF(kind);
   uint32_t voice_word = 0;
   unsigned long long fx0_word = 0, fx1_word = 0;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
@@ -364,6 +373,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
   int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
+  int* ur = (int*)scratch;                         scratch += 96;   // copy of the unit record (sizeof(PgUnit) <= 96)
+  if (tid < (int)(sizeof(PgUnit) / 4)) ur[tid] = (int)unit_w;     // (read behind the barrier of the deferral decision / the block's first barrier)
   SrcScratch S;
   src_carve(scratch, S);
   S.diag = L.diag;
@@ -375,11 +386,11 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
   if (FAST_ONLY) {
-    if (unit.staged && unit.staged <= L.staged_on) return;  // rendered by the stage kernels of this round
+    if (u_staged && u_staged <= L.staged_on) return;  // rendered by the stage kernels of this round
     if (tid == 0) {
       // Ramps only start with a parameter command, and commands are always rendered (and the ramp state re-evaluated at the
       // end of the block) by the generic kernel: the unit record alone decides, no walk over the effect states.
-      int ok = !(unit.static_defer || unit.maybe_ramping);
+      int ok = !(u_static_defer || u_maybe_ramping);
       for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
       unit.deferred = ok ? 0 : 1;
       if (!ok && L.n_chunks > 1) pg_raise_super_deferred(L);  // nobody renders the later blocks of this unit
@@ -396,10 +407,10 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   // The first effects' state blocks (one qword per lane, ~1 KB each) are in flight since the head of the kernel (or requested here when the
   // launch carries no slot tables): the HBM round trips complete under the source stage; the words wait in registers until the chain stages
   // them in LDS.
-  if (FAST_ONLY && !tables && unit.n_fx > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[unit.fx0])[tid];
-  bool fx0_fresh = FAST_ONLY && unit.n_fx > 0;  // the generic kernel applies commands to the global copy first
-  bool fx1_fresh = tables && sf.y >= 0 && unit.n_fx > 1;
-  const bool external = unit.kind == UNIT_BUS || unit.kind == UNIT_EFFECT;
+  if (FAST_ONLY && !tables && u_n_fx0 > 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[u_fx0])[tid];
+  // (the fast kernels run ONE segment per block: the first two effects' states arrive in fx0_word / fx1_word; the generic kernel applies commands
+  // to the global copy first and stages from there)
+  const bool external = u_kind0 == UNIT_BUS || u_kind0 == UNIT_EFFECT;
   float* ext = L.bus + (size_t)slot * L.bus_unit_stride + (size_t)chunk * 2 * (size_t)N;  // (a bus launch behind a super-block: block c of the summed bus)
   if (external) {
     for (int i = tid; i < 2 * N; i += nt) sig[i] = ext[i];
@@ -423,7 +434,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     while (!FAST_ONLY && ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {  // (the fast kernel defers units with commands)
       const PgCmd cmd = L.cmds[ci];
       if (cmd.type == CMD_CALL_SPLIT) {
-        if (frame0 > call_start && unit.kind == UNIT_SUBMIXER && call_idx < PG_MAX_CALLS - 1) {
+        if (frame0 > call_start && PG_UL(kind) == UNIT_SUBMIXER && call_idx < PG_MAX_CALLS - 1) {
           __syncthreads();
           if (submixer_finish_call(unit, sig, out, call_start, frame0, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
           ++call_idx;
@@ -456,14 +467,14 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     const uint64_t pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)frame0;
     bool audible_input;
     if (external) {
-      audible_input = (unit.kind == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[chunk] != 0) : true);
+      audible_input = (PG_UL(kind) == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[chunk] != 0) : true);
     } else {
       audible_input = false;
       // (not in the four-per-CU kernel, whose registers are spoken for: the host sends graphs with nested mixers to the wide kernel instead)
-      if (!(FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) && unit.n_children > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
+      if (!(FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) && PG_UL(n_children) > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
         const int k = seg_idx < PG_MAX_CALLS - 1 ? seg_idx : PG_MAX_CALLS - 1;
-        for (int c = 0; c < unit.n_children; ++c) {
-          const int2 cr = L.child_rows[unit.child_off + c];
+        for (int c = 0; c < PG_UL(n_children); ++c) {
+          const int2 cr = L.child_rows[PG_UL(child_off) + c];
           const float* row = L.rows_base + (size_t)cr.x * L.out_stride + 2 * frame0;
           for (int i = tid; i < 2 * seg; i += nt) sseg[i] += row[i];
           const PgUnit& cu = L.units[cr.y];
@@ -474,29 +485,29 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       // where the MixedSource::write call that this segment belongs to ends (PgVoice::zombie_end): the whole write for a source of the main
       // mixer; for a sub-mixer the parent's current chunk — up to its next call boundary (CMD_CALL_SPLIT) or the end of the block
       uint64_t call_end_pos = L.call_end;
-      if (unit.kind != UNIT_SOURCE) {
+      if (PG_UL(kind) != UNIT_SOURCE) {
         int split = N;
         if (!FAST_ONLY) for (int cj = ci; cj < L.n_cmds && L.cmds[cj].unit == u; ++cj) if (L.cmds[cj].type == CMD_CALL_SPLIT && (int)L.cmds[cj].frame > frame0) { split = (int)L.cmds[cj].frame; break; }
         call_end_pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)split;
       }
-      for (int vi = 0; vi < unit.n_voices; ++vi) {
-        PgVoice* gv = &L.voices[vi == 0 ? unit.voice0 : L.voice_index[unit.voice_off + vi]];
+      for (int vi = 0; vi < PG_UL(n_voices); ++vi) {
+        PgVoice* gv = &L.voices[vi == 0 ? PG_UL(voice0) : L.voice_index[PG_UL(voice_off) + vi]];
         audible_input |= voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos);
       }
     }
     PG_STAMP(L.diag, 1);
     // process_effects (mixed.rs:627-655)
-    if (unit.n_fx > 0) {
+    if (PG_UL(n_fx) > 0) {
       bool input_bypassed = !audible_input;
-      if (!(unit.effects_bypassed && input_bypassed)) {
+      if (!(PG_UL(effects_bypassed) && input_bypassed)) {
         bool all_bypassed = true;
-        for (int fi = 0; fi < unit.n_fx; ++fi) {
+        for (int fi = 0; fi < PG_UL(n_fx); ++fi) {
           // stage the effect's state block in LDS: the per-block bookkeeping of lane 0 (smoother checks, coefficient and
           // delay-length updates, ring positions) then costs LDS instead of HBM round trips; written back afterwards
-          PgFx& gfx = L.fx[L.fx_index[unit.fx_off + fi]];
+          PgFx& gfx = L.fx[L.fx_index[PG_UL(fx_off) + fi]];
           __syncthreads();
-          if (fi == 0 && fx0_fresh) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; fx0_fresh = false; }
-          else if (fi == 1 && fx1_fresh) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx1_word; fx1_fresh = false; }
+          if (fi == 0 && FAST_ONLY) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; }
+          else if (fi == 1 && tables && sf.y >= 0) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx1_word; }
           else for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
           __syncthreads();
           PgFx& fx = *lfx;
@@ -509,7 +520,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
         }
         __syncthreads();
-        if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
+        if (tid == 0) { unit.effects_bypassed = all_bypassed ? 1 : 0; PG_UL(effects_bypassed) = all_bypassed ? 1 : 0; }   // (the segment loop ends in a barrier)
       }
     }
     any_audible |= audible_input;
@@ -520,9 +531,9 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 
   if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
     int ramping = 0;
-    for (int fi = 0; fi < unit.n_fx; ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[unit.fx_off + fi]], unit.staged != 0 || L.wide == 0) ? 0 : 1;  // (staged and lean kernels carry no ramp paths)
-    for (int vi = 0; vi < unit.n_voices; ++vi) {  // a pitch glide in progress is rendered here as well
-      const PgVoice& vv = L.voices[L.voice_index[unit.voice_off + vi]];
+    for (int fi = 0; fi < PG_UL(n_fx); ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[PG_UL(fx_off) + fi]], PG_UL(staged) != 0 || L.wide == 0) ? 0 : 1;  // (staged and lean kernels carry no ramp paths)
+    for (int vi = 0; vi < PG_UL(n_voices); ++vi) {  // a pitch glide in progress is rendered here as well
+      const PgVoice& vv = L.voices[L.voice_index[PG_UL(voice_off) + vi]];
       ramping |= (vv.current_speed != vv.target_speed) ? 1 : 0;
     }
     unit.maybe_ramping = ramping;
@@ -533,7 +544,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     for (int i = tid; i < 2 * N; i += nt) ext[i] = sig[i];
     return;
   }
-  if (unit.kind == UNIT_SUBMIXER) {
+  if (PG_UL(kind) == UNIT_SUBMIXER) {
     if (submixer_finish_call(unit, sig, out, call_start, N, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
     if (tid == 0) {
       unit.audible = (int)(call_mask & 1ull);  // the first call; later calls of the round (nested sub-mixers only) in call_audible
@@ -548,10 +559,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   // schedule cache: representatives replay the next block's resampler schedule (piece = this launch's length, capped)
   if (L.sched && tid == 0) {
     const int piece = N < SRC_OUT_CAP ? N : SRC_OUT_CAP;
-    for (int vi = 0; vi < unit.n_voices; ++vi) sched_publish(&L.voices[L.voice_index[unit.voice_off + vi]], L.sched, L.sched_bank, piece);
+    for (int vi = 0; vi < PG_UL(n_voices); ++vi) sched_publish(&L.voices[L.voice_index[PG_UL(voice_off) + vi]], L.sched, L.sched_bank, piece);  // (single-block rounds only; read here, not kept in registers across the body)
   }
 }
 
+#undef PG_UF
+#undef PG_UL
 #ifndef PG_FAST_WAVES
 #define PG_FAST_WAVES 2
 #endif
@@ -1129,7 +1142,8 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
 }
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes) {
   if (n_frames < PG_MIN_ROW_FRAMES) n_frames = PG_MIN_ROW_FRAMES;
-  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
+  static_assert(sizeof(PgUnit) <= 96, "pg_unit_body keeps a copy of the unit record in 96 bytes of LDS");
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64 + 96;
   size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
