@@ -82,6 +82,46 @@ def test_fed_voice_equals_the_preloaded_voice_bit_for_bit(channels, rate, feed):
         assert np.abs(outs[0][-2048:]).max() == 0.0
 
 
+@pytest.mark.parametrize("channels,rate", [(2, 44100), (1, 32000), (2, 48000), (1, 96000)])
+def test_fed_voice_against_the_oracle(channels, rate):
+    """The same comparison against the CPU oracle directly: a host-fed source holding a file's PCM must sound like the oracle's file source that
+    runs at its own rate (`source_rate` = the file's: no embedded resampling, ConvertedSource's ResampledSource and the channel mapper behind
+    it) — through the end of the data, where a ResampledSource keeps replaying its stale input range and the mixer keeps calling a source it
+    has marked inactive until its write ends. Ragged blocks, a volume event inside a block, two sources that end at
+    different times."""
+    import oracle
+
+    sizes = [1024, 333, 1, 700, 1024, 64, 1024, 511, 1024, 1024, 900, 1024]
+    bufs = [pcm_for(4, rate, 0.12, channels), pcm_for(17, rate, 0.07, channels)]
+
+    def render(g, fed):
+        m = g.add_mixer()
+        vs = []
+        for k, mixer in enumerate((m, 0)):
+            if fed:
+                v = g.add_stream_voice(mixer, channels, rate, 65536, volume=0.7, panning=0.2 - 0.5 * k)
+                g.feed_voice(v, bufs[k])
+                g.end_stream_voice(v)
+            else:
+                v = g.add_voice(mixer, bufs[k], channels, rate, volume=0.7, panning=0.2 - 0.5 * k, source_rate=rate, fade_out_seconds=-1.0)
+            vs.append(v)
+        chunks, pos = [], 0
+        for b, n in enumerate(sizes):
+            if b == 3:
+                g.set_voice_volume(vs[0], 0.3, pos + 100)
+            o = np.zeros(2 * n, np.float32)
+            g.write(o, pos)
+            chunks.append(o)
+            pos += n
+        return np.concatenate(chunks)
+
+    a = render(graph(), True)
+    b = render(oracle.OracleGraph(SR, 2, 1024), False)
+    d = a.astype(np.float64) - b
+    assert np.abs(b).max() > 1e-2
+    assert float(np.sqrt(np.mean(d * d))) <= 1e-6 and float(np.abs(d).max()) <= 1e-5, (float(np.abs(d).max()), int(np.flatnonzero(np.abs(d) > 1e-6)[:1][0]) // 2 if np.any(np.abs(d) > 1e-6) else None)
+
+
 def test_stream_voice_underrun_ring_full_stop_and_end():
     """A short ring read is a source that delivered less: the rest of the block is silent and the voice carries on with the next feed; the ring
     refuses a feed it has no room for (PG_ERR_QUEUE_FULL, nothing taken) until the device's progress has been collected; stop_voice ends the
