@@ -207,11 +207,7 @@ DEVO bool chorus_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       done += T;
     }
   }
-  if (tid == 0) {  // block-end phase bookkeeping (chorus.rs:388-393)
-    const double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;
-    c.current_phase += (double)n_samples / 2.0 * phase_inc;
-    while (c.current_phase >= 2.0 * F64_PI) c.current_phase -= 2.0 * F64_PI;
-  }
+  // (the call-end phase bookkeeping of chorus.rs:388-393 runs in the caller, once per process call: chorus_call_end)
   __syncthreads();
   return true;
 }
@@ -338,11 +334,7 @@ DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     }
     p0 += P;
   }
-  if (tid == 0) {  // block-end phase bookkeeping (chorus.rs:388-393)
-    const double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;
-    c.current_phase += (double)n_samples / 2.0 * phase_inc;
-    while (c.current_phase >= 2.0 * F64_PI) c.current_phase -= 2.0 * F64_PI;
-  }
+  // (the call-end phase bookkeeping of chorus.rs:388-393 runs in the caller, once per process call: chorus_call_end)
   __syncthreads();
   return true;
 }

@@ -7,6 +7,11 @@
 
 #define PG_USIZE_MAX 0xFFFFFFFFFFFFFFFFull
 #define PG_MAX_FRAMES 4096  // MixedSource::MAX_MIX_BUFFER_SAMPLES / 2 (src/source/mixed.rs:216)
+// Semantic chunks and kernel pieces. MixedSource::write walks a call in chunks of min(remaining, PG_MAX_FRAMES) frames from the call's
+// start and from every event (mixed.rs:679-712); sources, effect processors and sub-mixers are called once per chunk and take their
+// per-call decisions (bypass, tails, silence gates, block-end bookkeeping) there. The kernels render a chunk as PIECES of at most the
+// graph's max_frames frames (LDS-resident, <= 1024 for the staged kernels): per-chunk decisions are taken at a chunk's first piece, kept in
+// the unit / effect / voice records and closed at its last piece, so the chunk grid is the reference's whatever max_frames is.
 
 enum PgSmoothKind { SM_EXP = 0, SM_LIN = 1, SM_SPRING = 2 };
 
@@ -140,6 +145,10 @@ struct PgFx {
   int32_t bypassed;
   int32_t standalone;  // 1: plain Effect::process without the processor's bypass logic
   uint64_t tail_counter, silence_counter;
+  // the process call (semantic chunk) in progress, across its pieces: frames the effect has rendered so far and — while the processor
+  // watches for silence (unknown tail, effect.rs:128-144) — the peak of what it put out
+  uint32_t call_frames;
+  float call_max;
   union {
     PgGain gain; PgPan pan; PgFilter filter; PgEq5 eq5; PgDelay delay; PgReverb reverb; PgChorus chorus; PgComp comp; PgGate gate; PgDist dist;
   } u;
@@ -195,6 +204,9 @@ struct PgVoice {
   // when the write ends (mixed.rs:612-616, 715). Only a ResampledSource makes that audible (asked again, it refills its stale input range and
   // plays on): the end position of the write in which such a voice was marked.
   uint64_t zombie_end;
+  // process_sources leaves a source alone for the rest of a chunk once a write returned nothing (`written == 0` -> break 'source,
+  // mixed.rs:617-620): set when that happens in a piece, cleared at the first piece of the mixer's next chunk
+  int32_t chunk_skip, pad_skip;
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.
@@ -243,11 +255,19 @@ struct PgUnit {
   int32_t staged;               // host: the chain is [Gain|Panning]* -> Reverb: eligible for the staged pipeline (pg_stage*_kernel)
   int32_t stage_flags;          // device: hand-over between the stage kernels of one block (PG_STAGE_*)
   int32_t child_off, n_children;  // host: nested sub-mixers of this mixer, entries of PgLaunch::child_rows (summed before the sources)
-  int32_t pad4;
-  uint64_t call_audible;        // device: bit k = result of SubMixerProcessor::process for the k-th call of this round (a parent with
-                                // events mid-block calls its sub-mixers once per segment, mixed.rs:679-712)
+  int32_t seg_idx;              // device: semantic chunks this mixer has begun in the main mixer's current chunk, minus one (indexes its sub-mixers' call_audible)
+  uint64_t call_audible;        // device: bit k = result of SubMixerProcessor::process for the k-th call of the main mixer's current chunk (a parent
+                                // with events inside it calls its sub-mixers once per segment, mixed.rs:679-712)
+  // device: the chunk (this mixer's own MixedSource::write chunk) and the call (SubMixerProcessor::process of its parent) in progress, across pieces
+  int32_t chunk_audible_input;  // audible_input of the chunk, decided at its first piece (process_effects and every processor of the chain use it)
+  int32_t chunk_any_audible;    // main-mixer sources: OR of `produced_output` over the pieces so far
+  float call_max;               // peak of the call's output so far (submixer.rs:57: max_abs over the whole call)
+  uint32_t call_frames;         // frames of the call rendered in earlier pieces
+  int32_t call_idx;             // calls finished in the main mixer's current chunk
+  int32_t pad_call;
 };
-enum { PG_STAGE_ACTIVE = 1, PG_STAGE_INPUT_BYPASSED = 2, PG_STAGE_ALL_BYPASSED = 4, PG_STAGE_AUDIBLE = 8, PG_STAGE_SKIPPED = 16 };
+enum { PG_STAGE_ACTIVE = 1, PG_STAGE_INPUT_BYPASSED = 2, PG_STAGE_ALL_BYPASSED = 4, PG_STAGE_AUDIBLE = 8, PG_STAGE_SKIPPED = 16,
+       PG_STAGE_FIRST = 32, PG_STAGE_LAST = 64 };  // the block is the first / last piece of its chunk
 
 enum PgCmdType {
   CMD_FX_PARAM = 0,     // target = fx index, param = parameter index, value = raw (already denormalized/clamped) value
@@ -260,6 +280,11 @@ enum PgCmdType {
   CMD_CALL_SPLIT = 7,   // nested sub-mixers: an ancestor splits its block at `frame` -> this unit's write() call ends there and a new one begins
   CMD_NOP = 8,          // an event whose effect was removed before it came due: nothing to apply, but the mixer's block still ends a segment at its
                         // time (the reference pops the event, logs "not found" and carries on, mixed.rs:862-924 — per-call logic counts calls)
+  // Markers (frame = the launch's frame count: never applied, never a split): where the unit's current chunk / call ends when that is NOT the
+  // end of the main mixer's chunk — the unit (CHUNK_END) or one of its ancestors (CALL_END) has its next event at position value64, inside the
+  // main chunk but beyond this piece. The kernels close per-chunk / per-call state at a piece's end when the marker's position is that end.
+  CMD_CHUNK_END = 9,
+  CMD_CALL_END = 10,
 };
 #define PG_MAX_CALLS 64  // calls of one sub-mixer per launch round (bits of PgUnit::call_audible); the host bounds the round accordingly
 struct PgCmd {
@@ -326,6 +351,16 @@ struct PgLaunch {
                           // request unit record, first voice and the first two effect states side by side instead of one after the other
   uint64_t bus_unit_stride;  // floats between the external buffers of consecutive units of the launch (a standalone effect with more than two
                              // channels runs one stereo unit per channel pair); 0 for the bus
+  // Chunk grid of the main mixer (see PG_MAX_FRAMES): block 0 of the launch starts grid_off frames behind a chunk start, chunks of
+  // PG_MAX_FRAMES follow each other from there until grid_span frames behind that chunk start (the end of the write call or the next
+  // main-mixer event). grid_span == 0: every block is a chunk of its own (standalone effects, launches of one whole chunk).
+  uint32_t grid_off, grid_span;
+};
+// Where block c of a launch sits in the main mixer's chunk grid.
+struct PgPiece {
+  bool first, last;       // first / last piece of its chunk
+  int c_last;             // block (relative to the launch's block 0) that holds the chunk's last frame
+  uint64_t chunk_end;     // position (frames) at which the chunk ends
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
 enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take

@@ -394,8 +394,15 @@ DEVN void chorus_serial(PgFx& fx, float* sig, int n) {
     sig[f] = left_input * dry_amount + left_output * wet_amount;
     sig[f + 1] = right_input * dry_amount + right_output * wet_amount;
   }
-  double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;  // :388-393
-  c.current_phase += (double)n / 2.0 * phase_inc;
+}
+// "Move our LFO offset to keep our oscillators updated when changing the rate or phase" (chorus.rs:388-393): once per process call, behind its
+// last frame, with the call's whole length and the rate the call ended on. The callers run it when a call's last piece has been rendered
+// (fx_process_wg): update_lfos re-seats the oscillators on current_phase every frame while rate or phase ramp, so the value must not move
+// between the pieces of a call.
+DEV void chorus_call_end(PgFx& fx, uint64_t call_frames) {
+  PgChorus& c = fx.u.chorus;
+  double phase_inc = 2.0 * F64_PI * (double)c.rate.current / (double)fx.sample_rate;
+  c.current_phase += (double)(call_frames * 2ull) / 2.0 * phase_inc;
   while (c.current_phase >= 2.0 * F64_PI) c.current_phase -= 2.0 * F64_PI;
 }
 

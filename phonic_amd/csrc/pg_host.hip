@@ -191,13 +191,16 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
   int n = (int)topo.size();
   hipLaunchKernelGGL(pg_patch_units_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, g->d_units.d, g->d_topo.d, n);
   HIP_TRY(hipGetLastError());
-  if ((size_t)std::max(g->n_graph_units, 1) > g->unit_out_rows || g->max_blocks != g->unit_out_blocks)
+  if ((size_t)std::max(g->n_graph_units, 1) > g->unit_out_rows || g->unit_out_blocks < std::max<size_t>(g->max_blocks, (PG_MAX_FRAMES + g->max_frames - 1) / g->max_frames))
     return set_error(PG_ERR_STATE, "per-unit buffers were not reserved by the mutating call");
   g->topo_dirty = false;
   g->last_change_round = g->launch_counter;  // the patch kernel marked every unit: the generic kernel must look at them again
   return PG_OK;
 }
 
+// Per-unit output tables the write path needs: one per block of a super-block launch, and one per piece of a chunk (the mixer sum runs
+// behind a chunk's last piece).
+static size_t graph_table_blocks(const pg_graph* g) { return std::max<size_t>(g->max_blocks, (PG_MAX_FRAMES + g->max_frames - 1) / g->max_frames); }
 // Device capacity for the graph as the host mirror describes it now. Called at the end of every mutating call (after graph_quiesce):
 // this is where the library allocates — grow-by-doubling — so that rebuild_topology and everything else inside write never does.
 static int graph_reserve(pg_graph* g) {
@@ -212,17 +215,18 @@ static int graph_reserve(pg_graph* g) {
   }
   // per-unit output rows (one table of rows per block of a super-block launch), deferral list, stage hand-over, mixer partials
   const size_t rows = std::max<size_t>(n_units, 1);
-  if (rows > g->unit_out_rows || g->max_blocks != g->unit_out_blocks) {
+  const size_t blocks = graph_table_blocks(g);
+  if (rows > g->unit_out_rows || blocks != g->unit_out_blocks) {
     if (g->d_unit_out) (void)pg_free(g->d_unit_out);
     g->d_unit_out = nullptr;
     size_t nr = rows > g->unit_out_rows ? std::max(rows, g->unit_out_rows * 2) : g->unit_out_rows;
-    HIP_TRY(pg_malloc((void**)&g->d_unit_out, (nr * g->stride * g->max_blocks + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
+    HIP_TRY(pg_malloc((void**)&g->d_unit_out, (nr * g->stride * blocks + 4) * sizeof(float)));  // +4: the mixer sum reads whole float4s (odd max_frames)
     if (g->d_audible_tab) (void)pg_free(g->d_audible_tab);
     g->d_audible_tab = nullptr;
-    HIP_TRY(pg_malloc((void**)&g->d_audible_tab, nr * g->max_blocks * sizeof(int32_t)));  // one `audible` word per unit row and block of a super-block
-    HIP_TRY(pg_memset(g->d_audible_tab, 0, nr * g->max_blocks * sizeof(int32_t)));
+    HIP_TRY(pg_malloc((void**)&g->d_audible_tab, nr * blocks * sizeof(int32_t)));  // one `audible` word per unit row and block
+    HIP_TRY(pg_memset(g->d_audible_tab, 0, nr * blocks * sizeof(int32_t)));
     g->unit_out_rows = nr;
-    g->unit_out_blocks = g->max_blocks;
+    g->unit_out_blocks = blocks;
   }
   if (rows > g->defer_rows) {
     if (g->d_defer) (void)pg_free(g->d_defer);
@@ -276,12 +280,16 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   g->device = device; g->sample_rate = sample_rate; g->channels = 2; g->max_frames = max_frames;
   g->stride = (uint32_t)(2 * max_frames);
   if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
-  if (pg_malloc((void**)&g->d_bus, (g->stride + 4) * sizeof(float)) != hipSuccess || pg_malloc((void**)&g->d_audible, PG_AUDIBLE_SLOTS * sizeof(int)) != hipSuccess ||
-      pg_host_malloc((void**)&g->h_pinned, (g->stride + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+  // staging of pg_graph_write (host buffers): whole chunks, so at least one of PG_MAX_FRAMES frames; one `audible` word per piece of a chunk
+  // (and per block of a super-block launch)
+  g->bus_frames = std::max<size_t>(max_frames, PG_MAX_FRAMES);
+  g->audible_slots = std::max<size_t>(PG_AUDIBLE_SLOTS, (PG_MAX_FRAMES + max_frames - 1) / max_frames);
+  if (pg_malloc((void**)&g->d_bus, (2 * g->bus_frames + 4) * sizeof(float)) != hipSuccess || pg_malloc((void**)&g->d_audible, g->audible_slots * sizeof(int)) != hipSuccess ||
+      pg_host_malloc((void**)&g->h_pinned, (2 * g->bus_frames + 4) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
     return nullptr;
   }
-  (void)pg_memset(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int));
+  (void)pg_memset(g->d_audible, 0, g->audible_slots * sizeof(int));
   if (pg_malloc((void**)&g->d_bus_progress, PG_BUS_PIPELINE_MAX * 8) == hipSuccess) (void)pg_memset(g->d_bus_progress, 0xff, PG_BUS_PIPELINE_MAX * 8); else g->d_bus_progress = nullptr;
   if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
@@ -810,11 +818,13 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
   { int rc = graph_quiesce(g); if (rc) return rc; }
   // staging of pg_graph_write (host buffers): one super-block + the status words
   float* nb = nullptr; float* np = nullptr;
-  const size_t words = (size_t)g->stride * (size_t)n_blocks + 4;
+  const size_t frames = std::max<size_t>(g->max_frames * (size_t)n_blocks, PG_MAX_FRAMES);
+  const size_t words = 2 * frames + 4;
   HIP_TRY(pg_malloc((void**)&nb, words * sizeof(float)));
   if (pg_host_malloc((void**)&np, words * sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)pg_free(nb); return set_error(PG_ERR_DEVICE, "pinned allocation failed"); }
   (void)pg_free(g->d_bus); (void)pg_host_free(g->h_pinned);
   g->d_bus = nb; g->h_pinned = np;
+  g->bus_frames = frames;
   g->max_blocks = (size_t)n_blocks;
   g->topo_dirty = true;
   return graph_reserve(g);  // the per-unit output table grows here, never inside write
@@ -970,104 +980,97 @@ static void bus_pipeline_setup(pg_graph* g, PgLaunch& B) {
   }
 }
 
-// One launch round: all graph units for frames [t0, t0 + n_chunks * n) -> per-unit rows -> tree sum -> (bus chain) -> d_dst.
-// n_chunks > 1 (super-block): n == max_frames, no commands, graph_super_ok(). The `audible` word of block c of the round goes to
-// d_audible[audible_slot + c] (the bus chain's audible_input; in defer_bus mode the caller reads the words of a whole write call).
-static int launch_round(pg_graph* g, float* d_dst, uint32_t n, uint64_t t0, hipStream_t stream, bool run_bus, const std::vector<PgCmd>& cmds, int n_chunks = 1,
-                        int audible_slot = 0) {
-  if (g_fail_round_countdown.load(std::memory_order_relaxed) > 0 && g_fail_round_countdown.fetch_sub(1) == 1)
-    return set_error(PG_ERR_DEVICE, "injected device failure (pg_debug_fail_launch_round)");
+#define HIP_TRY_FAIL(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error(PG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)); g->failed = true; return 0; } } while (0)
+// The unit kernels of ONE level of the mixer tree for n_chunks blocks of n frames starting at t0: block c goes to the per-unit output table
+// `row_block + c` (a chunk's pieces sit in consecutive tables; the mixer sum and the bus chain run behind a chunk's last piece). `round`: the
+// launch round the blocks belong to (deferral feedback, schedule-cache bank); grid_off / grid_span: PgLaunch (pg_dev.h).
+struct LaunchSpan {
+  uint32_t n = 0;            // frames per block
+  uint64_t t0 = 0;           // position of block 0
+  int n_chunks = 1;
+  int row_block = 0;
+  uint32_t grid_off = 0, grid_span = 0;
   const PgCmd* d_cmds = nullptr;
-  if (!cmds.empty()) { int rc = stage_commands(g, cmds, stream, &d_cmds); if (rc) return rc; }
-  PgLaunch L;
+  int n_cmds = 0;
+  uint64_t round = 0;
+  bool timed = false;        // a hipEvent pair is reserved for this span (g->ev_used names it)
+  bool generic_idle = false;
+};
+static void fill_launch(pg_graph* g, const LaunchSpan& sp, PgLaunch& L) {
   memset(&L, 0, sizeof L);
   L.units = g->d_units.d; L.voices = g->d_voices.d; L.fx = g->d_fx.d;
   L.voice_index = g->d_voice_index.d; L.fx_index = g->d_fx_index.d;
-  L.cmds = d_cmds; L.n_cmds = (int)cmds.size();
-  L.n_frames = n; L.pos = t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
+  L.cmds = sp.d_cmds; L.n_cmds = sp.n_cmds;
+  L.n_frames = sp.n; L.pos = sp.t0; L.sample_rate = g->sample_rate; L.fast = g->fast;
   L.out_stride = g->stride;
-  L.rows_base = g->d_unit_out; L.child_rows = g->d_child_rows.d;
+  L.chunk_stride = (uint64_t)g->unit_out_rows * g->stride;
+  L.rows_base = g->d_unit_out + (size_t)sp.row_block * (size_t)L.chunk_stride; L.child_rows = g->d_child_rows.d;
   L.call_end = g->call_end;
   L.diag = g->d_diag;
-  L.n_chunks = n_chunks; L.chunk_stride = (uint64_t)g->unit_out_rows * g->stride; L.error_word = g->d_error;
+  L.n_chunks = sp.n_chunks; L.error_word = g->d_error;
   L.fast_scratch_bytes = (uint32_t)pg_fast_scratch_bytes(g->fast_kind_mask);
-  const uint64_t round = g->launch_counter;
-  if (!cmds.empty()) g->last_change_round = round;
-  L.round = (uint32_t)round; L.host_feedback = g->d_feedback;
-  const bool nested = g->levels.size() > 1;
-  // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
-  // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.
-  // (Graphs with nested sub-mixers always launch it: the parents are rendered there.)
-  const bool generic_idle = !nested && cmds.empty() && graph_steady(g);
+  L.round = (uint32_t)sp.round; L.host_feedback = g->d_feedback;
+  L.grid_off = sp.grid_off; L.grid_span = sp.grid_span;
   // (a super-block runs without the resampler schedule cache: its banks alternate per launch, not per block; voices of a cached
   // class replay their schedule serially, and the cache re-validates itself by key when single-block rounds resume)
-  L.sched = n_chunks > 1 ? nullptr : g->d_sched.d; L.sched_bank = (int)(g->launch_counter & 1);
-  g->launch_counter++;
-  // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
-  // average can time every n-th round (pg_graph_set_timing_period)
-  const bool timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < g->ev_pool.size() && g->n_graph_units > 0;
-  size_t timed_level = 0;  // the level holding most units carries the timing events
-  for (size_t li = 1; li < g->levels.size(); ++li) if (g->levels[li].cnt > g->levels[timed_level].cnt) timed_level = li;
-  for (size_t li = 0; li < g->levels.size(); ++li) {
-    const Level& lv = g->levels[li];
-    if (lv.cnt == 0) continue;
-    // this level's slice of the per-slot tables: launch slot b of the level = row lv.off + b
-    L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
-    L.unit_out = g->d_unit_out + (size_t)lv.off * g->stride;
-    L.audible_tab = g->d_audible_tab + lv.off; L.audible_stride = g->unit_out_rows;
-    L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off;
-    if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
-    g->defer_phase++;
-    const bool timed_here = timed && li == timed_level;
-    // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
-    // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
-    // dispatch itself (hipExtLaunchKernel: no marker packets in the stream); several launches are bracketed by event records.
-    const bool time_generic = g->fast && lv.n_static_defer * 2 > lv.cnt;
-    hipEvent_t e0 = timed_here ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed_here ? g->ev_pool[g->ev_used].second : nullptr;
-    if (g->fast) {
-      // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
-      L.mode = 1; L.wide = g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || nested || g->any_outer) ? 1 : 2) : 0;  // (2: the four-per-CU kernel; it neither sums nested mixers nor stages a ResampledSource)
-      // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
-      const int n_lean = lv.n_staged - lv.n_staged_wide;
-      const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;
-      const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
-      const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && lv.n_staged_wide > 0;
-      const bool fused = !staged || n_handled < lv.cnt;
-      const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
-      const bool ride = timed_here && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
-      const bool bracket = timed_here && !time_generic && n_launches > 1;
-      if (bracket) HIP_TRY(hipEventRecord(e0, stream));
-      L.stage_buf = nullptr; L.staged_on = 0;
-      if (staged) {
-        L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 2 : 1;
-        HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
-      }
-      if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
-      if (bracket) HIP_TRY(hipEventRecord(e1, stream));
-      L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
-      if (!generic_idle) HIP_TRY(pg_launch_units(L, stream, timed_here && time_generic ? e0 : nullptr, timed_here && time_generic ? e1 : nullptr));
-    } else {
-      L.mode = 0;
-      if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
-      HIP_TRY(pg_launch_units(L, stream, e0, e1));
+  L.sched = sp.n_chunks > 1 ? nullptr : g->d_sched.d; L.sched_bank = (int)(sp.round & 1);
+}
+static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_t stream) {
+  const Level& lv = g->levels[li];
+  if (lv.cnt == 0) return PG_OK;
+  PgLaunch L;
+  fill_launch(g, sp, L);
+  const uint32_t n = sp.n;
+  const bool nested = g->levels.size() > 1;
+  // this level's slice of the per-slot tables: launch slot b of the level = row lv.off + b
+  L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
+  L.unit_out = g->d_unit_out + (size_t)sp.row_block * (size_t)L.chunk_stride + (size_t)lv.off * g->stride;
+  L.audible_tab = g->d_audible_tab + (size_t)sp.row_block * g->unit_out_rows + lv.off; L.audible_stride = g->unit_out_rows;
+  L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off;
+  if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
+  g->defer_phase++;
+  // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
+  // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
+  // dispatch itself (hipExtLaunchKernel: no marker packets in the stream); several launches are bracketed by event records.
+  const bool timed_here = sp.timed;
+  const bool time_generic = g->fast && lv.n_static_defer * 2 > lv.cnt;
+  hipEvent_t e0 = timed_here ? g->ev_pool[g->ev_used].first : nullptr, e1 = timed_here ? g->ev_pool[g->ev_used].second : nullptr;
+  if (g->fast) {
+    // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
+    L.mode = 1; L.wide = g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || nested || g->any_outer) ? 1 : 2) : 0;  // (2: the four-per-CU kernel; it neither sums nested mixers nor stages a ResampledSource)
+    // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
+    const int n_lean = lv.n_staged - lv.n_staged_wide;
+    const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;
+    const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
+    const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && lv.n_staged_wide > 0;
+    const bool fused = !staged || n_handled < lv.cnt;
+    const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
+    const bool ride = timed_here && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
+    const bool bracket = timed_here && !time_generic && n_launches > 1;
+    if (bracket) HIP_TRY(hipEventRecord(e0, stream));
+    L.stage_buf = nullptr; L.staged_on = 0;
+    if (staged) {
+      L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 2 : 1;
+      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
     }
+    if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
+    if (bracket) HIP_TRY(hipEventRecord(e1, stream));
+    L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
+    if (!sp.generic_idle) HIP_TRY(pg_launch_units(L, stream, timed_here && time_generic ? e0 : nullptr, timed_here && time_generic ? e1 : nullptr));
+  } else {
+    L.mode = 0;
+    if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
+    HIP_TRY(pg_launch_units(L, stream, e0, e1));
   }
-  if (timed) { g->ev_blocks[g->ev_used] = (uint32_t)n_chunks; g->ev_used++; }
-  L.mode = 0;
-  // the main mixer sums the rows of its own sub-mixers and sources: the last level
-  const Level& top = g->levels.back();
-  HIP_TRY(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_dst, n * 2, g->d_audible_tab + top.off, g->unit_out_rows, g->d_audible + audible_slot, stream,
-                        n_chunks, (size_t)L.chunk_stride));
-  if (run_bus && !g->mixers[0].fx.empty()) {
-    PgLaunch B = L;  // (n_chunks rides along: the generic kernel walks the summed blocks of a super-block in order)
-    B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
-    B.bus = d_dst; B.bus_audible = g->d_audible + audible_slot; B.audible_tab = nullptr;
-    bus_pipeline_setup(g, B);
-    HIP_TRY(pg_launch_units(B, stream));
-  }
+  if (timed_here) { g->ev_blocks[g->ev_used] = (uint32_t)sp.n_chunks; g->ev_used++; }
   return PG_OK;
 }
-
+// The level that holds most units carries the timing events of a round
+static size_t timed_level_of(const pg_graph* g) {
+  size_t t = 0;
+  for (size_t li = 1; li < g->levels.size(); ++li) if (g->levels[li].cnt > g->levels[t].cnt) t = li;
+  return t;
+}
 }  // extern "C"
 
 // MixedSource::write of the main mixer (src/source/mixed.rs:659-719)
@@ -1101,6 +1104,7 @@ static int flush_stream_feeds(pg_graph* g, hipStream_t stream) {
 void graph_begin_write(pg_graph* g, uint64_t pos) {
   drain_control_messages(g);  // process_messages (mixed.rs:294-499)
   apply_remove_pending(g, pos);
+  g->messages_due = true;     // StopSource messages travel with the call's first launch
 }
 // "Return early and avoid touching the buffer if there's nothing to do" (mixed.rs:664-670): no playing sources, no effects, no
 // sub-mixers, no events. (Sources of the main mixer that ended are dropped after the write they ended in, :715 — the host learns
@@ -1128,7 +1132,103 @@ void graph_collect_status(pg_graph* g) {
   g->main_active_voices = *(volatile int*)(g->h_feedback + 1);
 }
 
-size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin) {
+// The bus chain over blocks [row_block, +n_chunks) of a chunk (or of several whole chunks) whose sum sits in d_dst. Commands (main-mixer
+// effect events, due at the chunk's first frame) ride on a launch of the first block alone: a launch that walks several blocks applies nothing.
+static int launch_bus(pg_graph* g, float* d_dst, LaunchSpan sp, int audible_slot, hipStream_t stream) {
+  if (g->mixers[0].fx.empty()) return PG_OK;
+  auto one = [&](const LaunchSpan& q, float* dst, int slot) -> int {
+    PgLaunch B;
+    fill_launch(g, q, B);
+    B.mode = 0;
+    B.n_units = 1; B.unit_order = nullptr; B.unit_base = g->mixers[0].unit_slot;
+    B.bus = dst; B.bus_audible = g->d_audible + slot; B.audible_tab = nullptr;
+    B.sched = nullptr;
+    bus_pipeline_setup(g, B);
+    HIP_TRY(pg_launch_units(B, stream));
+    return PG_OK;
+  };
+  if (sp.n_cmds > 0 && sp.n_chunks > 1) {
+    LaunchSpan head = sp;
+    head.n_chunks = 1;
+    int rc = one(head, d_dst, audible_slot);
+    if (rc) return rc;
+    sp.d_cmds = nullptr; sp.n_cmds = 0;
+    sp.t0 += sp.n; sp.grid_off += sp.n; sp.n_chunks -= 1; sp.row_block += 1;
+    return one(sp, d_dst + (size_t)sp.n * 2, audible_slot + 1);
+  }
+  return one(sp, d_dst, audible_slot);
+}
+
+// Commands of the launch that renders frames [t0, t0 + n) of the chunk [chunk_t0, chunk_end): `head` (main-mixer events and messages due at
+// the chunk's first frame: first piece only), the sub-mixers' own events inside the piece (each sub-mixer splits its block there on the
+// device), call boundaries for the descendants of a mixer that splits (CMD_CALL_SPLIT), and the markers that tell a unit where its chunk /
+// its parent's call ends when that is inside the main chunk but beyond this piece (CMD_CHUNK_END / CMD_CALL_END).
+static void collect_piece_commands(pg_graph* g, std::vector<PgCmd>& cmds, uint64_t t0, uint64_t n, uint64_t chunk_t0, uint64_t chunk_end) {
+  const uint64_t t1 = t0 + n;
+  const bool first_piece = t0 == chunk_t0;
+  // Nested sub-mixers: a mixer that splits its chunk at an event calls its sub-mixers once per segment (mixed.rs:679-712), so
+  // every event of a mixer with sub-mixers is also a call boundary for all its descendants.
+  if (g->levels.size() > 1) {
+    for (size_t m = 1; m < g->mixers.size(); ++m) {
+      if (g->mixers[m].children.empty() || g->mixers[m].events.empty()) continue;
+      std::vector<int> desc(g->mixers[m].children);
+      for (size_t i = 0; i < desc.size(); ++i) for (int c : g->mixers[desc[i]].children) desc.push_back(c);
+      uint64_t next_after = UINT64_MAX;
+      for (const Event& e : g->mixers[m].events) {
+        if (e.sample_time >= t1) { next_after = e.sample_time; break; }
+        if (first_piece ? e.sample_time <= t0 : e.sample_time < t0) continue;  // (the chunk's first frame is a call start anyway)
+        for (int d : desc) {
+          PgCmd c;
+          memset(&c, 0, sizeof c);
+          c.type = CMD_CALL_SPLIT; c.unit = g->mixers[d].unit_slot; c.frame = (uint32_t)(e.sample_time - t0);
+          cmds.push_back(c);
+        }
+      }
+      if (next_after < chunk_end) for (int d : desc) {
+        PgCmd c;
+        memset(&c, 0, sizeof c);
+        c.type = CMD_CALL_END; c.unit = g->mixers[d].unit_slot; c.frame = (uint32_t)n; c.value64 = next_after;
+        cmds.push_back(c);
+      }
+    }
+  }
+  // sub-mixer events inside [t0, t1): each sub-mixer splits its own block on the device
+  for (size_t m = 1; m < g->mixers.size(); ++m) {
+    HostMixer& mx = g->mixers[m];
+    while (!mx.events.empty() && mx.events.front().sample_time < t1) {
+      PgCmd c = mx.events.front().cmd;
+      uint64_t t = mx.events.front().sample_time;
+      c.frame = t <= t0 ? 0u : (uint32_t)(t - t0);
+      c.unit = mx.unit_slot;
+      cmds.push_back(c);
+      mx.events.erase(mx.events.begin());
+    }
+    if (!mx.events.empty() && mx.events.front().sample_time < chunk_end && !mx.removed) {
+      PgCmd c;
+      memset(&c, 0, sizeof c);
+      c.type = CMD_CHUNK_END; c.unit = mx.unit_slot; c.frame = (uint32_t)n; c.value64 = mx.events.front().sample_time;
+      cmds.push_back(c);
+    }
+  }
+  // everything is sorted by (unit, frame), stable (markers carry the launch's frame count: last)
+  std::stable_sort(cmds.begin(), cmds.end(), [](const PgCmd& a, const PgCmd& b) { return a.unit != b.unit ? a.unit < b.unit : a.frame < b.frame; });
+  // SetSourceVolume / SetSourcePanning events reach the source through a ONE-slot queue that the mixer force_pushes into (mixed.rs:810-845,
+  // amplified.rs:33-35): of several such events that come due in front of the same chunk only the last one is still there when the source runs —
+  // and that matters, an exponential smoother snaps to a target that is close enough (smoothing.rs:221-226), so applying the earlier ones too
+  // can leave another `current` behind. (Speed and seek messages travel through the file's 128-slot queue and all arrive.)
+  for (size_t i = 0; i < cmds.size(); ++i) {
+    if (cmds[i].type != CMD_VOICE_VOLUME && cmds[i].type != CMD_VOICE_PAN) continue;
+    for (size_t j = i + 1; j < cmds.size() && cmds[j].unit == cmds[i].unit && cmds[j].frame == cmds[i].frame; ++j)
+      if (cmds[j].type == cmds[i].type && cmds[j].target == cmds[i].target) { cmds[i].type = CMD_NOP; break; }
+  }
+}
+
+// Renders frames [pos, pos + n_samples / 2) of the write call into d_out. The call is walked in the reference's chunks — min(remaining,
+// PG_MAX_FRAMES) frames from the call's start and from every main-mixer event (mixed.rs:679-712) — whatever max_frames is: a chunk is rendered
+// as pieces of at most max_frames frames, every per-chunk decision taken once per chunk on the device (pg_dev.h: PG_MAX_FRAMES).
+// cap_frames > 0: stop in front of the first chunk that would end beyond cap_frames (the caller's staging holds that much; >= PG_MAX_FRAMES)
+// and return what was rendered; the caller goes on with begin = false. Returns the samples rendered (0: nothing to do, or the graph failed).
+size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin, size_t cap_frames) {
   if (g->failed) return 0;
   // a consistency flag the kernels mirrored into the mapped feedback block (a unit left unrendered inside a super-block launch): what was
   // handed out since is not trustworthy — the graph goes silent like a GuardedSource whose source panicked (src/source/guarded.rs:87-107)
@@ -1146,14 +1246,19 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
   if (!g->stream_voices.empty() && flush_stream_feeds(g, stream)) { g->failed = true; return 0; }
   if (graph_is_empty(g)) return 0;
-  const uint64_t frames = n_samples / 2;
+  const uint64_t frames = n_samples / 2, mf = g->max_frames, CH = PG_MAX_FRAMES;
   uint64_t done = 0;
-  bool first = true;
+  auto fail = [&]() -> size_t { g->failed = true; return 0; };
   while (done < frames) {
     const uint64_t now = pos + done;
-    // main-mixer events due now apply at frame 0 of this round; the next main event bounds the round (:679-693)
-    std::vector<PgCmd> cmds;
     HostMixer& main = g->mixers[0];
+    if (cap_frames && done > 0) {  // would the next chunk still fit the caller's staging? (decided before its events are taken out of the queue)
+      uint64_t next_n = std::min<uint64_t>(frames - done, CH);
+      for (const Event& e : main.events) if (e.sample_time > now) { next_n = std::min<uint64_t>(next_n, e.sample_time - now); break; }
+      if (done + next_n > cap_frames) break;
+    }
+    // main-mixer events due now apply at frame 0 of the chunk; the next main event bounds it (:679-693)
+    std::vector<PgCmd> head;
     while (!main.events.empty() && main.events.front().sample_time <= now) {
       PgCmd c = main.events.front().cmd;
       if (g->defer_bus && (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET || c.type == CMD_NOP)) {  // the bus chain runs in pg_graph_process_bus_device
@@ -1164,93 +1269,131 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       }
       c.frame = 0;
       c.unit = (c.type == CMD_FX_PARAM || c.type == CMD_FX_RESET || c.type == CMD_NOP) ? main.unit_slot : g->source_unit_of_voice[c.param];  // voice commands carry the voice id in `param`
-      cmds.push_back(c);
+      head.push_back(c);
       main.events.erase(main.events.begin());
     }
-    uint64_t n = std::min<uint64_t>(frames - done, g->max_frames);
-    if (!main.events.empty()) n = std::min<uint64_t>(n, main.events.front().sample_time - now);
-    if (n == 0) continue;
+    // the regular chunk grid holds from here to the end of the call or the next main-mixer event
+    uint64_t span = frames - done;
+    if (!main.events.empty()) span = std::min<uint64_t>(span, main.events.front().sample_time - now);
+    if (span == 0) continue;
+    uint64_t chunk_n = std::min<uint64_t>(span, CH);
     // StopSource messages: processed by process_messages at the start of write (:294-499)
-    if (first) {
+    if (g->messages_due) {
       for (size_t m = 0; m < g->mixers.size(); ++m) {
         for (PgCmd c : g->mixers[m].messages) {
           c.frame = 0;
           c.unit = m == 0 ? g->source_unit_of_voice[c.param] : g->mixers[m].unit_slot;
-          cmds.push_back(c);
+          head.push_back(c);
         }
         g->mixers[m].messages.clear();
       }
-      first = false;
+      g->messages_due = false;
     }
-    // Nested sub-mixers: a mixer that splits its block at an event calls its sub-mixers once per segment (mixed.rs:679-712), so
-    // every event of a mixer with sub-mixers is also a call boundary (CMD_CALL_SPLIT) for all its descendants. A sub-mixer keeps
-    // one result bit per call: the round is bounded so that at most PG_MAX_CALLS - 1 boundaries fall inside it.
+    // ---- super-block: whole chunks without a command anywhere in them, in steady state, as ONE launch sequence (every workgroup of the staged /
+    // fast kernels walks the blocks of its unit; per-chunk decisions are still taken per chunk, on the device) ----
+    uint64_t k = 0;
+    if (head.empty() && span >= mf && graph_super_ok(g)) {
+      uint64_t kmax = std::min<uint64_t>(span / mf, g->max_blocks);
+      if (cap_frames) kmax = std::min<uint64_t>(kmax, (cap_frames - std::min<uint64_t>(done, cap_frames)) / mf);
+      uint64_t t_next = UINT64_MAX;
+      for (const HostMixer& mx : g->mixers) if (!mx.events.empty()) t_next = std::min(t_next, mx.events.front().sample_time);
+      if (t_next != UINT64_MAX && t_next < now + kmax * mf) kmax = t_next > now ? (t_next - now) / mf : 0;
+      // the launch must end where a chunk ends: at a multiple of the chunk length or at the end of the span
+      if (CH % mf == 0) k = (kmax * mf >= span && span % mf == 0) ? span / mf : (kmax / (CH / mf)) * (CH / mf);
+      else k = (span % mf == 0 && span <= CH && span / mf <= kmax) ? span / mf : 0;
+    }
+    if (k > 0) {
+      LaunchSpan sp;
+      sp.n = (uint32_t)mf; sp.t0 = now; sp.n_chunks = (int)k; sp.row_block = 0; sp.grid_off = 0; sp.grid_span = (uint32_t)std::min<uint64_t>(span, 0x7fffffffull);
+      sp.round = g->launch_counter++;
+      sp.generic_idle = true;  // (graph_super_ok: steady state, one level)
+      sp.timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < g->ev_pool.size() && g->n_graph_units > 0;
+      if (launch_level(g, 0, sp, stream)) return fail();
+      // where the blocks' `audible` words go: with the bus chain deferred to the caller, word c of the call belongs to its c-th block
+      const int slot = g->defer_bus ? (int)std::min<uint64_t>(done / mf, (uint64_t)g->audible_slots - k) : 0;
+      {
+        const Level& top = g->levels.back();
+        HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_out + done * 2, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
+                                   g->d_audible + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride));
+      }
+      if (!g->defer_bus && launch_bus(g, d_out + done * 2, sp, slot, stream)) return fail();
+      done += k * mf;
+      continue;
+    }
+    // ---- one chunk, piece by piece ----
+    // A sub-mixer keeps one result bit per call of its parent: the chunk is bounded so that at most PG_MAX_CALLS - 1 call boundaries fall inside it
     if (g->levels.size() > 1) {
       std::vector<uint64_t> cuts;
       for (size_t m = 1; m < g->mixers.size(); ++m) {
         if (g->mixers[m].children.empty()) continue;
-        for (const Event& e : g->mixers[m].events) { if (e.sample_time >= now + n) break; if (e.sample_time > now) cuts.push_back(e.sample_time); }
+        for (const Event& e : g->mixers[m].events) { if (e.sample_time >= now + chunk_n) break; if (e.sample_time > now) cuts.push_back(e.sample_time); }
       }
       std::sort(cuts.begin(), cuts.end());
       cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-      if (cuts.size() > (size_t)(PG_MAX_CALLS - 1)) n = cuts[PG_MAX_CALLS - 1] - now;
-      for (size_t m = 1; m < g->mixers.size(); ++m) {
-        if (g->mixers[m].children.empty()) continue;
-        std::vector<int> desc(g->mixers[m].children);
-        for (size_t i = 0; i < desc.size(); ++i) for (int c : g->mixers[desc[i]].children) desc.push_back(c);
-        for (const Event& e : g->mixers[m].events) {
-          if (e.sample_time >= now + n) break;
-          if (e.sample_time <= now) continue;
-          for (int d : desc) {
-            PgCmd c;
-            memset(&c, 0, sizeof c);
-            c.type = CMD_CALL_SPLIT; c.unit = g->mixers[d].unit_slot; c.frame = (uint32_t)(e.sample_time - now);
-            cmds.push_back(c);
-          }
-        }
+      if (cuts.size() > (size_t)(PG_MAX_CALLS - 1)) chunk_n = cuts[PG_MAX_CALLS - 1] - now;
+    }
+    const uint64_t n_pieces = (chunk_n + mf - 1) / mf, n_full = chunk_n / mf;
+    if (n_pieces > g->unit_out_blocks) { set_error(PG_ERR_STATE, "per-unit buffers were not reserved for a chunk's pieces"); return fail(); }
+    std::vector<LaunchSpan> spans((size_t)n_pieces);
+    const uint64_t round0 = g->launch_counter;
+    g->launch_counter += n_pieces;
+    const bool steady_now = g->levels.size() == 1 && graph_steady(g);
+    const size_t tl = timed_level_of(g);
+    for (uint64_t p = 0; p < n_pieces; ++p) {
+      LaunchSpan& sp = spans[(size_t)p];
+      sp.t0 = now + p * mf; sp.n = (uint32_t)std::min<uint64_t>(mf, chunk_n - p * mf);
+      sp.n_chunks = 1; sp.row_block = (int)p; sp.grid_off = (uint32_t)(p * mf); sp.grid_span = (uint32_t)chunk_n;
+      sp.round = round0 + p;
+      std::vector<PgCmd> cmds;
+      if (p == 0) cmds = head;
+      collect_piece_commands(g, cmds, sp.t0, sp.n, now, now + chunk_n);
+      if (!cmds.empty()) {
+        if (stage_commands(g, cmds, stream, &sp.d_cmds)) return fail();
+        sp.n_cmds = (int)cmds.size();
+        g->last_change_round = sp.round;
+      }
+      // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
+      // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.
+      // (Graphs with nested sub-mixers always launch it: the parents are rendered there.)
+      sp.generic_idle = steady_now && cmds.empty() && g->last_change_round < round0;
+    }
+    for (size_t li = 0; li < g->levels.size(); ++li) {
+      for (uint64_t p = 0; p < n_pieces; ++p) {
+        LaunchSpan sp = spans[(size_t)p];
+        // the event pair costs ~8 us of stream time per round (also when it rides on the dispatch): callers that only need the
+        // average can time every n-th round (pg_graph_set_timing_period)
+        sp.timed = li == tl && g->timing_period > 0 && ((sp.round + 1) % (uint64_t)g->timing_period) == 0 && g->ev_used < g->ev_pool.size() && g->n_graph_units > 0;
+        if (launch_level(g, li, sp, stream)) return fail();
       }
     }
-    // sub-mixer events inside [now, now+n): each sub-mixer splits its own block on the device
-    for (size_t m = 1; m < g->mixers.size(); ++m) {
-      HostMixer& mx = g->mixers[m];
-      while (!mx.events.empty() && mx.events.front().sample_time < now + n) {
-        PgCmd c = mx.events.front().cmd;
-        uint64_t t = mx.events.front().sample_time;
-        c.frame = t <= now ? 0u : (uint32_t)(t - now);
-        c.unit = mx.unit_slot;
-        cmds.push_back(c);
-        mx.events.erase(mx.events.begin());
+    // the chunk's sum and bus chain: its full pieces in one launch each, a shorter last piece in launches of its own
+    const int slot0 = g->defer_bus ? (int)std::min<uint64_t>(done / mf, (uint64_t)g->audible_slots - n_pieces) : 0;
+    const size_t chunk_stride = (size_t)g->unit_out_rows * g->stride;
+    const Level& top = g->levels.back();
+    float* dst = d_out + done * 2;
+    if (n_full > 0) HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
+                                               g->d_audible + slot0, stream, (int)n_full, chunk_stride));
+    if (n_pieces > n_full) {
+      const LaunchSpan& r = spans[(size_t)n_full];
+      HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)n_full * chunk_stride + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst + n_full * mf * 2, r.n * 2,
+                                 g->d_audible_tab + (size_t)n_full * g->unit_out_rows + top.off, g->unit_out_rows, g->d_audible + slot0 + (int)n_full, stream, 1, chunk_stride));
+    }
+    if (!g->defer_bus && !g->mixers[0].fx.empty()) {
+      // the bus unit's commands of the chunk's first piece (main-mixer effect events) ride on its bus launch
+      if (n_full > 0) {
+        LaunchSpan b = spans[0];
+        b.n_chunks = (int)n_full;
+        if (launch_bus(g, dst, b, slot0, stream)) return fail();
+      }
+      if (n_pieces > n_full) {
+        LaunchSpan b = spans[(size_t)n_full];
+        if (n_full > 0) { b.d_cmds = nullptr; b.n_cmds = 0; }
+        if (launch_bus(g, dst + n_full * mf * 2, b, slot0 + (int)n_full, stream)) return fail();
       }
     }
-    // bus commands run in the bus launch; everything is sorted by (unit, frame), stable
-    std::stable_sort(cmds.begin(), cmds.end(), [](const PgCmd& a, const PgCmd& b) { return a.unit != b.unit ? a.unit < b.unit : a.frame < b.frame; });
-    // SetSourceVolume / SetSourcePanning events reach the source through a ONE-slot queue that the mixer force_pushes into (mixed.rs:810-845,
-    // amplified.rs:33-35): of several such events that come due in front of the same chunk only the last one is still there when the source runs —
-    // and that matters, an exponential smoother snaps to a target that is close enough (smoothing.rs:221-226), so applying the earlier ones too
-    // can leave another `current` behind. (Speed and seek messages travel through the file's 128-slot queue and all arrive.)
-    for (size_t i = 0; i < cmds.size(); ++i) {
-      if (cmds[i].type != CMD_VOICE_VOLUME && cmds[i].type != CMD_VOICE_PAN) continue;
-      for (size_t j = i + 1; j < cmds.size() && cmds[j].unit == cmds[i].unit && cmds[j].frame == cmds[i].frame; ++j)
-        if (cmds[j].type == cmds[i].type && cmds[j].target == cmds[i].target) { cmds[i].type = CMD_NOP; break; }
-    }
-    // Super-block: when the call still spans several whole blocks of max_frames, nothing is scheduled inside them and the graph is in
-    // steady state, ONE launch sequence renders them all (the reference's MixedSource::write walks its <= 4096-frame chunks in one call
-    // the same way, mixed.rs:679-712); every per-block decision is still taken per block, on the device.
-    uint64_t k = 1;
-    if (cmds.empty() && n == g->max_frames && graph_super_ok(g)) {
-      k = std::min<uint64_t>((frames - done) / g->max_frames, g->max_blocks);
-      uint64_t t_next = UINT64_MAX;
-      for (const HostMixer& mx : g->mixers) if (!mx.events.empty()) t_next = std::min(t_next, mx.events.front().sample_time);
-      if (t_next != UINT64_MAX && t_next < now + k * n) k = (t_next - now) / n;  // (t_next >= now + n: no command fell into this block)
-      if (k < 1) k = 1;
-    }
-    // where the blocks' `audible` words go: with the bus chain deferred to the caller, word c of the call belongs to its c-th chunk (the
-    // sharded handle cuts its calls at every main-mixer event, so chunks and blocks coincide there); else the round's own words
-    const int slot = g->defer_bus ? (int)std::min<uint64_t>(done / g->max_frames, (uint64_t)PG_AUDIBLE_SLOTS - k) : 0;
-    if (launch_round(g, d_out + done * 2, (uint32_t)n, now, stream, !g->defer_bus, cmds, (int)k, slot)) { g->failed = true; return 0; }
-    done += n * k;
+    done += chunk_n;
   }
-  return n_samples;
+  return (size_t)done * 2;
 }
 
 extern "C" {
@@ -1264,29 +1407,35 @@ size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64
 
 size_t pg_graph_write(pg_graph* g, float* out, size_t n_samples, uint64_t pos_in_frames) {
   if (g->failed) return 0;
+  if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   (void)hipSetDevice(g->device);
-  size_t total = 0;
-  // the staging bus holds max_blocks chunks of max_frames (one super-block); larger writes are split like the reference's mix_buffer loop
-  const size_t cap = (size_t)g->stride * g->max_blocks;
-  size_t off = 0;
+  // ONE write call of the main mixer whatever its length (process_messages once, one call end): the staging bus holds whole chunks — at least
+  // PG_MAX_FRAMES frames — and the call is rendered in spans of as many chunks as fit, each copied out behind its last launch
+  graph_begin_write(g, pos_in_frames);
+  g->call_end = pos_in_frames + n_samples / 2;
+  const size_t cap_frames = g->bus_frames;
+  size_t off = 0, total = 0;
   uint64_t pos = pos_in_frames;
   while (off < n_samples) {
-    size_t n = std::min(cap, n_samples - off);
-    size_t w = graph_write_impl(g, g->d_bus, n, pos, g->stream);
-    if (w == 0) { if (g->failed) return 0; if (off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
+    const size_t w = graph_write_impl(g, g->d_bus, n_samples - off, pos, g->stream, false, cap_frames);
+    if (w == 0) {  // nothing to do (from here on): silence for the rest of a call that has produced output, 0 for one that has not
+      if (g->failed || off == 0) return 0;
+      memset(out + off, 0, (n_samples - off) * sizeof(float));
+      break;
+    }
     // device feedback: how many main-mixer sources are still alive (transient sources are dropped when exhausted, :715)
-    if (graph_enqueue_status(g, g->stream) != PG_OK || hipMemcpyAsync(g->h_pinned, g->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+    if (graph_enqueue_status(g, g->stream) != PG_OK || hipMemcpyAsync(g->h_pinned, g->d_bus, w * sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         pg_stream_sync(g->stream) != hipSuccess) {
       g->failed = true;
       set_error(PG_ERR_DEVICE, "device failure in write: %s", hipGetErrorString(hipGetLastError()));
       return 0;
     }
     g->cmds_since_sync = 0;
-    memcpy(out + off, g->h_pinned, n * sizeof(float));
+    memcpy(out + off, g->h_pinned, w * sizeof(float));
     graph_collect_status(g);
-    off += n; pos += n / 2; total += n;
+    off += w; pos += w / 2; total += w;
   }
-  return total;
+  return off >= n_samples || total > 0 ? n_samples : 0;
 }
 
 }  // extern "C"
@@ -1302,12 +1451,13 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
   if (g->last_stream && g->last_stream != s) { HIP_TRY(pg_stream_sync(g->last_stream)); g->cmds_since_sync = 0; }
   g->last_stream = s;
   if (g->topo_dirty && rebuild_topology(g, s)) return graph_fail(g, PG_ERR_DEVICE);
-  size_t frames = n_samples / 2, done = 0;
+  const uint64_t frames = n_samples / 2, mf = g->max_frames, CH = PG_MAX_FRAMES;
+  uint64_t done = 0;
   HostMixer& main = g->mixers[0];
   while (done < frames) {
     const uint64_t now = pos_in_frames + done;
-    // effect events of the main mixer (queued by write in defer_bus mode) split the bus block at their sample times, exactly
-    // like the event loop of MixedSource::write (mixed.rs:679-712)
+    // effect events of the main mixer (queued by write in defer_bus mode) cut the bus into chunks at their sample times, exactly
+    // like the event loop of MixedSource::write (mixed.rs:679-712); between them the chunks are PG_MAX_FRAMES long, rendered in pieces
     std::vector<PgCmd> cmds;
     while (!main.bus_events.empty() && main.bus_events.front().sample_time <= now) {
       PgCmd c = main.bus_events.front().cmd;
@@ -1315,31 +1465,58 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
       cmds.push_back(c);
       main.bus_events.erase(main.bus_events.begin());
     }
-    uint64_t n64 = std::min<uint64_t>(frames - done, g->max_frames);
-    if (!main.bus_events.empty()) n64 = std::min<uint64_t>(n64, main.bus_events.front().sample_time - now);
-    if (n64 == 0) continue;
-    const uint32_t n = (uint32_t)n64;
-    uint64_t k = 1;  // whole blocks this launch walks
-    if (cmds.empty() && n == g->max_frames) {
-      k = (frames - done) / g->max_frames;
-      if (!main.bus_events.empty()) k = std::min<uint64_t>(k, (main.bus_events.front().sample_time - now) / n);
-      k = std::max<uint64_t>(1, std::min<uint64_t>(k, PG_AUDIBLE_SLOTS));
-    }
+    uint64_t span = frames - done;
+    if (!main.bus_events.empty()) span = std::min<uint64_t>(span, main.bus_events.front().sample_time - now);
+    if (span == 0) continue;
+    // whole blocks of max_frames in one launch (as many chunks as the span holds), a chunk's shorter last piece in a launch of its own
     const PgCmd* d_cmds = nullptr;
     if (!cmds.empty()) { int rc = stage_commands(g, cmds, s, &d_cmds); if (rc) return rc; }
-    PgLaunch B;
-    memset(&B, 0, sizeof B);
-    B.units = g->d_units.d; B.voices = g->d_voices.d; B.fx = g->d_fx.d;
-    B.voice_index = g->d_voice_index.d; B.fx_index = g->d_fx_index.d;
-    B.cmds = d_cmds; B.n_cmds = (int)cmds.size(); B.error_word = g->d_error;
-    B.n_frames = n; B.pos = now; B.sample_rate = g->sample_rate; B.fast = g->fast;
-    B.n_units = 1; B.unit_base = main.unit_slot;
-    B.n_chunks = (int)k;
-    B.bus = d_bus + done * 2;
-    B.bus_audible = bus_audible ? bus_audible + std::min<uint64_t>(done / g->max_frames, (uint64_t)PG_AUDIBLE_SLOTS - k) : nullptr;
-    bus_pipeline_setup(g, B);
-    HIP_TRY(pg_launch_units(B, s));
-    done += (uint64_t)n * k;
+    uint64_t off = 0;  // frames of the span rendered
+    while (off < span) {
+      const uint64_t chunk_start = (off / CH) * CH, chunk_end = std::min<uint64_t>(chunk_start + CH, span);
+      LaunchSpan sp;
+      sp.t0 = now + off; sp.grid_off = (uint32_t)off; sp.grid_span = (uint32_t)std::min<uint64_t>(span, 0x7fffffffull);
+      sp.round = g->launch_counter;
+      uint64_t k;
+      if (chunk_end - off < mf) { sp.n = (uint32_t)(chunk_end - off); k = 1; }      // the chunk's last, shorter piece
+      else {
+        sp.n = (uint32_t)mf;
+        // full pieces: to the end of this chunk, and on through the following whole chunks when the pieces tile them
+        k = (chunk_end - off) / mf;
+        if (CH % mf == 0 && (chunk_end - off) % mf == 0) k = (span - off) / mf;
+        k = std::max<uint64_t>(1, std::min<uint64_t>(k, g->audible_slots));
+      }
+      sp.n_chunks = (int)k;
+      if (off == 0 && d_cmds) { sp.d_cmds = d_cmds; sp.n_cmds = (int)cmds.size(); }
+      // word c of the call belongs to its c-th block of max_frames (a chunk's flag sits in the word of its last piece)
+      const uint64_t word = std::min<uint64_t>((done + off) / mf, (uint64_t)g->audible_slots - k);
+      auto one = [&](const LaunchSpan& q, float* dst, int* flags) -> int {
+        PgLaunch B;
+        fill_launch(g, q, B);
+        B.mode = 0; B.n_units = 1; B.unit_order = nullptr; B.unit_base = main.unit_slot;
+        B.bus = dst; B.bus_audible = flags; B.audible_tab = nullptr; B.sched = nullptr;
+        bus_pipeline_setup(g, B);
+        HIP_TRY(pg_launch_units(B, s));
+        return PG_OK;
+      };
+      float* dst = d_bus + (done + off) * 2;
+      int* flags = bus_audible ? bus_audible + word : nullptr;
+      if (sp.n_cmds > 0 && sp.n_chunks > 1) {  // commands ride on a launch of the first block alone
+        LaunchSpan head = sp;
+        head.n_chunks = 1;
+        int rc = one(head, dst, flags);
+        if (rc) return rc;
+        LaunchSpan rest = sp;
+        rest.d_cmds = nullptr; rest.n_cmds = 0; rest.t0 += sp.n; rest.grid_off += sp.n; rest.n_chunks -= 1;
+        rc = one(rest, dst + (size_t)sp.n * 2, flags ? flags + 1 : nullptr);
+        if (rc) return rc;
+      } else {
+        int rc = one(sp, dst, flags);
+        if (rc) return rc;
+      }
+      off += (uint64_t)sp.n * k;
+    }
+    done += span;
   }
   return PG_OK;
 }

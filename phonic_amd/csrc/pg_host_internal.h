@@ -239,7 +239,10 @@ struct pg_graph {
   size_t stage_rows = 0;
   bool defer_bus = false;
   size_t max_blocks = 1;        // blocks of max_frames one launch sequence may render (pg_graph_set_max_blocks_per_launch); sizes d_unit_out
-  size_t unit_out_blocks = 0;   // ... as allocated
+  size_t unit_out_blocks = 0;   // per-unit output tables as allocated: max(max_blocks, pieces of a chunk)
+  size_t bus_frames = 0;        // frames the staging of pg_graph_write holds (whole chunks: >= PG_MAX_FRAMES)
+  size_t audible_slots = 0;     // words of d_audible: one per block of a launch sequence / piece of a chunk
+  bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
   unsigned long long* d_bus_progress = nullptr;  // progress words of the pipelined bus chain (pg_bus_pipeline)
   uint32_t bus_epoch = 0;       // launch number of the pipelined bus chain, carried by its progress words
@@ -282,7 +285,7 @@ struct pg_graph {
   float* d_unit_out = nullptr; size_t unit_out_rows = 0;
   float* d_partial = nullptr; size_t partial_rows = 0;
   float* d_bus = nullptr;               // [2*max_frames + 4]
-  int* d_audible = nullptr;             // [PG_AUDIBLE_SLOTS] audible_input of the bus chain, one word per block of a round / of a deferred-bus call
+  int* d_audible = nullptr;             // [audible_slots] audible_input of the bus chain, one word per block of a round / of a deferred-bus call
   int32_t* d_audible_tab = nullptr;     // [max_blocks][unit_out_rows] per-unit `audible` results, block by block (PgLaunch::audible_tab)
   bool status_pending = false;          // graph_enqueue_status ran, graph_collect_status has not
   float* h_pinned = nullptr;
@@ -304,5 +307,5 @@ bool graph_is_empty(const pg_graph* g);
 uint64_t graph_next_main_event(const pg_graph* g);
 int graph_enqueue_status(pg_graph* g, hipStream_t stream);
 void graph_collect_status(pg_graph* g);
-size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin = true);
+size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t pos, hipStream_t stream, bool begin = true, size_t cap_frames = 0);
 int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, hipStream_t s, int* bus_audible);

@@ -31,6 +31,22 @@ __device__ __forceinline__ void pg_raise_super_deferred(const PgLaunch& L) {
   if (L.host_feedback) { *(volatile unsigned long long*)(L.host_feedback + 2) = (unsigned long long)PG_DEVERR_SUPER_DEFERRED; __threadfence_system(); }
 }
 
+// Where block c of the launch sits in the main mixer's chunk grid (PgLaunch::grid_off / grid_span, pg_dev.h).
+__device__ __forceinline__ PgPiece pg_piece(const PgLaunch& L, int c) {
+  PgPiece p;
+  const uint32_t N = L.n_frames;
+  if (L.grid_span == 0) { p.first = true; p.last = true; p.c_last = c; p.chunk_end = L.pos + (uint64_t)(c + 1) * (uint64_t)N; return p; }
+  const uint32_t o = L.grid_off + (uint32_t)c * N;
+  const uint32_t cs = o & ~((uint32_t)PG_MAX_FRAMES - 1u);
+  uint32_t ce = cs + (uint32_t)PG_MAX_FRAMES;
+  if (ce > L.grid_span) ce = L.grid_span;
+  p.first = o == cs;
+  p.last = o + N >= ce;
+  p.c_last = c + (int)((ce - o - 1u) / N);
+  p.chunk_end = L.pos - (uint64_t)L.grid_off + (uint64_t)ce;
+  return p;
+}
+
 // ---- parameter updates (Effect::process_parameter_update of each effect), lane 0 --------------------
 // Returns 1 when the whole workgroup must flush state afterwards (compressor look-ahead line re-created).
 // aux: time-constant coefficients the HOST computed for this update (pg_host.hip: fx_param_aux) — exp(-1 / (t * fs)) sits within 1e-5 of one, where a
@@ -204,12 +220,25 @@ __device__ __noinline__ void fx_flush_wg(PgFx& fx, int reset_message) {
 
 // ---- Effect::process dispatch: time-parallel steady-state path when eligible, exact serial path otherwise ----
 // FAST_ONLY kernels contain no serial effect code at all (register budget); eligibility was checked up front.
+// The effect's own call-end bookkeeping, behind the last piece of a process call. `n` = this piece's samples; fx.call_frames = the frames of
+// the call's earlier pieces (kept by the processor; 0 for a standalone effect, whose every launch is one call).
+template <int KMASK>
+__device__ __forceinline__ void fx_call_end(PgFx& fx, int n, bool call_last) {
+  if constexpr ((KMASK >> 6) & 1) {
+    if (fx.kind == 6 && call_last) {
+      __syncthreads();
+      if (pg_tid() == 0) chorus_call_end(fx, (uint64_t)fx.call_frames + (uint64_t)(n / 2));
+      __syncthreads();
+    }
+  }
+}
 template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast) {
+__device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastCtx& fc, int fast, bool call_last) {
   if (FAST_ONLY) {
     // no serial code in this kernel: the host's routing (lean / wide / staged) and the eligibility check of the previous block must
     // agree with what the time-parallel path accepts. A decline here leaves the effect unapplied for this block: make it visible.
     if (!fx_fast_process<KMASK>(fx, sig, n, fc) && fc.err && pg_tid() == 0) atomicOr(fc.err, PG_DEVERR_FAST_DECLINED);
+    fx_call_end<KMASK>(fx, n, call_last);
     return;
   } else {
     // One pass in all cases but one: a Reverb whose room size moves. Its linear smoother arrives after `pending` frames (<= 109 at 44.1 kHz:
@@ -218,7 +247,7 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
     int off = 0;
 #pragma nounroll
     while (off < n) {
-      if (fast && fx_fast_process<KMASK>(fx, sig + off, n - off, fc)) return;
+      if (fast && fx_fast_process<KMASK>(fx, sig + off, n - off, fc)) break;
       __syncthreads();
       int head = n - off;
       if (fast && off == 0 && fx.kind == 5 && fx.u.reverb.room.kind == SM_LIN && fx.u.reverb.room.pending > 0 &&
@@ -242,33 +271,43 @@ __device__ __forceinline__ void fx_process_wg(PgFx& fx, float* sig, int n, FastC
       __syncthreads();
       off += head;
     }
+    fx_call_end<KMASK>(fx, n, call_last);
   }
 }
 
 // ---- EffectProcessor::process  src/source/mixed/effect.rs:56-145 -------------------------------------
+// One process call of the processor = one chunk of its mixer, rendered as pieces: `first` / `last` name the chunk's first / last piece.
 // ctl: LDS words for uniform decisions. Returns true when the effect processed output.
-// pre-part: bypass decision (:88-101). Returns true when the effect is bypassed for this block. All lanes call.
-__device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, int* ctl) {
+// pre-part: the bypass decision (:88-101), taken at the chunk's first piece and kept for its later ones. Returns true when the effect is
+// bypassed for this chunk. All lanes call.
+__device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, bool first, int* ctl) {
   __syncthreads();
   if (pg_tid() == 0) {
-    bool should_bypass = input_bypassed && fx.tail_counter == 0 && fx.silence_counter == PG_USIZE_MAX;  // :88-91
-    if (should_bypass && !fx.bypassed) fx.bypassed = 1;                                                // process_stopped: no-op for stock effects
-    else if (!should_bypass && fx.bypassed) { fx.bypassed = 0; fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0; }
+    if (first) {
+      bool should_bypass = input_bypassed && fx.tail_counter == 0 && fx.silence_counter == PG_USIZE_MAX;  // :88-91
+      if (should_bypass && !fx.bypassed) fx.bypassed = 1;                                                // process_stopped: no-op for stock effects
+      else if (!should_bypass && fx.bypassed) { fx.bypassed = 0; fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0; }
+      fx.call_frames = 0; fx.call_max = 0.0f;
+    }
     ctl[0] = fx.bypassed;
   }
   __syncthreads();
   return ctl[0] != 0;
 }
-// post-part: update_tail_counters / reset_tail_counters (:111-152) after the effect rendered `n` samples into `sig`
-__device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, int n, bool input_bypassed, uint32_t sample_rate, int* ctl, float* red) {
+// post-part: update_tail_counters / reset_tail_counters (:111-152) once the effect has rendered the whole chunk: `n` samples of this piece in
+// `sig`, fx.call_frames frames in the pieces before it. The counters move at the last piece, by the chunk's length; the silence detection
+// looks at the peak over the whole chunk (fx.call_max carries it from piece to piece).
+__device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, int n, bool input_bypassed, bool last, uint32_t sample_rate, int* ctl, float* red) {
   if (input_bypassed) {  // update_tail_counters :111-145
     if (pg_tid() == 0) {
       uint64_t tail_frames;
       if (fx_process_tail(fx, tail_frames)) {
-        if (tail_frames == PG_USIZE_MAX) fx.tail_counter = tail_frames;
-        else if (fx.tail_counter == PG_USIZE_MAX) fx.tail_counter = tail_frames;
-        else { uint64_t fp = (uint64_t)(n / 2); fx.tail_counter = fx.tail_counter > fp ? fx.tail_counter - fp : 0; }
-        fx.silence_counter = PG_USIZE_MAX;
+        if (last) {
+          if (tail_frames == PG_USIZE_MAX) fx.tail_counter = tail_frames;
+          else if (fx.tail_counter == PG_USIZE_MAX) fx.tail_counter = tail_frames;
+          else { uint64_t fp = (uint64_t)fx.call_frames + (uint64_t)(n / 2); fx.tail_counter = fx.tail_counter > fp ? fx.tail_counter - fp : 0; }
+          fx.silence_counter = PG_USIZE_MAX;
+        }
         ctl[1] = 0;
       } else ctl[1] = 1;
     }
@@ -276,25 +315,28 @@ __device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, in
     if (ctl[1]) {  // unknown tail: detect silence
       float max_sample = wg_max_abs(sig, n, red);
       if (pg_tid() == 0) {
-        if (max_sample < 0.001f) {
-          uint64_t fp = (uint64_t)(n / 2);
+        max_sample = fmaxf(max_sample, fx.call_max);
+        if (!last) fx.call_max = max_sample;
+        else if (max_sample < 0.001f) {
+          uint64_t fp = (uint64_t)fx.call_frames + (uint64_t)(n / 2);
           fx.silence_counter = (fx.silence_counter > PG_USIZE_MAX - fp) ? PG_USIZE_MAX : fx.silence_counter + fp;
           if (fx.silence_counter >= 2ull * (uint64_t)sample_rate) { fx.tail_counter = 0; fx.silence_counter = PG_USIZE_MAX; }
         } else fx.silence_counter = 0;
       }
     }
-  } else if (pg_tid() == 0) {
+  } else if (pg_tid() == 0 && last) {
     fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0;  // reset_tail_counters :148-152
   }
+  if (pg_tid() == 0) { if (last) { fx.call_frames = 0; fx.call_max = 0.0f; } else fx.call_frames += (uint32_t)(n / 2); }
   __syncthreads();
 }
 template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, uint32_t sample_rate, FastCtx& fc, int fast, int* ctl,
-                                     float* red) {
-  if (fx_processor_pre(fx, input_bypassed, ctl)) return false;
+__device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n, bool input_bypassed, bool first, bool last, uint32_t sample_rate, FastCtx& fc, int fast,
+                                     int* ctl, float* red) {
+  if (fx_processor_pre(fx, input_bypassed, first, ctl)) return false;
   PG_STAMP(fc.diag, 9);
-  fx_process_wg<FAST_ONLY, KMASK>(fx, sig, n, fc, fast);
-  fx_processor_post(fx, sig, n, input_bypassed, sample_rate, ctl, red);
+  fx_process_wg<FAST_ONLY, KMASK>(fx, sig, n, fc, fast, last);
+  fx_processor_post(fx, sig, n, input_bypassed, last, sample_rate, ctl, red);
   return true;
 }
 
@@ -302,24 +344,46 @@ __device__ __forceinline__ bool fx_processor_process(PgFx& fx, float* sig, int n
 // dynamic LDS: [sig 2*n_frames f32][tmp 2*n_frames f32][scratch]
 extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 
-// SubMixerProcessor::process (src/source/mixed/submixer.rs:47-77) for frames [a, b) of the block = one write() call of this
-// sub-mixer: silence gate on the call's peak, then the call's samples (or silence) go to the unit's output row. Returns whether the
-// call produced output. (A sub-mixer without sources, effects or events returns 0 samples: max over an empty slice = 0 -> silent.)
-__device__ __forceinline__ bool submixer_finish_call(PgUnit& unit, const float* sig, float* out, int a, int b, uint32_t sample_rate, int* ctl, float* red) {
+// SubMixerProcessor::process (src/source/mixed/submixer.rs:47-77): one call = one write() of this sub-mixer = one chunk of its parent,
+// rendered as pieces. Frames [a, b) of this piece belong to the call in progress; `closes`: the call ends at b. The silence gate looks at the
+// peak of the WHOLE call (unit.call_max carries it from piece to piece, unit.call_frames the frames of the earlier pieces) and decides when
+// the call closes; until then a piece's samples go to the unit's output row as they are, and a call that closes below the gate takes them
+// back — its rows of the earlier pieces sit in the tables in front of this one (`table_stride` floats apart, `piece_frames` frames each;
+// the mixer sum runs behind a chunk's last piece). Returns whether the call produced output (meaningful when it closes).
+// (A sub-mixer without sources, effects or events returns 0 samples: max over an empty slice = 0 -> silent.)
+__device__ __forceinline__ bool submixer_call_piece(PgUnit& unit, int* ur_call /* LDS copy of {call_max, call_frames} */, const float* sig, float* out, int a, int b, bool closes,
+                                                     uint32_t sample_rate, size_t table_stride, int piece_frames, int* ctl, float* red) {
   const int tid = pg_tid(), nt = blockDim.x;
   const float max_sample = wg_max_abs(sig + 2 * a, 2 * (b - a), red);
   if (tid == 0) {
-    int audible;
-    if (max_sample < 0.001f) {
-      unit.silence_counter += (uint64_t)(b - a);
-      audible = unit.silence_counter < 2ull * (uint64_t)sample_rate ? 1 : 0;
-    } else { unit.silence_counter = 0; audible = 1; }
-    ctl[3] = audible;
+    const float peak = fmaxf(max_sample, __int_as_float(ur_call[0]));
+    const uint32_t before = (uint32_t)ur_call[1];
+    int audible = 1, take_back = 0;
+    if (!closes) { unit.call_max = peak; unit.call_frames = before + (uint32_t)(b - a); ur_call[0] = __float_as_int(peak); ur_call[1] = (int)(before + (uint32_t)(b - a)); }
+    else {
+      if (peak < 0.001f) {
+        unit.silence_counter += (uint64_t)before + (uint64_t)(b - a);
+        audible = unit.silence_counter < 2ull * (uint64_t)sample_rate ? 1 : 0;
+      } else unit.silence_counter = 0;
+      take_back = (!audible && before > 0) ? (int)before : 0;
+      unit.call_max = 0.0f; unit.call_frames = 0; ur_call[0] = 0; ur_call[1] = 0;
+    }
+    ctl[3] = audible; ctl[4] = take_back;
   }
   __syncthreads();
   const bool audible = ctl[3] != 0;
   if (audible) { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = sig[i]; }
   else { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = 0.0f; }
+  int back = ctl[4];
+  if (back > 0 && a == 0) {  // (a call that began in an earlier piece reaches this one at its frame 0)
+    float* row = out;
+    while (back > 0) {
+      row -= table_stride;
+      const int k = back < piece_frames ? back : piece_frames;
+      for (int i = 2 * (piece_frames - k) + tid; i < 2 * piece_frames; i += nt) row[i] = 0.0f;
+      back -= k;
+    }
+  }
   __syncthreads();
   return audible;
 }
@@ -373,7 +437,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
   int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
-  int* ur = (int*)scratch;                         scratch += 96;   // copy of the unit record (sizeof(PgUnit) <= 96)
+  int* ur = (int*)scratch;                         scratch += 128;  // copy of the unit record (sizeof(PgUnit) <= 128)
   if (tid < (int)(sizeof(PgUnit) / 4)) ur[tid] = (int)unit_w;     // (read behind the barrier of the deferral decision / the block's first barrier)
   SrcScratch S;
   src_carve(scratch, S);
@@ -417,27 +481,51 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   } else {
     for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
   }
+  // Where this piece sits: in the main mixer's chunk grid (pc), and — units with events of their own or of an ancestor inside the main chunk
+  // (the generic kernel only) — where the unit's own chunk / its parent's call end before the main chunk does (CMD_CHUNK_END / CMD_CALL_END).
+  const PgPiece pc = pg_piece(L, chunk);
+  const uint64_t pos0 = L.pos + (uint64_t)chunk * (uint64_t)N;
+  uint64_t chunk_end_mark = pc.chunk_end, call_end_mark = pc.chunk_end;
+  int ci = 0;  // command cursor (commands are sorted by (unit, frame))
+  while (ci < L.n_cmds && L.cmds[ci].unit < u) ++ci;
+  if (!FAST_ONLY) {
+    for (int cj = ci; cj < L.n_cmds && L.cmds[cj].unit == u; ++cj) {
+      if ((int)L.cmds[cj].frame < N) continue;
+      if (L.cmds[cj].type == CMD_CHUNK_END && L.cmds[cj].value64 < chunk_end_mark) chunk_end_mark = L.cmds[cj].value64;
+      if (L.cmds[cj].type == CMD_CALL_END && L.cmds[cj].value64 < call_end_mark) call_end_mark = L.cmds[cj].value64;
+    }
+    if (call_end_mark < chunk_end_mark) chunk_end_mark = call_end_mark;  // (a call boundary ends the chunk as well)
+  }
+  if (tid == 0 && pc.first) {  // a new chunk of the main mixer: its sub-mixers' calls and segments count from here
+    unit.call_idx = 0; unit.call_audible = 0; unit.seg_idx = -1; unit.chunk_any_audible = 0;
+    PG_UL(call_idx) = 0; PG_UL(seg_idx) = -1; PG_UL(chunk_any_audible) = 0;
+    ((unsigned long long*)&PG_UL(call_audible))[0] = 0ull;
+  }
   __syncthreads();
 
   // ---- event-split loop of MixedSource::write (mixed.rs:679-712) for this unit ----
-  int ci = 0;  // command cursor (commands are sorted by (unit, frame))
-  while (ci < L.n_cmds && L.cmds[ci].unit < u) ++ci;
   int frame0 = 0;
-  bool any_audible = false;
-  // nested sub-mixers: an ancestor that splits its block at events calls this unit once per segment (CMD_CALL_SPLIT marks the
-  // boundaries); the silence gate and the `audible` result are per call. Only the generic kernel sees more than one call.
+  // nested sub-mixers: an ancestor that splits its chunk at events calls this unit once per segment (CMD_CALL_SPLIT marks the
+  // boundaries); the silence gate and the `audible` result are per call. Only the generic kernel sees more than one call per piece.
   float* const out = external ? nullptr : L.unit_out + (size_t)chunk * L.chunk_stride + (size_t)slot * L.out_stride;
-  int call_start = 0, call_idx = 0, seg_idx = 0;
-  unsigned long long call_mask = 0;
+  int call_start = 0;
+  bool cmd_at_0 = false;
   while (frame0 < N) {
     // apply all commands due at frame0 (process_events, event.rs:41-50)
     while (!FAST_ONLY && ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {  // (the fast kernel defers units with commands)
       const PgCmd cmd = L.cmds[ci];
+      if (frame0 == 0) cmd_at_0 = true;
       if (cmd.type == CMD_CALL_SPLIT) {
-        if (frame0 > call_start && PG_UL(kind) == UNIT_SUBMIXER && call_idx < PG_MAX_CALLS - 1) {
+        if ((frame0 > call_start || PG_UL(call_frames) > 0) && PG_UL(kind) == UNIT_SUBMIXER && PG_UL(call_idx) < PG_MAX_CALLS - 1) {
           __syncthreads();
-          if (submixer_finish_call(unit, sig, out, call_start, frame0, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
-          ++call_idx;
+          const bool aud = submixer_call_piece(unit, &PG_UL(call_max), sig, out, call_start, frame0, true, L.sample_rate, (size_t)L.chunk_stride, (int)(L.out_stride / 2), ctl, red);
+          if (tid == 0) {
+            const unsigned long long m = ((unsigned long long*)&PG_UL(call_audible))[0] | (aud ? 1ull << PG_UL(call_idx) : 0ull);
+            ((unsigned long long*)&PG_UL(call_audible))[0] = m; unit.call_audible = m;
+            if (PG_UL(call_idx) == 0) unit.audible = aud ? 1 : 0;
+            PG_UL(call_idx) += 1; unit.call_idx = PG_UL(call_idx);
+          }
+          __syncthreads();
           call_start = frame0;
         }
         ++ci;
@@ -464,18 +552,25 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     if (ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame < N) frame1 = (int)L.cmds[ci].frame;
     const int seg = frame1 - frame0;
     float* sseg = sig + 2 * frame0;
-    const uint64_t pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)frame0;
+    const uint64_t pos = pos0 + (uint64_t)frame0;
+    // this segment within the unit's chunk (one MixedSource::write chunk = one call of every source, processor and sub-mixer under it):
+    // a chunk begins with the main mixer's chunk and at every command of the unit; it ends where the next one begins
+    const bool seg_first = frame0 > 0 || pc.first || cmd_at_0;
+    const bool seg_last = frame1 < N || pos0 + (uint64_t)N >= chunk_end_mark;
+    const uint64_t seg_chunk_end = frame1 < N ? pos0 + (uint64_t)frame1 : chunk_end_mark;
+    if (seg_first) { __syncthreads(); if (tid == 0) { PG_UL(seg_idx) += 1; unit.seg_idx = PG_UL(seg_idx); } __syncthreads(); }
     bool audible_input;
     if (external) {
-      audible_input = (PG_UL(kind) == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[chunk] != 0) : true);
+      // (the main mixer's chunk: the flag of the summed input sits in the word of the chunk's last piece)
+      audible_input = (PG_UL(kind) == UNIT_EFFECT) ? true : (L.bus_audible ? (L.bus_audible[pc.c_last] != 0) : true);
     } else {
       audible_input = false;
       // (not in the four-per-CU kernel, whose registers are spoken for: the host sends graphs with nested mixers to the wide kernel instead)
       if (!(FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) && PG_UL(n_children) > 0) {  // process_sub_mixers (mixed.rs:505-554): add_buffers per sub-mixer, in the order they were added
-        const int k = seg_idx < PG_MAX_CALLS - 1 ? seg_idx : PG_MAX_CALLS - 1;
+        const int k = PG_UL(seg_idx) < PG_MAX_CALLS - 1 ? PG_UL(seg_idx) : PG_MAX_CALLS - 1;
         for (int c = 0; c < PG_UL(n_children); ++c) {
           const int2 cr = L.child_rows[PG_UL(child_off) + c];
-          const float* row = L.rows_base + (size_t)cr.x * L.out_stride + 2 * frame0;
+          const float* row = L.rows_base + (size_t)chunk * L.chunk_stride + (size_t)cr.x * L.out_stride + 2 * frame0;
           for (int i = tid; i < 2 * seg; i += nt) sseg[i] += row[i];
           const PgUnit& cu = L.units[cr.y];
           audible_input |= k == 0 ? cu.audible != 0 : ((cu.call_audible >> k) & 1ull) != 0;
@@ -483,16 +578,28 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
         __syncthreads();
       }
       // where the MixedSource::write call that this segment belongs to ends (PgVoice::zombie_end): the whole write for a source of the main
-      // mixer; for a sub-mixer the parent's current chunk — up to its next call boundary (CMD_CALL_SPLIT) or the end of the block
+      // mixer; for a sub-mixer the parent's current chunk — up to its next call boundary (CMD_CALL_SPLIT, CMD_CALL_END) or the end of the main chunk
       uint64_t call_end_pos = L.call_end;
       if (PG_UL(kind) != UNIT_SOURCE) {
-        int split = N;
-        if (!FAST_ONLY) for (int cj = ci; cj < L.n_cmds && L.cmds[cj].unit == u; ++cj) if (L.cmds[cj].type == CMD_CALL_SPLIT && (int)L.cmds[cj].frame > frame0) { split = (int)L.cmds[cj].frame; break; }
-        call_end_pos = L.pos + (uint64_t)chunk * (uint64_t)N + (uint64_t)split;
+        call_end_pos = call_end_mark;
+        if (!FAST_ONLY) for (int cj = ci; cj < L.n_cmds && L.cmds[cj].unit == u; ++cj) if (L.cmds[cj].type == CMD_CALL_SPLIT && (int)L.cmds[cj].frame > frame0 && (int)L.cmds[cj].frame < N) { call_end_pos = pos0 + (uint64_t)L.cmds[cj].frame; break; }
       }
+      int later = 0;
       for (int vi = 0; vi < PG_UL(n_voices); ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? PG_UL(voice0) : L.voice_index[PG_UL(voice_off) + vi]];
-        audible_input |= voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos);
+        const int r = voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos, seg_first, seg_chunk_end);
+        audible_input |= (r & 1) != 0;
+        later |= r & 2;
+      }
+      if (PG_UL(kind) == UNIT_SOURCE) {  // (no chain: the unit's result is whether its source produced output anywhere in the chunk)
+        if (audible_input && tid == 0) { unit.chunk_any_audible = 1; PG_UL(chunk_any_audible) = 1; }
+      } else {
+        // audible_input of the chunk (mixed.rs:696-706) is decided where the chunk begins: sub-mixers audible in it, sources that produced output
+        // in this piece, sources that start in one of its later pieces; the later pieces take the decision from the unit record
+        __syncthreads();
+        if (seg_first) { if (tid == 0) { const int ai = (audible_input || later) ? 1 : 0; unit.chunk_audible_input = ai; PG_UL(chunk_audible_input) = ai; } }
+        __syncthreads();
+        audible_input = PG_UL(chunk_audible_input) != 0;
       }
     }
     PG_STAMP(L.diag, 1);
@@ -513,19 +620,18 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           PgFx& fx = *lfx;
           PG_STAMP(L.diag, 8);
           bool is_active;
-          if (fx.standalone) { fx_process_wg<FAST_ONLY, KMASK>(fx, sseg, seg * 2, fc, L.fast); is_active = true; }
-          else is_active = fx_processor_process<FAST_ONLY, KMASK>(fx, sseg, seg * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+          if (fx.standalone) { fx_process_wg<FAST_ONLY, KMASK>(fx, sseg, seg * 2, fc, L.fast, true); is_active = true; }
+          else is_active = fx_processor_process<FAST_ONLY, KMASK>(fx, sseg, seg * 2, input_bypassed, seg_first, seg_last, L.sample_rate, fc, L.fast, ctl, red);
           if (is_active) { input_bypassed = false; all_bypassed = false; }
           __syncthreads();
           for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
         }
         __syncthreads();
-        if (tid == 0) { unit.effects_bypassed = all_bypassed ? 1 : 0; PG_UL(effects_bypassed) = all_bypassed ? 1 : 0; }   // (the segment loop ends in a barrier)
+        // (the chain's result counts from the next chunk on: the later pieces of this one still see the flag the chunk began with)
+        if (tid == 0 && seg_last) { unit.effects_bypassed = all_bypassed ? 1 : 0; PG_UL(effects_bypassed) = all_bypassed ? 1 : 0; }   // (the segment loop ends in a barrier)
       }
     }
-    any_audible |= audible_input;
     frame0 = frame1;
-    ++seg_idx;
     __syncthreads();
   }
 
@@ -545,15 +651,26 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     return;
   }
   if (PG_UL(kind) == UNIT_SUBMIXER) {
-    if (submixer_finish_call(unit, sig, out, call_start, N, L.sample_rate, ctl, red)) call_mask |= 1ull << call_idx;
+    const bool closes = pos0 + (uint64_t)N >= call_end_mark;
+    const bool aud = submixer_call_piece(unit, &PG_UL(call_max), sig, out, call_start, N, closes, L.sample_rate, (size_t)L.chunk_stride, (int)(L.out_stride / 2), ctl, red);
     if (tid == 0) {
-      unit.audible = (int)(call_mask & 1ull);  // the first call; later calls of the round (nested sub-mixers only) in call_audible
-      if (!FAST_ONLY) unit.call_audible = call_mask;
-      if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = call_mask != 0 ? 1 : 0;  // (mixers of the main mixer are never split by an ancestor: one call)
+      unsigned long long m = ((unsigned long long*)&PG_UL(call_audible))[0];
+      if (closes) {
+        if (aud) m |= 1ull << PG_UL(call_idx);
+        unit.call_audible = m;
+        if (PG_UL(call_idx) == 0) unit.audible = aud ? 1 : 0;  // the first call; later calls of the main chunk (nested sub-mixers only) in call_audible
+        unit.call_idx = PG_UL(call_idx) + 1;
+      }
+      // the main mixer reads one flag per chunk, in the word of the chunk's last piece (mixers of the main mixer are never split by an ancestor: one call)
+      if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = (pc.last && m != 0) ? 1 : 0;
     }
   } else {
     for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i];
-    if (tid == 0) { unit.audible = any_audible ? 1 : 0; if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = any_audible ? 1 : 0; }
+    if (tid == 0) {
+      const int any = PG_UL(chunk_any_audible) != 0 ? 1 : 0;
+      if (pc.last) unit.audible = any;
+      if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = (pc.last && any) ? 1 : 0;
+    }
   }
   PG_STAMP(L.diag, 15);
   // schedule cache: representatives replay the next block's resampler schedule (piece = this launch's length, capped)
@@ -642,9 +759,11 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
     float* blk = L.bus + (size_t)c * 2 * (size_t)N;
     for (int i = tid; i < 2 * N; i += nt) sig[i] = __builtin_nontemporal_load(blk + i);
     __syncthreads();
-    const bool audible_input = L.bus_audible ? (L.bus_audible[c] != 0) : true;
+    // (per chunk of the main mixer: the flag of its summed input sits in the word of its last piece, the processor decides at its first)
+    const PgPiece pc = pg_piece(L, c);
+    const bool audible_input = L.bus_audible ? (L.bus_audible[pc.c_last] != 0) : true;
     const bool input_bypassed = !audible_input && !active_before;
-    const bool is_active = fx_processor_process<false, KMASK>(*lfx, sig, 2 * N, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+    const bool is_active = fx_processor_process<false, KMASK>(*lfx, sig, 2 * N, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
     __syncthreads();
     if (is_active) for (int i = tid; i < 2 * N; i += nt) blk[i] = sig[i];
     any_active = (active_before || is_active) ? 1 : 0;
@@ -773,15 +892,26 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   if (!ctl[5]) return -1;
   // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
   const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
+  const int chunk_audible_input = unit.chunk_audible_input;
   for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
   __syncthreads();
+  // (staged units are sub-mixers of the main mixer without commands: their chunks are the main mixer's)
+  const PgPiece pc = pg_piece(L, chunk);
   bool audible_input = false;
+  int later = 0;
   for (int vi = 0; vi < n_voices; ++vi) {
     PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[voice_off + vi]];
-    audible_input |= voice_process<false, 0>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word);
+    const int r = voice_process<false, 0>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word, pc.chunk_end, pc.first, pc.chunk_end);
+    audible_input |= (r & 1) != 0;
+    later |= r & 2;
   }
+  // audible_input of the chunk: decided at its first piece (sources that wrote here or start in a later piece), kept for the others
+  if (pc.first) { audible_input = audible_input || later != 0; if (tid == 0) unit.chunk_audible_input = audible_input ? 1 : 0; }
+  else audible_input = chunk_audible_input != 0;
   PG_STAMP(L.diag, 1);
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
+  if (pc.first) flags |= PG_STAGE_FIRST;
+  if (pc.last) flags |= PG_STAGE_LAST;
   bool input_bypassed = !audible_input;
   if (effects_bypassed && input_bypassed) flags |= PG_STAGE_SKIPPED;  // process_effects (mixed.rs:627-655)
   else {
@@ -793,8 +923,8 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
       __syncthreads();
       bool is_active;
       constexpr int KM = TAG == 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
-      if (lfx->standalone) { fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast); is_active = true; }
-      else is_active = fx_processor_process<true, KM>(*lfx, sig, N * 2, input_bypassed, L.sample_rate, fc, L.fast, ctl, red);
+      if (lfx->standalone) { fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast, true); is_active = true; }
+      else is_active = fx_processor_process<true, KM>(*lfx, sig, N * 2, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
       if (is_active) { input_bypassed = false; all_bypassed = false; }
       __syncthreads();
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&g1)[i] = ((const uint32_t*)lfx)[i];
@@ -803,7 +933,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fxr_word;
     __syncthreads();
     PG_STAMP(L.diag, 8);
-    const bool active = lfx->standalone ? true : !fx_processor_pre(*lfx, input_bypassed, ctl);
+    const bool active = lfx->standalone ? true : !fx_processor_pre(*lfx, input_bypassed, pc.first, ctl);
     if (active) {
       flags |= PG_STAGE_ACTIVE;
       const RevLds m = rev_lds(m0.arena);
@@ -898,33 +1028,27 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       (void)rev_block_params(*lfx, m, ctl, b);
       rev_tail_impl<!RESIDENT>(lfx->u.reverb, sig, N, m, b, L.diag);
       PG_STAMP(L.diag, 60);
-      if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, L.sample_rate, ctl, red);
+      if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, (flags & PG_STAGE_LAST) != 0, L.sample_rate, ctl, red);
       PG_STAMP(L.diag, 61);
       all_bypassed = false;
       __syncthreads();
       for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
     }
     __syncthreads();
-    if (tid == 0) unit.effects_bypassed = all_bypassed ? 1 : 0;
+    if (tid == 0 && (flags & PG_STAGE_LAST)) unit.effects_bypassed = all_bypassed ? 1 : 0;  // (counts from the next chunk on)
   }
   if (!RESIDENT) lds_dma_wait();  // (bypassed / skipped reverb: the dry signal is the output)
   __syncthreads();
   PG_STAMP(L.diag, 62);
-  // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77) ----
-  float max_sample = wg_max_abs(sig, 2 * N, red);
-  if (tid == 0) {
-    int audible;
-    if (max_sample < 0.001f) {
-      unit.silence_counter += (uint64_t)N;
-      audible = unit.silence_counter < 2ull * (uint64_t)L.sample_rate ? 1 : 0;
-    } else { unit.silence_counter = 0; audible = 1; }
-    unit.audible = audible;
-    if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = audible;
-    ctl[3] = audible;
-  }
+  // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77), one call per chunk ----
+  const bool closes = (flags & PG_STAGE_LAST) != 0;
+  if (tid == 0) { ctl[8] = __float_as_int(unit.call_max); ctl[9] = (int)unit.call_frames; }
   __syncthreads();
-  if (ctl[3]) { for (int i = tid; i < 2 * N; i += nt) out[i] = sig[i]; }
-  else { for (int i = tid; i < 2 * N; i += nt) out[i] = 0.0f; }
+  const bool aud = submixer_call_piece(unit, ctl + 8, sig, out, 0, N, closes, L.sample_rate, (size_t)L.chunk_stride, (int)(L.out_stride / 2), ctl, red);
+  if (tid == 0) {
+    if (closes) { unit.audible = aud ? 1 : 0; unit.call_audible = aud ? 1ull : 0ull; }
+    if (L.audible_tab) L.audible_tab[(size_t)chunk * L.audible_stride + slot] = (closes && aud) ? 1 : 0;
+  }
   PG_STAMP(L.diag, 15);
 }
 
@@ -1142,8 +1266,8 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
 }
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes) {
   if (n_frames < PG_MIN_ROW_FRAMES) n_frames = PG_MIN_ROW_FRAMES;
-  static_assert(sizeof(PgUnit) <= 96, "pg_unit_body keeps a copy of the unit record in 96 bytes of LDS");
-  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64 + 96;
+  static_assert(sizeof(PgUnit) <= 128, "pg_unit_body keeps a copy of the unit record in 128 bytes of LDS");
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64 + 128;
   size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);

@@ -608,8 +608,11 @@ DEVO void voice_seek(PgVoice* v, double seconds) {
 // VolumeFader applied, `finished` kept. Returns frames written. `post_on` (out): the fader / gain / pan of a steady stereo voice were
 // fused into the resampler's output loop (and, with `acc`, added straight into the mixer's block): nothing is left to do for the caller.
 // GLIDE = false: the kernel variant never sees a gliding voice (the fast kernel defers such units), so the loop is left out.
+// `ask_ends`: the mixer's write call ends with these frames. A call that fills a piece of its chunk goes on in the chunk's next piece (the
+// mixer asks a source once per chunk, mixed.rs:595-600): what the reference does when a call returns — the fader's "have we arrived" test
+// (fader.rs:118-121) and with it `playback_finished` — waits for the piece the call ends in.
 template <bool GLIDE>
-DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, bool allow_post, int* post_on) {
+DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, bool allow_post, int* post_on, bool ask_ends = true) {
   *post_on = 0;
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
@@ -674,13 +677,13 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
           for (int c = 0; c < C; ++c) out[f * C + c] *= cur;
         }
         v->fader_current = cur;
-        if (fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
+        if ((ask_ends || wf < frames) && fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
       }
     }
   }
   __syncthreads();
-  if (tid == 0) {  // preloaded.rs:465-472
-    bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;
+  if (tid == 0 && (ask_ends || wf < frames)) {  // preloaded.rs:465-472, when the write call returns (at the end of the file the resampler may still
+    bool fade_out_completed = v->fader_state == 2 && v->fader_target == 0.0f;   // hold a frame or two of output for the call's next piece)
     if (v->pos_eof || fade_out_completed) v->finished = 1;
   }
   __syncthreads();
@@ -892,7 +895,7 @@ DEVO int resampled_source_write(PgVoice* v, float* out, int frames, int pending_
 // ADAPTERS: 0 = the kernel variant never sees a ResampledSource-backed or host-fed voice (the staged kernels: the host keeps such units out);
 // 1 = host-fed voices only (the four-per-CU fast kernel: a graph with a ResampledSource takes the wide kernel instead); 2 = both.
 template <bool GLIDE, int ADAPTERS>
-DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added) {
+DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const SrcScratch& S, float* acc, int* added, bool ask_ends = true) {
   *added = 0;
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
@@ -913,7 +916,7 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
     }
   } else {
     int post_on;
-    wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on);
+    wf = file_source_write<GLIDE>(v, out, frames, pending_stop, S, acc, true, &post_on, ask_ends);
     if (post_on) { *added = acc ? 1 : 0; return wf * 2; }  // (stereo samples: a fused mono voice has been mapped to both channels on the way)
   }
   __syncthreads();
@@ -958,10 +961,13 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 }
 
 // MixedSource::process_sources for ONE playing source (src/source/mixed.rs:558-624): renders into `tmp` and adds
-// into `sig`. Returns true when the source produced output.
+// into `sig`. One call of process_sources = one chunk of the mixer, rendered as pieces: `chunk_first` names the chunk's first piece,
+// `chunk_end` the position at which the chunk ends. Returns bit 0: the source produced output in this piece; bit 1 (first piece only): it
+// has not started yet but will inside this chunk — `audible_input` of the chunk (mixed.rs:696-706) is decided at the first piece.
 template <bool GLIDE, int ADAPTERS = 2>
-DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
-                        const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0, uint64_t call_end = 0) {
+DEVO int voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
+                       const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0, uint64_t call_end = 0, bool chunk_first = true,
+                       uint64_t chunk_end = 0) {
   SrcScratch S = S0;
   const int tid = pg_tid(), nt = blockDim.x;
   static_assert(sizeof(PgVoice) / 4 <= 256, "one dword per lane");
@@ -975,13 +981,23 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
   __syncthreads();
   S.sched_rd = (sched && lv->sched_class >= 0) ? sched + (size_t)lv->sched_class * 2 + sched_bank : nullptr;
   PG_STAMP(S.diag, 16);
+  // A source that broke out of its chunk's loop (nothing written, or exhausted: mixed.rs:612-620) is left alone until the mixer's next chunk
+  const bool skip = lv->chunk_skip != 0 && !chunk_first;
+  if (lv->chunk_skip != 0 && chunk_first) { __syncthreads(); if (tid == 0) { lv->chunk_skip = 0; gv->chunk_skip = 0; } __syncthreads(); }
   // (an exhausted ResampledSource-backed voice is still asked for the rest of the write in which it ran out: PgVoice::zombie_end)
-  if (!lv->active && !(ADAPTERS == 2 && pos < lv->zombie_end)) return false;
+  if (!lv->active && !(ADAPTERS == 2 && pos < lv->zombie_end)) return 0;
+  if (skip) return 0;
   const int out_len = frames * 2;
   int total_written = 0;
   if (lv->start_time > pos) {
     uint64_t fu = lv->start_time - pos;
-    if (fu >= (uint64_t)frames) return false;
+    if (fu >= (uint64_t)frames) {
+      // not in this piece — but a source that starts in a later piece of the chunk will write there (a fresh file source always has frames; a
+      // host-fed one only if its ring holds some)
+      const bool will = chunk_first && lv->start_time < chunk_end && lv->active && !lv->finished &&
+                        (!lv->stream_on || (lv->stream_fed & 0x7fffffffffffffffull) > lv->playback_pos);
+      return will ? 2 : 0;
+    }
     total_written = (int)fu * 2;
   }
   bool produced_output = false;
@@ -1002,18 +1018,23 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     uint64_t remaining = (uint64_t)(out_len - total_written);
     if (samples_until_stop < remaining) remaining = samples_until_stop;
     int to_write = (int)(remaining < 8192 ? remaining : 8192);
+    // (a call that reaches the end of this piece without reaching a stop time or the end of the chunk goes on in the next piece)
+    const bool ask_ends = pos + (uint64_t)frames >= chunk_end || samples_until_stop <= (uint64_t)(out_len - total_written);
     int added;
-    int written = voice_write<GLIDE, ADAPTERS>(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added);
+    int written = voice_write<GLIDE, ADAPTERS>(lv, tmp, to_write / 2, pending_stop, S, sig + total_written, &added, ask_ends);
     if (!added) for (int i = tid; i < written; i += nt) sig[total_written + i] = sig[total_written + i] + tmp[i];  // add_buffers
     __syncthreads();
     total_written += written;
     produced_output |= written > 0;
     // is_transient && is_exhausted (ResampledSource: the source is exhausted AND both staging buffers are empty, resampled.rs:162-164)
     const bool exhausted = lv->outer_on ? (lv->finished && lv->in_start >= lv->in_end && lv->out_start >= lv->out_end) : lv->finished != 0;
-    if (exhausted) {
-      if (tid == 0) { if (ADAPTERS == 2 && lv->active && lv->outer_on) lv->zombie_end = call_end; lv->active = 0; }
+    if (!ask_ends && written == to_write) {
+      // the call filled this piece and goes on in the chunk's next one: the mixer looks at the source (is_exhausted, written == 0) when the
+      // call returns, not here — a ResampledSource whose staging buffers happen to be empty at this frame refills them inside the same call
+    } else if (exhausted) {
+      if (tid == 0) { if (ADAPTERS == 2 && lv->active && lv->outer_on) lv->zombie_end = call_end; lv->active = 0; lv->chunk_skip = 1; }
       break;
-    } else if (written == 0) break;
+    } else if (written == 0) { if (tid == 0) lv->chunk_skip = 1; break; }
   }
   __syncthreads();
   {  // write the voice state back
@@ -1022,7 +1043,7 @@ DEVO bool voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp
     for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
   }
   __syncthreads();
-  return produced_output;
+  return produced_output ? 1 : 0;
 }
 
 // The f32 schedule recurrence of one piece (cubic.rs:72-90 with ratio < 1): identical operations to the replay in
