@@ -88,10 +88,10 @@ def pmc_traffic(name, v_per_gpu, block):
 
 
 def cpu_baseline(name, block, seconds_budget=12.0):
-    """Times the CPU oracle on a bounded sample of the same workload with all host cores (one graph per core). A short parallel
-    run calibrates the block count so that the timed sample takes about `seconds_budget` seconds on this host. The library timed
-    here is oracle/_build/libphonic_oracle_native.so (-O3 -march=native, built on this host when g++ is there), else
-    the portable -O2 build the parity tests use; the flags are reported."""
+    """Times the CPU oracle on a bounded sample of the same workload: (a) with all host cores (one graph per core), about `seconds_budget`
+    seconds, and (b) on ONE thread (one graph), about a third of that. A short run calibrates each block count on this host.
+    The library timed here is oracle/_build/libphonic_oracle_native.so (-O3 -march=native, built on this host when g++ is there),
+    else the portable -O2 build the parity tests use; the flags are reported."""
     import ctypes as C
 
     import numpy as np
@@ -100,12 +100,10 @@ def cpu_baseline(name, block, seconds_budget=12.0):
     import oracle
 
     cores = os.cpu_count() or 1
-    threads = cores
     lib, flags = oracle.lib_native()
     per_graph = {"headline": 4, "c2": 16, "c3": 8, "c4": 32, "c5": 2}[name]
-    n_graphs = threads
 
-    def run(n_blocks):
+    def run(n_blocks, n_graphs, threads):
         graphs = [oracle.OracleGraph(48000, 2, block, library=lib) for _ in range(n_graphs)]
         for i, g in enumerate(graphs):
             build_workload(g, name, per_graph, i * per_graph, per_graph * n_graphs, 0.5)
@@ -115,18 +113,23 @@ def cpu_baseline(name, block, seconds_budget=12.0):
         lib.po_graphs_render_parallel(handles, n_graphs, threads, outs.ctypes.data_as(C.POINTER(C.c_float)), block * 2, n_blocks, 0)
         return time.perf_counter() - t0
 
-    cal_blocks = 16
-    t_cal = run(cal_blocks)
-    n_blocks = int(max(cal_blocks, min(4000, seconds_budget * cal_blocks / max(t_cal, 1e-6))))
-    dt = run(n_blocks)
-    vf = n_graphs * per_graph * n_blocks * block
+    def sample(n_graphs, threads, budget):
+        cal_blocks = 16
+        t_cal = run(cal_blocks, n_graphs, threads)
+        n_blocks = int(max(cal_blocks, min(4000, budget * cal_blocks / max(t_cal, 1e-6))))
+        dt = run(n_blocks, n_graphs, threads)
+        return n_graphs * per_graph * n_blocks * block / dt, n_blocks, dt
+
+    v_all, nb_all, dt_all = sample(cores, cores, seconds_budget)
+    v_one, nb_one, dt_one = sample(1, 1, seconds_budget / 3.0)
     return {
-        "value": vf / dt,
+        "value": v_all,
         "unit": "voice-frames/s",
-        "cores": threads,
+        "cores": cores,
         "kind": "port",
         "flags": flags,
-        "sample": f"{n_graphs} oracle graphs x {per_graph} voices x {n_blocks} blocks of {block} frames, {threads} threads, {dt:.1f} s",
+        "sample": f"{cores} oracle graphs x {per_graph} voices x {nb_all} blocks of {block} frames, {cores} threads, {dt_all:.1f} s",
+        "single_thread": {"value": v_one, "cores": 1, "sample": f"1 oracle graph x {per_graph} voices x {nb_one} blocks of {block} frames, 1 thread, {dt_one:.1f} s"},
     }
 
 
@@ -189,7 +192,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --voices per GPU; strong: --total-voices split over the GPUs")
     ap.add_argument("--voices", type=int, default=0, help="weak scaling: voices PER GPU (default: the config's count)")
     ap.add_argument("--total-voices", type=int, default=0, help="strong scaling: voices of the whole job (default: c5 8192, else the config's count)")
-    ap.add_argument("--block", type=int, default=1024)
+    ap.add_argument("--block", type=int, default=1024, help="frames per step (= per write call when --superblock 1: a host's callback size)")
+    ap.add_argument("--max-frames", type=int, default=0, help="the graph's max_frames: the kernels' piece size (default: min(--block, 1024) — a write is walked in the "
+                    "reference's <= 4096-frame chunks whatever this is; the staged kernels take pieces of <= 1024 frames)")
     ap.add_argument("--superblock", type=int, default=32, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true", help="skip the second set of legs (one write call per block) behind config.realtime")
@@ -260,14 +265,15 @@ def main():
         total_voices = v_per_gpu * world
         first_voice = rank * v_per_gpu
     block = args.block
+    mf = args.max_frames or min(block, 1024)   # the kernels' piece size; a step (and a real-time call) is `block` frames
     bus_on_root = name in ("c2", "c4")  # bus effects: once, behind the sum (on the root after the reduce when there are several ranks)
     sb = max(1, args.superblock)
-    g = Graph(48000, 2, block, local_rank)
+    g = Graph(48000, 2, mf, local_rank)
     if args.exact:
         g.set_fast_math(0)
     g.set_staged(args.staged)
     g.set_timing_period(args.time_every)
-    g.set_max_blocks_per_launch(sb)
+    g.set_max_blocks_per_launch(max(1, min(64, sb * block // mf)))
     if world > 1 and bus_on_root:
         g.set_defer_bus(True)
     build_workload(g, name, v_per_gpu, first_voice, total_voices, 2.0)
@@ -291,6 +297,7 @@ def main():
     if bus_on_root:
         ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
     pos = 0
+    calls = []   # blocks per write call, as issued (reported under config.blocks_per_call)
 
     def render(n_blocks, per_call=None):
         """n_blocks consecutive blocks: super-blocks of `per_call` (default: --superblock; one ABI call each), the remainder in one smaller call."""
@@ -304,6 +311,7 @@ def main():
             if k > ring.room():
                 ring.close()                                    # (the ring's super-block ends where the call does)
             bus = ring.slots(k)
+            calls.append(k)
             w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
             if w != k * n_samples:
                 raise RuntimeError("graph write failed: " + str(w))
@@ -360,14 +368,16 @@ def main():
         for (_, ms, launches, blocks) in legs:
             if launches and ms > 0:
                 bpl = blocks / launches
-                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * block * bpl / (ms * 1e-3) / 1e9, launches))
+                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches))   # (a launch renders bpl pieces of max_frames frames)
         if not per_leg:
             return [0.0], (0.0, 0.0, 0.0, 0)
         return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
 
     render(args.warmup)
     ring.drain()
+    del calls[:]
     legs, dts = legs_for(args.min_seconds)
+    offline_calls = sorted(calls)
     # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
     # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
     rt_legs, rt_dts = (legs_for(args.min_seconds / 2, 1) if (sb > 1 and world == 1 and not args.no_realtime) else (None, None))
@@ -382,7 +392,7 @@ def main():
         dt = dts[med]
         value = total_voices * block * args.steps / dt
         ach, (ms_l, bpl_l, achieved, launches_l) = roofline_of(legs)
-        traffic, traffic_note = pmc_traffic(name, v_per_gpu, block)
+        traffic, traffic_note = pmc_traffic(name, v_per_gpu, mf)
         out = {
             "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample",
             "value": value,
@@ -403,7 +413,9 @@ def main():
                 "voices_per_gpu": v_per_gpu,
                 "total_voices": total_voices,
                 "block_frames": block,
-                "blocks_per_call": sb,
+                "max_frames": mf,
+                "blocks_per_call": offline_calls[len(offline_calls) // 2] if offline_calls else sb,   # as issued (the median call of the timed legs)
+                "blocks_per_call_requested": sb,
                 "sample_rate": 48000,
                 "master_frames_per_s": value / total_voices,
                 "x_realtime": value / total_voices / 48000.0,
@@ -427,18 +439,19 @@ def main():
                 "kernel": g.dominant_kernel(),
                 "kernel_ms": ms_l,
                 "blocks_per_launch": bpl_l,
-                "kernel_ms_per_block": ms_l / bpl_l if bpl_l else 0.0,
+                "kernel_ms_per_block": ms_l / bpl_l if bpl_l else 0.0,   # per piece of max_frames frames
+                "kernel_ms_per_step": ms_l / bpl_l * block / mf if bpl_l else 0.0,
                 "launches": launches_l,
                 "timed_every": args.time_every,
                 "bytes_per_voice_frame": B_ALG[name],
-                "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * block * bpl_l,
+                "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * mf * bpl_l,
             },
         }
         if rt_legs:
             rt_dt = rt_dts[int(np.argsort(rt_dts)[len(rt_dts) // 2])]
             rt_ach, (rt_ms, rt_bpl, rt_achieved, _) = roofline_of(rt_legs)
             out["config"]["realtime"] = {
-                "what": "one pg_graph_write_device call per 1024-frame block (src/output/wav.rs:210-250, cpal), same graph, same run",
+                "what": f"one pg_graph_write_device call per {block}-frame block (src/output/wav.rs:210-250, cpal), same graph, same run",
                 "blocks_per_call": 1,
                 "ms_per_step": rt_dt / args.steps * 1e3,
                 "value": total_voices * block * args.steps / rt_dt,

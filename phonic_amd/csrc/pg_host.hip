@@ -1016,6 +1016,8 @@ static void fill_launch(pg_graph* g, const LaunchSpan& sp, PgLaunch& L) {
   L.sched = sp.n_chunks > 1 ? nullptr : g->d_sched.d; L.sched_bank = (int)(sp.round & 1);
 }
 static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_t stream) {
+  if (li == 0 && g_fail_round_countdown.load(std::memory_order_relaxed) > 0 && g_fail_round_countdown.fetch_sub(1) == 1)   // (once per launch round)
+    return set_error(PG_ERR_DEVICE, "injected device failure (pg_debug_fail_launch_round)");
   const Level& lv = g->levels[li];
   if (lv.cnt == 0) return PG_OK;
   PgLaunch L;

@@ -87,9 +87,9 @@ def _make_plan(seed, salt=0):
 
 
 def render_plan(plan, g, split=0, events_at_call_start=False, mutations=True):
-    """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its blocks, events and chain mutations included. split: pull
-    every block in pieces of that many frames (the oracle walks a long write in chunks of its 4096-frame mix buffer, a HIP graph in chunks of
-    its max_frames: per-call logic — tails, ramps — sees different calls unless the caller pulls both in the same pieces)."""
+    """Build the plan's graph on `g` (the HIP graph or the oracle's) and render its calls, events and chain mutations included. split: pull
+    every call in pieces of that many frames (diagnostics: a HIP graph walks a long write in the reference's 4096-frame chunks whatever its
+    max_frames is, so both sides are pulled in the same calls)."""
     seed, descs, sizes, ev_block = plan["seed"], plan["descs"], plan["sizes"], plan["ev_block"]
     fx_ids, voice_ids, fx_mixer = [], [], {}
     for chain, voices in plan["mixers"]:
@@ -160,9 +160,7 @@ def test_random_graph_matches_oracle(seed):
     outs = [render_plan(plan, g), render_plan(plan, oracle.OracleGraph(SR, 2, 1024))]
     a, b = outs
     assert np.isfinite(a).all() and g.device_errors() == 0   # (no kernel met an effect state its time-parallel paths decline)
-    if float(np.abs(b).max()) <= 1e-4:   # e.g. a gate that never opens: both sides silent
-        assert float(np.abs(a).max()) <= 1e-4
-        pytest.skip("silent case")
+    assert float(np.abs(b).max()) > 1e-4   # (make_plan draws until the oracle's render is audible)
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     what = {"chains": [[(_capi.FX_NAMES[k], p) for (k, p, _) in chain] for chain, _ in plan["mixers"]], "bus": [(_capi.FX_NAMES[k], p) for (k, p, _) in plan["bus"]],
@@ -177,10 +175,10 @@ def test_random_graph_matches_oracle(seed):
 @pytest.mark.parametrize("seed", list(range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 16))) + ([] if FUZZ_SEEDS else [734]))
 def test_random_graph_superblock_writes(seed):
     """The same random graphs pulled in calls of one to four whole blocks with super-block launches enabled (pg_graph_set_max_blocks_per_launch):
-    units enter and leave the steady state (events, chain mutations, voices that end, tails, gates), and the host must fall back to single
-    blocks exactly where it has to — the render equals the block-by-block pull BIT FOR BIT. Events sit at the start of a call here: behind an
-    event inside a call the chunks are counted from the event (as MixedSource::write counts them, mixed.rs:679-712), not from the caller's
-    block grid, and per-call logic (ramps, tails) then legitimately sees other calls than a block-by-block pull would give it."""
+    units enter and leave the steady state (events anywhere inside the calls, chain mutations, voices that end, tails, gates), and the host must
+    fall back to single launches exactly where it has to — the render equals the one without super-block launches BIT FOR BIT. A call is walked in
+    the reference's chunks (<= 4096 frames from the call's start and from every main-mixer event, mixed.rs:679-712) whatever max_frames is, so the
+    oracle is pulled in the SAME calls."""
     from phonic_amd.graph import Graph
 
     plan = make_plan(seed)
@@ -188,16 +186,17 @@ def test_random_graph_superblock_writes(seed):
     plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
     g = Graph(SR, 2, 1024, 0)
     g.set_max_blocks_per_launch(4)
-    a = render_plan(plan, g, events_at_call_start=True)
-    a1 = render_plan(plan, Graph(SR, 2, 1024, 0), split=1024, events_at_call_start=True)           # the same pull, block by block
-    assert np.array_equal(a, a1), f"super-block render differs from the block-by-block one in {int(np.count_nonzero(a != a1))} samples, sizes {plan['sizes']}"
-    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024), split=1024, events_at_call_start=True)
+    a = render_plan(plan, g)
+    a1 = render_plan(plan, Graph(SR, 2, 1024, 0))           # the same calls, one launch sequence per piece
+    assert np.array_equal(a, a1), f"super-block render differs from the piece-by-piece one in {int(np.count_nonzero(a != a1))} samples, sizes {plan['sizes']}"
+    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all() and g.device_errors() == 0
-    if float(np.abs(b).max()) <= 1e-4:
-        assert float(np.abs(a).max()) <= 1e-4
-        pytest.skip("silent case")
+    assert float(np.abs(b).max()) > 1e-4
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
+    if (float(np.sqrt(np.mean(d * d))) > 1e-5 * scale or float(np.abs(d).max()) > 1e-4 * scale) and reference_is_discontinuous_here(
+            plan, lambda: oracle.OracleGraph(SR, 2, 1024), b, 1e-5 * scale, 1e-4 * scale):
+        pytest.skip("the reference is discontinuous at this input (DESIGN §2 (10))")
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale}) sizes {plan['sizes']}"
     assert float(np.abs(d).max()) <= 1e-4 * scale
 
@@ -206,25 +205,21 @@ def test_random_graph_superblock_writes(seed):
 def test_random_graph_on_three_shards(seed):
     """The same random graphs behind ONE pg_sharded_* handle with three shards (on one device here): sub-mixers and main-mixer sources are placed
     on the least loaded shard, events travel to the shard that owns their target, the partial buses meet on the root in shard order in front of
-    the bus chain. Against the oracle (the sum over shards reassociates the f32 master-bus sum: tolerance, not bit-equality)."""
+    the bus chain. Against the oracle (the sum over shards reassociates the f32 master-bus sum: tolerance, not bit-equality). Odd seeds: calls of
+    one to four blocks rendered as super-blocks, events anywhere inside them, the oracle pulled in the same calls (every shard walks a call in
+    the reference's chunks)."""
     from phonic_amd.graph import ShardedGraph
 
     plan = make_plan(seed)
     g = ShardedGraph([0, 0, 0], SR, 2, 1024)
-    if seed % 2:   # odd seeds: whole-block calls of one to four blocks rendered as super-blocks (bus decisions per block, flags OR-ed over the shards)
+    if seed % 2:   # odd seeds: whole-block calls of one to four blocks rendered as super-blocks (bus decisions per chunk, flags OR-ed over the shards)
         rng = np.random.default_rng(13000 + seed)
         plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
         g.set_max_blocks_per_launch(4)
-    # chain mutations (move_effect / remove_effect) included. Calls longer than max_frames: the device walks them in chunks of its max_frames
-    # (1024), the oracle in chunks of the reference's 4096-frame mix buffer — per-chunk logic (ramps, tails, the chorus' block-end phase
-    # bookkeeping) legitimately differs unless both are pulled in the same pieces, with events on call starts (see the super-block family)
-    multi = bool(seed % 2)
-    a = render_plan(plan, g, events_at_call_start=multi)
-    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024), split=1024 if multi else 0, events_at_call_start=multi)
+    a = render_plan(plan, g)
+    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all() and g.device_errors() == 0
-    if float(np.abs(b).max()) <= 1e-4:
-        assert float(np.abs(a).max()) <= 1e-4
-        pytest.skip("silent case")
+    assert float(np.abs(b).max()) > 1e-4
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale, f"rms {np.sqrt(np.mean(d * d))} (scale {scale})"
@@ -330,9 +325,7 @@ def test_random_nested_graph_matches_oracle(seed):
     a = render_nested_plan(plan, g)
     b = render_nested_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all() and g.device_errors() == 0
-    if float(np.abs(b).max()) <= 1e-4:
-        assert float(np.abs(a).max()) <= 1e-4
-        pytest.skip("silent case")
+    assert float(np.abs(b).max()) > 1e-4   # (make_nested_plan draws until the oracle's render is audible)
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     what = {"mixers": [(parent, [(_capi.FX_NAMES[k], p) for (k, p, _) in chain], len(voices)) for parent, chain, voices in plan["mixers"]],
@@ -506,15 +499,17 @@ def test_random_graph_other_rates_and_block_sizes(seed):
     rng = np.random.default_rng(41000 + seed)
     sr = int(rng.choice([22050, 44100, 96000]))
     mf = int(rng.choice([256, 512, 2048, 4096]))
-    plan = make_plan(seed)
-    plan["sizes"] = [int(rng.choice([mf, mf, mf // 2, max(1, mf // 3), 64, 1])) for _ in range(9)]
+    sizes = [int(rng.choice([mf, mf, mf // 2, max(1, mf // 3), 64, 1])) for _ in range(9)]
+    for salt in range(8):   # (make_plan draws until audible at 48 kHz in 1024-frame blocks; at this rate and these sizes the next plans are tried until one is)
+        plan = make_plan(seed + 100003 * salt)
+        plan["sizes"] = sizes
+        b = render_plan(plan, oracle.OracleGraph(sr, 2, mf))
+        if float(np.abs(b).max()) > 1e-3:
+            break
     g = Graph(sr, 2, mf, 0)
     a = render_plan(plan, g)
-    b = render_plan(plan, oracle.OracleGraph(sr, 2, mf))
     assert np.isfinite(a).all() and g.device_errors() == 0
-    if float(np.abs(b).max()) <= 1e-4:
-        assert float(np.abs(a).max()) <= 1e-4
-        pytest.skip("silent case")
+    assert float(np.abs(b).max()) > 1e-4
     d = a.astype(np.float64) - b.astype(np.float64)
     scale = max(1.0, float(np.abs(b).max()))
     what = {"sr": sr, "max_frames": mf, "sizes": plan["sizes"], "chains": [[_capi.FX_NAMES[k] for (k, _, _) in chain] for chain, _ in plan["mixers"]], "bus": [_capi.FX_NAMES[k] for (k, _, _) in plan["bus"]]}
@@ -700,3 +695,64 @@ def test_random_graph_on_the_exact_serial_kernels(seed):
         d = a.astype(np.float64) - b.astype(np.float64)
         scale = max(1.0, float(np.abs(b).max()))
         assert float(np.sqrt(np.mean(d * d))) <= 1e-5 * scale and float(np.abs(d).max()) <= 1e-4 * scale, (make.__name__, float(np.sqrt(np.mean(d * d))))
+
+
+# Call lengths of the long-call family: below, at and above max_frames and the reference's 4096-frame chunk, not multiples of either
+LONG_CALLS = [1024, 2048, 3072, 4096, 5000, 700, 2500, 8192, 6144, 333, 4097, 1, 9000, 1500]
+
+
+def _long_call_render(family, seed):
+    """(render(graph) -> samples, call sizes, tolerance (rms, max-abs) relative to the oracle's peak) of a family's plan pulled in long calls."""
+    import copy
+
+    rng = np.random.default_rng(77000 + seed)
+    if family == "flat":
+        plan = make_plan(seed)
+        plan["sizes"] = [int(rng.choice(LONG_CALLS)) for _ in range(9)]
+        return (lambda g: render_plan(copy.deepcopy(plan), g)), plan["sizes"], (1e-5, 1e-4)
+    if family == "nested":
+        plan = make_nested_plan(seed)
+        plan["sizes"] = [int(rng.choice(LONG_CALLS)) for _ in range(len(plan["sizes"]))]
+        return (lambda g: render_nested_plan(copy.deepcopy(plan), g)), plan["sizes"], (1e-5, 1e-4)
+    if family == "voices":
+        plan = make_voice_plan(seed)
+        old_total = sum(plan["sizes"])
+        plan["sizes"] = [int(rng.choice(LONG_CALLS)) for _ in range(len(plan["sizes"]))]
+        stretch = sum(plan["sizes"]) / max(1, old_total)
+        plan["actions"] = [(ab, kind, vi, x, int(t * stretch)) for (ab, kind, vi, x, t) in plan["actions"]]
+        return (lambda g: render_voice_plan(copy.deepcopy(plan), g)), plan["sizes"], (1e-6, 1e-5)
+    plan = make_topology_plan(seed)
+    plan["steps"] = [(int(rng.choice(LONG_CALLS)), acts) for (_, acts) in plan["steps"]]
+    return (lambda g: render_topology_plan(copy.deepcopy(plan), g)), [n for n, _ in plan["steps"]], (1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("family", ["flat", "nested", "voices", "topology"])
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 10)))
+def test_random_graphs_in_long_calls(family, seed):
+    """MixedSource::write walks a call in chunks of min(remaining, 4096) frames from the call's start and from every event (mixed.rs:216,679-712);
+    sources, effect processors and sub-mixers are called once per chunk and take their per-call decisions there (bypass and tail counters,
+    silence gates, the chorus' call-end phase bookkeeping, the fader's arrival test, is_exhausted). The graph keeps that grid whatever its
+    max_frames is: a chunk is rendered as pieces of at most max_frames frames. Calls of 1 to 9000 frames with events anywhere, the four plan
+    families:  (1) on the exact serial kernels max_frames 1024 / 256 / 1000 equal max_frames 4096 — one piece per chunk — BIT FOR BIT;
+    (2) on the time-parallel kernels super-block launches equal single launches bit for bit;  (3) every configuration agrees with the oracle
+    pulled in the SAME calls."""
+    from phonic_amd.graph import Graph
+
+    render, sizes, (tol_rms, tol_max) = _long_call_render(family, seed)
+    ref = render(oracle.OracleGraph(SR, 2, 1024))
+    scale = 1.0 if family == "voices" else max(1.0, float(np.abs(ref).max()))
+    outs = {}
+    for key, mf, fast, blocks in (("s4096", 4096, 0, 1), ("s1024", 1024, 0, 1), ("s256", 256, 0, 1), ("s1000", 1000, 0, 1),
+                                  ("f1024", 1024, 1, 1), ("f1024x8", 1024, 1, 8), ("f512x16", 512, 1, 16)):
+        g = Graph(SR, 2, mf, 0)
+        if not fast:
+            g.set_fast_math(0)
+        if blocks > 1:
+            g.set_max_blocks_per_launch(blocks)
+        outs[key] = render(g)
+        assert np.isfinite(outs[key]).all() and g.device_errors() == 0, key
+        d = outs[key].astype(np.float64) - ref.astype(np.float64)
+        assert float(np.sqrt(np.mean(d * d))) <= tol_rms * scale and float(np.abs(d).max()) <= tol_max * scale, (key, sizes, float(np.sqrt(np.mean(d * d))), float(np.abs(d).max()))
+    for key in ("s1024", "s256", "s1000"):
+        assert np.array_equal(outs[key], outs["s4096"]), (key, sizes, int(np.flatnonzero(outs[key] != outs["s4096"])[0]) // 2)
+    assert np.array_equal(outs["f1024x8"], outs["f1024"]), (sizes, int(np.flatnonzero(outs["f1024x8"] != outs["f1024"])[0]) // 2)

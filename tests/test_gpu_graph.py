@@ -991,11 +991,7 @@ def test_superblock_launch_with_a_bus_chain_is_bit_identical_to_single_blocks(bu
             if c == 1:
                 g.schedule_param(ids[0], "thrs" if bus == "limiter" else "gan4", -9.0, pos + 2 * N)      # inside the call, on a block boundary
             o = np.zeros(per_call * 2 * N, np.float32)
-            if mode == "oracle":     # the oracle walks a long call in chunks of the reference's 4096-frame mix buffer, the device in chunks of its max_frames:
-                for k in range(per_call):   # pulled block by block both count the same chunks (events sit on block boundaries)
-                    assert g.write(o[k * 2 * N:(k + 1) * 2 * N], pos + k * N) in (0, 2 * N)
-            else:
-                assert g.write(o, pos) in (0, o.size)
+            assert g.write(o, pos) in (0, o.size)     # (oracle and device in the same calls: both walk them in the reference's 4096-frame chunks)
             chunks.append(o)
             pos += per_call * N
         outs.append(np.concatenate(chunks))
@@ -1297,12 +1293,8 @@ def test_sharded_superblock_write_takes_the_bus_decisions_per_block(n_shards):
             g.set_max_blocks_per_launch(per_call)
         build(g)
         o = np.zeros((calls, per_call * 2 * N), np.float32)
-        for c in range(calls):
-            if mode == "sharded":
-                assert g.write(o[c], c * per_call * N) == o[c].size
-            else:   # (the oracle's chunk is the reference's 4096-frame mix buffer, the device's its max_frames: pulled per block they agree on the chunks)
-                for k in range(per_call):
-                    assert g.write(o[c][k * 2 * N:(k + 1) * 2 * N], (c * per_call + k) * N) == 2 * N
+        for c in range(calls):   # (oracle and device in the same calls: both walk them in the reference's 4096-frame chunks)
+            assert g.write(o[c], c * per_call * N) == o[c].size
         outs.append(o.reshape(-1))
         if mode == "sharded":
             assert g.device_errors() == 0
