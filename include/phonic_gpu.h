@@ -175,7 +175,11 @@ typedef struct pg_voice_options {
                               preloaded.rs:71-117); 0 = the graph's rate (what Player passes). When it differs, ConvertedSource puts a cubic
                               ResampledSource — 512-frame input / output staging, src/source/resampled.rs:44-152 — between the file source
                               and the channel mapping (src/source/converted.rs:15-45), exactly as for any source whose rate is not the mixer's */
-  uint32_t reserved;
+  uint32_t non_transient;  /* 0 (default) = PlayingSource::is_transient (src/source/mixed.rs:34-42,117-123): the mixer drops the source when it is exhausted
+                              (mixed.rs:612-616,715) and RemoveAllPendingEvents takes it when it has not started yet (:298-305). 1 = a source the
+                              mixer keeps: exhausted, it stays in the list (asked once per chunk, delivering nothing), stop_all_voices does not take it,
+                              write never returns 0 for want of sources — until pg_graph_remove_voice. (In the reference: generators; here: a host-fed
+                              source the host wants to keep across pauses of its stream.) */
 } pg_voice_options;
 
 void pg_voice_options_default(pg_voice_options* opt);
@@ -232,6 +236,11 @@ int pg_graph_feed_voice(pg_graph* g, int voice_id, const float* frames, size_t n
 int pg_graph_end_stream_voice(pg_graph* g, int voice_id);
 /* Frames of the stream the device has read so far (waits for the graph's work; negative on failure): frees that much ring for feeds. */
 int64_t pg_graph_stream_voice_consumed(pg_graph* g, int voice_id);
+
+/* MixerMessage::RemoveSource (src/source/mixed.rs:149-151,400-402): the source leaves its mixer at the start of the next write, at once — no
+ * fade-out (stop_voice is the call that fades) — whether transient or not, started or not; events already scheduled for it find no source and
+ * are dropped when they come due. Any thread. Later calls with this id return PG_ERR_NOT_FOUND. */
+int pg_graph_remove_voice(pg_graph* g, int voice_id);
 
 /* EffectHandle::set_parameter((id, update), sample_time) (src/player/handles/effect.rs:67-95) */
 int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized,
@@ -355,6 +364,7 @@ int pg_sharded_set_voice_speed(pg_sharded_graph* s, int voice_id, double speed, 
 int pg_sharded_seek_voice(pg_sharded_graph* s, int voice_id, double position_seconds, uint64_t sample_time);
 int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_time);
 int pg_sharded_stop_all_voices(pg_sharded_graph* s);
+int pg_sharded_remove_voice(pg_sharded_graph* s, int voice_id);
 int pg_sharded_is_voice_playing(pg_sharded_graph* s, int voice_id);
 /* Source::write: host buffer (waits for the result) / buffer on the root device (asynchronous on the shards' streams, several calls may be
  * enqueued before pg_sharded_synchronize; at most max_blocks x max_frames frames per call). Both return the samples written, or 0 when

@@ -58,6 +58,7 @@ struct po_graph {
   std::map<int, MixedSource*> mixers;            // id -> mixer (0 = main)
   std::map<int, MixedSource*> effect_mixer;      // effect id -> owning mixer
   std::map<int, MixedSource*> voice_mixer;       // voice id -> owning mixer
+  std::map<int, bool> voice_transient;           // voice id -> PlayingSource::is_transient
   std::map<int, int> mixer_parent;               // mixer id -> parent mixer id
   int next_mixer = 1, next_effect = 0, next_voice = 0;
   uint32_t sample_rate;
@@ -169,7 +170,8 @@ int po_graph_add_voice(po_graph* g, int mixer_id, const float* pcm, size_t n_fra
   std::unique_ptr<MixedSource::PlayingSource> ps(new MixedSource::PlayingSource());
   int id = g->next_voice++;
   ps->playback_id = id;
-  ps->is_transient = true;
+  ps->is_transient = opt->non_transient == 0;   // PlayingSource::is_transient (mixed.rs:34-42): a source the mixer keeps when it is exhausted
+  g->voice_transient[id] = ps->is_transient;
   ps->queues.file = file; ps->queues.amplified = amp; ps->queues.panned = pan;
   ps->source.reset(pan);
   ps->start_time = opt->start_time;
@@ -189,6 +191,7 @@ static int push_event(MixedSource* mx, const MixedSource::MixerEvent& ev) {
 }
 int po_graph_stop_all_voices(po_graph* g) {  // Player::stop_all_sources (src/player.rs:1012-1045)
   for (auto& kv : g->voice_mixer) {  // send_stop() to every transient source: it stops when it is asked for output next
+    if (!g->voice_transient[kv.first]) continue;
     MixedSource::Message m;
     m.kind = MixedSource::Message::StopSource;
     m.id = kv.first; m.sample_time = 0;
@@ -270,6 +273,15 @@ int po_graph_set_voice_panning(po_graph* g, int voice, float v, uint64_t sample_
   MixedSource::MixerEvent ev;
   ev.kind = MixedSource::MixerEvent::SetSourcePanning; ev.id = voice; ev.sample_time = sample_time; ev.f = v;
   return push_event(it->second, ev);
+}
+int po_graph_remove_voice(po_graph* g, int voice) {  // MixerMessage::RemoveSource (mixed.rs:149-151,400-402)
+  auto it = g->voice_mixer.find(voice);
+  if (it == g->voice_mixer.end()) return PG_ERR_NOT_FOUND;
+  MixedSource::Message m;
+  m.kind = MixedSource::Message::RemoveSource; m.id = voice;
+  it->second->message_queue.push_back(std::move(m));
+  g->voice_mixer.erase(it);   // (Player::remove_generator drops the handle's entry: later calls with this id fail)
+  return PG_OK;
 }
 int po_graph_stop_voice(po_graph* g, int voice, uint64_t sample_time) {
   auto it = g->voice_mixer.find(voice);

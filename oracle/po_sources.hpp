@@ -451,8 +451,8 @@ struct MixedSource : Source {
     q.swap(message_queue);
     for (auto& m : q) {
       switch (m.kind) {
-        case Message::RemoveAllPendingEvents: {  // :298-305 (every played file source is transient)
-          for (size_t i = 0; i < playing_sources.size();) { if (playing_sources[i]->start_time > pos_in_frames) playing_sources.erase(playing_sources.begin() + i); else ++i; }
+        case Message::RemoveAllPendingEvents: {  // :298-305
+          for (size_t i = 0; i < playing_sources.size();) { if (playing_sources[i]->is_transient && playing_sources[i]->start_time > pos_in_frames) playing_sources.erase(playing_sources.begin() + i); else ++i; }
           for (size_t i = 0; i < events.size();) { if (events[i].sample_time > pos_in_frames) events.erase(events.begin() + i); else ++i; }
         } break;
         case Message::AddSource: {

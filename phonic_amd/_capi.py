@@ -54,7 +54,7 @@ class VoiceOptions(C.Structure):
         ("fade_in_seconds", C.c_float),
         ("fade_out_seconds", C.c_float),
         ("source_rate", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("non_transient", C.c_uint32),
     ]
 
 
@@ -103,7 +103,7 @@ def default_voice_options(**kw):
     o.loop_start = o.loop_end = 0
     o.start_time = 0
     o.fade_in_seconds, o.fade_out_seconds = 0.0, 0.05
-    o.source_rate, o.reserved = 0, 0
+    o.source_rate, o.non_transient = 0, 0
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)
@@ -138,6 +138,7 @@ def declare(lib, prefix):
         "graph_set_voice_volume": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_set_voice_panning": (C.c_int, [vp, C.c_int, C.c_float, C.c_uint64]),
         "graph_stop_voice": (C.c_int, [vp, C.c_int, C.c_uint64]),
+        "graph_remove_voice": (C.c_int, [vp, C.c_int]),
         "graph_set_voice_speed": (C.c_int, [vp, C.c_int, C.c_double, C.c_float, C.c_uint64]),
         "graph_seek_voice": (C.c_int, [vp, C.c_int, C.c_double, C.c_uint64]),
         "graph_write": (C.c_size_t, [vp, P(C.c_float), C.c_size_t, C.c_uint64]),
@@ -281,7 +282,7 @@ def load():
                        ("set_voice_speed", [C.c_int, C.c_double, C.c_float, C.c_uint64]), ("seek_voice", [C.c_int, C.c_double, C.c_uint64]),
                        ("remove_mixer", [C.c_int]), ("remove_effect", [C.c_int]), ("move_effect", [C.c_int, C.c_int, C.c_int, C.c_int]),
                        ("set_reduce", [C.c_int]), ("reduce_mode", []), ("is_voice_playing", [C.c_int]),
-                       ("stop_voice", [C.c_int, C.c_uint64]), ("stop_all_voices", []), ("synchronize", []), ("device_errors", [])):
+                       ("stop_voice", [C.c_int, C.c_uint64]), ("remove_voice", [C.c_int]), ("stop_all_voices", []), ("synchronize", []), ("device_errors", [])):
         fn = getattr(lib, "pg_sharded_" + name)
         fn.restype = C.c_int
         fn.argtypes = [vp] + args

@@ -171,6 +171,10 @@ class GraphHandle:
     def stop_voice(self, voice, sample_time):
         self._check(self._fn("graph_stop_voice")(self._h, voice, sample_time))
 
+    def remove_voice(self, voice):
+        """MixerMessage::RemoveSource: the source leaves its mixer at the start of the next write, at once (no fade)."""
+        self._check(self._fn("graph_remove_voice")(self._h, voice))
+
     def set_voice_speed(self, voice, speed, sample_time, glide=None):
         """FilePlaybackHandle::set_speed(speed, glide): glide in semitones per second, None = immediate."""
         self._check(self._fn("graph_set_voice_speed")(self._h, voice, float(speed), float(glide) if glide else 0.0, sample_time))

@@ -25,6 +25,7 @@ enum CtrlType : int32_t {
   CT_VOICE_SEEK = 5,    // dvalue = position in seconds                                          (SeekSource)
   CT_VOICE_STOP = 6,    // sample_time = stop time (0: now); a message, not an event             (StopSource)
   CT_STOP_ALL = 7,      // Player::stop_all_sources: stop every source + RemoveAllPendingEvents
+  CT_VOICE_REMOVE = 8,  // id = voice id                                                         (RemoveSource)
 };
 
 struct CtrlMsg {

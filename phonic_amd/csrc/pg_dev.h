@@ -206,7 +206,8 @@ struct PgVoice {
   uint64_t zombie_end;
   // process_sources leaves a source alone for the rest of a chunk once a write returned nothing (`written == 0` -> break 'source,
   // mixed.rs:617-620): set when that happens in a piece, cleared at the first piece of the mixer's next chunk
-  int32_t chunk_skip, pad_skip;
+  int32_t chunk_skip;
+  int32_t persistent;  // host: !PlayingSource::is_transient — an exhausted source stays in the mixer's list (mixed.rs:612-620)
 };
 
 // Parameter indices per effect kind = order of `Effect::parameters()` in the reference.

@@ -378,7 +378,7 @@ int pg_graph_add_effect(pg_graph* g, int mixer_id, int kind, const pg_effect_ini
 static void drain_control_messages(pg_graph* g);
 static void stop_all_voices_now(pg_graph* g) {
   for (size_t v = 0; v < g->voices.size(); ++v) {
-    if (g->voices[v].mixer < 0) continue;
+    if (g->voices[v].mixer < 0 || !g->voices[v].transient) continue;   // (stop_all_sources stops the transient sources, player.rs:1013-1031)
     PgCmd c;
     memset(&c, 0, sizeof c);
     c.type = CMD_VOICE_STOP; c.target = g->voices[v].dev_index; c.value64 = 0; c.param = (int)v;
@@ -402,7 +402,7 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
     mx.remove_pending = false;
     for (size_t i = 0; i < mx.voices.size();) {
       const int v = mx.voices[i];
-      if ((size_t)v < mx.remove_voice_limit && g->voices[v].start_time > pos) {
+      if ((size_t)v < mx.remove_voice_limit && g->voices[v].transient && g->voices[v].start_time > pos) {   // (source.is_transient && source.start_time > time.pos_in_frames, mixed.rs:300-302)
         mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [v](const PgCmd& c) { return c.param == v; }), mx.messages.end());
         g->voices[v].mixer = -1;
         g->voice_alive_tab.set((size_t)v, 0);
@@ -534,6 +534,7 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
   v.start_time = opt->start_time;
   v.active = 1;
+  v.persistent = opt->non_transient != 0;
   v.current_speed = opt->speed; v.target_speed = opt->speed; v.speed_glide_rate = 0.0f; v.samples_to_next_speed_update = 0;
   {  // resampler schedule cache class: voices sharing the f32 ratio; the first one publishes
     uint32_t rb;
@@ -565,7 +566,8 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
   int rc = g->d_voices.push(v, &dev_index);
   if (rc) return -graph_fail(g, rc);
   int id = (int)g->voices.size();
-  { HostVoice hv; hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_pcm; hv.d_stage = d_stage; hv.outer = inner_rate != g->sample_rate; g->voices.push_back(hv); }
+  { HostVoice hv; hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_pcm; hv.d_stage = d_stage; hv.outer = inner_rate != g->sample_rate;
+    hv.transient = opt->non_transient == 0; g->voices.push_back(hv); }
   g->source_unit_of_voice.push_back(-1);
   // AddSource: sort by start time, insert BEFORE equal start times (mixed.rs:324-329)
   HostMixer& mx = g->mixers[mixer_id];
@@ -620,6 +622,7 @@ int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint
   v.panning = make_smooth(exp_spec, opt->panning, g->sample_rate);
   v.start_time = opt->start_time;
   v.active = 1;
+  v.persistent = opt->non_transient != 0;
   v.current_speed = 1.0; v.target_speed = 1.0;
   v.sched_class = -1;
   void* d_stage = nullptr;
@@ -638,6 +641,7 @@ int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint
   HostVoice hv;
   hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_ring; hv.d_stage = d_stage; hv.outer = rate != g->sample_rate;
   hv.stream = true; hv.h_ring = h_ring; hv.channels = channels; hv.cap_frames = capacity_frames;
+  hv.transient = opt->non_transient == 0;
   g->voices.push_back(hv);
   g->stream_voices.push_back(id);
   g->source_unit_of_voice.push_back(-1);
@@ -652,13 +656,14 @@ int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint
     g->main_active_voices += 1;
     g->ever_had_main_voice = true;
   }
-  if (!g->voice_alive_tab.append(1)) return -set_error(PG_ERR_STATE, "too many voices");
+  if (!g->voice_alive_tab.append(2)) return -set_error(PG_ERR_STATE, "too many voices");   // (2: alive and host-fed — no seek, no speed)
   g->topo_dirty = true;
   if (graph_reserve(g)) return -graph_fail(g, PG_ERR_DEVICE);
   return id;
 }
 static HostVoice* stream_voice(pg_graph* g, int voice_id) {
   if (voice_id < 0 || voice_id >= (int)g->voices.size() || !g->voices[voice_id].stream) { set_error(PG_ERR_NOT_FOUND, "Source with id %d is not a host-fed source", voice_id); return nullptr; }
+  if (g->voices[voice_id].mixer < 0) { set_error(PG_ERR_NOT_FOUND, "Source with id %d is gone (its mixer was removed)", voice_id); return nullptr; }   // (nobody would ever drain its ring)
   return &g->voices[voice_id];
 }
 // The next `n_frames` frames of the host's source (interleaved, the voice's channel count) -> the pinned staging ring; they travel to the
@@ -707,6 +712,9 @@ static int fx_kind_of(pg_graph* g, int effect_id) {  // -1: unknown or removed
   return (int)g->fx_kind_tab.get((size_t)effect_id);
 }
 static bool voice_alive(pg_graph* g, int voice_id) { return voice_id >= 0 && (size_t)voice_id < g->voice_alive_tab.size() && g->voice_alive_tab.get((size_t)voice_id) != 0; }
+// Seek and speed exist on FilePlaybackHandle only (src/player/handles/file.rs): a host-fed source (the host's own `dyn Source` behind a ring) has
+// neither a position to seek to nor a resampler to re-target — the device would rewind the ring's read position over stale frames.
+static bool voice_is_host_fed(pg_graph* g, int voice_id) { return voice_id >= 0 && (size_t)voice_id < g->voice_alive_tab.size() && g->voice_alive_tab.get((size_t)voice_id) == 2; }
 
 int pg_graph_schedule_param(pg_graph* g, int effect_id, uint32_t fourcc, float value, int is_normalized, uint64_t sample_time) {
   const int kind = fx_kind_of(g, effect_id);
@@ -741,14 +749,19 @@ int pg_graph_set_voice_volume(pg_graph* g, int voice_id, float volume, uint64_t 
 int pg_graph_set_voice_panning(pg_graph* g, int voice_id, float panning, uint64_t sample_time) { return voice_message(g, voice_id, pgc::CT_VOICE_PAN, panning, 0.0, sample_time); }
 int pg_graph_set_voice_speed(pg_graph* g, int voice_id, double speed, float glide, uint64_t sample_time) {
   if (!(speed > 0.0)) return set_error(PG_ERR_PARAMETER, "speed must be > 0");
+  if (voice_is_host_fed(g, voice_id)) return set_error(PG_ERR_PARAMETER, "Source with id %d is host-fed: it takes volume, panning and stop only", voice_id);
   return voice_message(g, voice_id, pgc::CT_VOICE_SPEED, glide, speed, sample_time);
 }
 int pg_graph_seek_voice(pg_graph* g, int voice_id, double position_seconds, uint64_t sample_time) {
   if (!(position_seconds >= 0.0)) return set_error(PG_ERR_PARAMETER, "seek position must be >= 0");
+  if (voice_is_host_fed(g, voice_id)) return set_error(PG_ERR_PARAMETER, "Source with id %d is host-fed: it takes volume, panning and stop only", voice_id);
   return voice_message(g, voice_id, pgc::CT_VOICE_SEEK, 0.0f, position_seconds, sample_time);
 }
 int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // MixerMessage::StopSource (mixed.rs:389-400): not an event
   return voice_message(g, voice_id, pgc::CT_VOICE_STOP, 0.0f, 0.0, sample_time);
+}
+int pg_graph_remove_voice(pg_graph* g, int voice_id) {  // MixerMessage::RemoveSource (mixed.rs:149-151,400-402)
+  return voice_message(g, voice_id, pgc::CT_VOICE_REMOVE, 0.0f, 0.0, 0);
 }
 
 static void push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
@@ -794,6 +807,24 @@ static void drain_control_messages(pg_graph* g) {
         if (m.id < 0 || m.id >= (int)g->voices.size() || g->voices[m.id].mixer < 0) break;
         const HostVoice& hv = g->voices[m.id];
         c.target = hv.dev_index; c.param = m.id;
+        if (m.type == pgc::CT_VOICE_REMOVE) {  // remove_matching_sources(|s| s.playback_id == playback_id): gone before this write renders anything
+          HostMixer& mx = g->mixers[hv.mixer];
+          mx.voices.erase(std::remove(mx.voices.begin(), mx.voices.end(), m.id), mx.voices.end());
+          mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [&](const PgCmd& x) { return x.param == m.id; }), mx.messages.end());
+          // events already queued for the source stay the mixer's events: when they come due they find no source (mixed.rs:810-845) but still
+          // split the block there — like the events of a removed effect
+          for (Event& e : mx.events) if ((e.cmd.type == CMD_VOICE_VOLUME || e.cmd.type == CMD_VOICE_PAN || e.cmd.type == CMD_VOICE_SPEED || e.cmd.type == CMD_VOICE_SEEK) && e.cmd.param == m.id) {
+            e.cmd.type = CMD_NOP; e.cmd.target = 0;
+            if (hv.mixer == 0) e.cmd.param = -1;
+          }
+          // (the count of live main-mixer sources comes from the device after a synchronous write; a source the mixer keeps is live by
+          // definition — a transient one may have ended already: its removal shows with the next count)
+          if (hv.mixer == 0 && !hv.transient && g->main_active_voices > 0) g->main_active_voices -= 1;
+          g->voices[m.id].mixer = -1;
+          g->voice_alive_tab.set((size_t)m.id, 0);
+          g->topo_dirty = true;
+          break;
+        }
         if (m.type == pgc::CT_VOICE_STOP) { c.type = CMD_VOICE_STOP; c.value64 = m.sample_time; g->mixers[hv.mixer].messages.push_back(c); break; }
         if (m.type == pgc::CT_VOICE_VOLUME) { c.type = CMD_VOICE_VOLUME; c.value = m.value; }
         else if (m.type == pgc::CT_VOICE_PAN) { c.type = CMD_VOICE_PAN; c.value = m.value; }

@@ -185,6 +185,7 @@ struct Event {  // MixerEvent (src/source/mixed.rs:47-109) resolved to a device 
 struct HostVoice {
   int mixer; int dev_index; uint64_t start_time; void* d_pcm; void* d_stage; bool outer;
   // host-fed source (pg_graph_add_stream_voice): pinned ring + word the feeds are staged in, device ring = d_pcm
+  bool transient = true;           // PlayingSource::is_transient (pg_voice_options::non_transient == 0)
   bool stream = false, ended = false, ended_sent = false;
   float* h_ring = nullptr;         // pinned: [cap_frames * channels] floats
   uint32_t channels = 0;

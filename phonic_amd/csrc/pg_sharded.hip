@@ -325,6 +325,10 @@ int pg_sharded_stop_voice(pg_sharded_graph* s, int voice_id, uint64_t sample_tim
   SHARDED_VOICE(s, voice_id, pk);
   return pg_graph_stop_voice(s->shards[shard_of(pk)], local_of(pk), sample_time);
 }
+int pg_sharded_remove_voice(pg_sharded_graph* s, int voice_id) {
+  SHARDED_VOICE(s, voice_id, pk);
+  return pg_graph_remove_voice(s->shards[shard_of(pk)], local_of(pk));
+}
 int pg_sharded_stop_all_voices(pg_sharded_graph* s) {
   for (pg_graph* g : s->shards) { int rc = pg_graph_stop_all_voices(g); if (rc) return rc; }
   return PG_OK;

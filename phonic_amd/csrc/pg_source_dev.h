@@ -589,7 +589,7 @@ DEVO void voice_update_speed(PgVoice* v) {
 }
 // PreloadedFileSource::set_speed  preloaded.rs:181-192 (lane 0)
 DEVO void voice_set_speed(PgVoice* v, double speed, float glide) {
-  if (v->finished) return;
+  if (v->finished || v->stream_on) return;  // (a host-fed source has no resampler of its own; the host refuses the call)
   v->samples_to_next_speed_update = 0;
   v->target_speed = speed;
   v->speed_glide_rate = glide > 0.0f ? glide : 0.0f;
@@ -597,7 +597,7 @@ DEVO void voice_set_speed(PgVoice* v, double speed, float glide) {
 }
 // PreloadedFileSource::seek  preloaded.rs:139-147 (lane 0)
 DEVO void voice_seek(PgVoice* v, double seconds) {
-  if (v->finished) return;
+  if (v->finished || v->stream_on) return;  // (playback_pos of a host-fed source counts the ring frames read)
   const double buffer_pos = seconds * (double)v->src_rate * (double)v->channels;
   uint64_t p = d2u64(buffer_pos);
   v->playback_pos = p < v->n_samples ? p : v->n_samples;
@@ -1031,7 +1031,7 @@ DEVO int voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp,
     if (!ask_ends && written == to_write) {
       // the call filled this piece and goes on in the chunk's next one: the mixer looks at the source (is_exhausted, written == 0) when the
       // call returns, not here — a ResampledSource whose staging buffers happen to be empty at this frame refills them inside the same call
-    } else if (exhausted) {
+    } else if (exhausted && !lv->persistent) {
       if (tid == 0) { if (ADAPTERS == 2 && lv->active && lv->outer_on) lv->zombie_end = call_end; lv->active = 0; lv->chunk_skip = 1; }
       break;
     } else if (written == 0) { if (tid == 0) lv->chunk_skip = 1; break; }

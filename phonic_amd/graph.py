@@ -175,6 +175,9 @@ class ShardedGraph:
     def stop_voice(self, voice, sample_time):
         self._check(self._lib.pg_sharded_stop_voice(self._h, voice, sample_time))
 
+    def remove_voice(self, voice):
+        self._check(self._lib.pg_sharded_remove_voice(self._h, voice))
+
     def set_voice_speed(self, voice, speed, sample_time, glide=None):
         self._check(self._lib.pg_sharded_set_voice_speed(self._h, voice, float(speed), float(glide) if glide else 0.0, sample_time))
 

@@ -386,9 +386,9 @@ class EffectProc:  # src/source/mixed/effect.rs
         return True
 
 
-class Playing:
-    def __init__(self, pid, chain, start):
-        self.pid, self.src, self.start, self.stop, self.active = pid, chain["panned"], start, None, True
+class Playing:  # PlayingSource (mixed.rs:34-42)
+    def __init__(self, pid, chain, start, transient=True):
+        self.pid, self.src, self.start, self.stop, self.active, self.transient = pid, chain["panned"], start, None, True, transient
         self.file, self.amp, self.panned = chain["file"], chain["amp"], chain["panned"]
 
 
@@ -396,6 +396,7 @@ class Mixer:  # MixedSource (stereo)
     def __init__(self, sr):
         self.sr, self.sources, self.mixers, self.effects, self.events = sr, [], [], [], []
         self.effects_bypassed = True
+        self.messages = []
         self.mix = np.zeros(MAX_MIX_BUFFER_SAMPLES, F)
 
     # Player side (messages are applied at the top of the next write: here directly, the scenarios call these between writes)
@@ -461,7 +462,7 @@ class Mixer:  # MixedSource (stereo)
                     out[total + i] = F(out[total + i] + self.mix[i])
                 total += w
                 produced = produced or w > 0
-                if s.src.is_exhausted():
+                if s.transient and s.src.is_exhausted():
                     s.active = False
                     break
                 elif w == 0:
@@ -478,7 +479,21 @@ class Mixer:  # MixedSource (stereo)
                 all_bypassed = False
         self.effects_bypassed = all_bypassed
 
+    def remove_all_pending(self, pos):  # MixerMessage::RemoveAllPendingEvents (mixed.rs:298-305), at the top of the write at `pos`
+        self.sources = [s for s in self.sources if not (s.transient and s.start > pos)]
+        self.events = [e for e in self.events if not e[0] > pos]
+
     def write(self, out, pos):  # mixed.rs:659-719
+        for msg in self.messages:  # process_messages (mixed.rs:294-499): what the scenario sent since the last write, in order
+            if msg[0] == "remove_all_pending":
+                self.remove_all_pending(pos)
+            elif msg[0] == "remove":  # RemoveSource (mixed.rs:400-402)
+                self.sources = [s for s in self.sources if s.pid != msg[1]]
+            else:  # StopSource (mixed.rs:389-400)
+                for s in self.sources:
+                    if s.pid == msg[1]:
+                        s.stop = msg[2]
+        self.messages = []
         if not self.sources and not self.effects and not self.mixers and not self.events:
             return 0
         out[:] = F(0.0)
@@ -498,7 +513,7 @@ class Mixer:  # MixedSource (stereo)
                 audible = self.process_sources(chunk, pos + done) or audible
                 self.process_effects(chunk, not audible)
                 done += n
-        self.sources = [s for s in self.sources if s.active]
+        self.sources = [s for s in self.sources if not (s.transient and not s.active)]
         return len(out)
 
 
@@ -614,6 +629,20 @@ SCENARIOS["resampled_source"] = {
                dict(mixer=0, tone=(8, 5000, 0.25, 1), volume=0.5, panning=-0.5, start=1000, repeat=0, source_rate=11025)],
     "actions": {},
 }
+SCENARIOS["non_transient"] = {
+    # PlayingSource::is_transient = false (mixed.rs:34-42; generators in the reference, any source the host wants to keep): voice 0 is a one-shot
+    # the mixer keeps after it has ended (asked once per chunk, delivers nothing, write keeps returning the block), voice 1 a kept source that has
+    # not started when Player::stop_all_sources comes (RemoveAllPendingEvents takes the transient voice 2 that has not started either, stops
+    # the transient voice 3 with its fade-out — and leaves 0 and 1 alone); RemoveSource then takes voice 1 in mid-flight, at once, and voice 0;
+    # the run's last writes find nothing left and return 0
+    "blocks": [256] * 30,
+    "mixers": [],
+    "voices": [dict(mixer=0, tone=(2, 8000, 0.1, 2), volume=0.6, panning=-0.2, start=0, repeat=0, transient=False),
+               dict(mixer=0, tone=(3, 7350, 0.5, 2), volume=0.5, panning=0.3, start=2000, repeat=USIZE_MAX, transient=False),
+               dict(mixer=0, tone=(4, 8000, 0.2, 1), volume=0.7, panning=0.0, start=2300, repeat=0),
+               dict(mixer=0, tone=(5, 8000, 0.6, 2), volume=0.4, panning=0.5, start=100, repeat=USIZE_MAX)],
+    "actions": {6: [("stop_all", None, None, None)], 16: [("remove", 1, None, None)], 20: [("remove", 0, None, None)]},
+}
 FX = {"gain": (RF.Gain, gain_tail, 0), "filter": (RF.Filter, filter_tail, 2), "delay": (RF.Delay, delay_tail, 4)}  # class, tail, pg_effect_kind
 
 
@@ -641,15 +670,21 @@ def run_scenario(sc):
         conv = Resampled(f, src_rate, SR) if src_rate != SR else f   # ConvertedSource (converted.rs:24-42): resample first, then map the channels
         amp = Amplified(Mapped(conv), v["volume"], SR)
         chain = {"file": f, "amp": amp, "panned": Panned(amp, v["panning"], SR)}
-        target[v["mixer"]].add_source(Playing(vi, chain, v["start"]))
+        target[v["mixer"]].add_source(Playing(vi, chain, v["start"], v.get("transient", True)))
         voices.append(v["mixer"])
     outs, pos = [], 0
     for b, n in enumerate(sc["blocks"]):
         for kind, who, val, t in sc["actions"].get(b, []):
             if kind == "stop":  # MixerMessage::StopSource: a message, applied at the top of the write
-                for s in target[voices[who]].sources:
-                    if s.pid == who:
-                        s.stop = t
+                target[voices[who]].messages.append(("stop", who, t))
+            elif kind == "remove":  # MixerMessage::RemoveSource
+                target[voices[who]].messages.append(("remove", who))
+            elif kind == "stop_all":  # Player::stop_all_sources (player.rs:1012-1045): send_stop to every transient source, RemoveAllPendingEvents to every mixer
+                for vi2, v2 in enumerate(sc["voices"]):
+                    if v2.get("transient", True):
+                        target[voices[vi2]].messages.append(("stop", vi2, 0))
+                for m in target:
+                    m.messages.append(("remove_all_pending",))
             elif kind == "param":
                 fx_of[who].insert_event((t, "param", who, val[0], val[1]))
             elif kind in ("speed", "seek"):
@@ -657,7 +692,9 @@ def run_scenario(sc):
             else:
                 target[voices[who]].insert_event((t, kind, who, val, None))
         o = np.zeros(2 * n, F)
-        main.write(o, pos)
+        w = main.write(o, pos)
+        if "returns" in sc:
+            sc["returns"].append(w)
         outs.append(o)
         pos += n
     return np.concatenate(outs)

@@ -23,7 +23,7 @@ class RawInit(C.Structure):  # pg_effect_init, include/phonic_gpu.h
 class RawVoice(C.Structure):  # pg_voice_options
     _fields_ = [("volume", C.c_float), ("panning", C.c_float), ("speed", C.c_double), ("repeat", C.c_uint64), ("has_repeat", C.c_uint32),
                 ("has_loop_range", C.c_uint32), ("loop_start", C.c_uint64), ("loop_end", C.c_uint64), ("start_time", C.c_uint64),
-                ("fade_in_seconds", C.c_float), ("fade_out_seconds", C.c_float), ("source_rate", C.c_uint32), ("reserved", C.c_uint32)]
+                ("fade_in_seconds", C.c_float), ("fade_out_seconds", C.c_float), ("source_rate", C.c_uint32), ("non_transient", C.c_uint32)]
 
 
 def cc(s):
@@ -91,10 +91,10 @@ def test_oracle_through_an_independent_binding_equals_the_shared_wrapper():
         ini.fourcc[i], ini.value[i] = cc(k), v
     dl2 = raw.po_graph_add_effect(h, m2, 4, C.byref(ini))
     o = RawVoice(volume=0.7, panning=-0.35, speed=1.1, repeat=3, has_repeat=1, has_loop_range=1, loop_start=200, loop_end=6000, start_time=333,
-                 fade_in_seconds=0.02, fade_out_seconds=0.03, source_rate=0, reserved=0)
+                 fade_in_seconds=0.02, fade_out_seconds=0.03, source_rate=0, non_transient=0)
     va2 = raw.po_graph_add_voice(h, m2, pcm_a.ctypes.data_as(f32p), pcm_a.size // 2, 2, 44100, C.byref(o))
     o = RawVoice(volume=0.4, panning=0.8, speed=1.0, repeat=2**64 - 1, has_repeat=1, has_loop_range=0, loop_start=0, loop_end=0, start_time=0,
-                 fade_in_seconds=0.0, fade_out_seconds=0.05, source_rate=24000, reserved=0)
+                 fade_in_seconds=0.0, fade_out_seconds=0.05, source_rate=24000, non_transient=0)
     vb2 = raw.po_graph_add_voice(h, 0, pcm_b.ctypes.data_as(f32p), pcm_b.size, 1, 32000, C.byref(o))
     assert (m2, rv2, dl2, va2, vb2) == (m, rv, dl, va, vb)
     got = np.zeros((blocks, 2 * N), np.float32)

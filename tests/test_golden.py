@@ -139,7 +139,7 @@ import numpy_restatement_graph as rgr  # noqa: E402
 IND_GR = np.load(os.path.join(HERE, "golden", "independent_graph.npz"))
 
 
-def _oracle_scenario(sc, g=None):
+def _oracle_scenario(sc, g=None, returns=None):
     """The scenario of numpy_restatement_graph.py on the C++ oracle's graph (or the graph given), through the API every graph test uses."""
     from phonic_amd import _capi
 
@@ -161,6 +161,8 @@ def _oracle_scenario(sc, g=None):
         loop = dict(has_loop_range=1, loop_start=v["loop"][0], loop_end=v["loop"][1]) if v.get("loop") else {}
         if v.get("source_rate"):
             loop["source_rate"] = v["source_rate"]
+        if not v.get("transient", True):
+            loop["non_transient"] = 1
         voices.append(g.add_voice(mixers[v["mixer"]], rgr.tone(i, rate, seconds, nch), nch, rate, volume=v["volume"], panning=v["panning"], start_time=v["start"],
                                   has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER if rep == rgr.USIZE_MAX else rep, **loop))
     outs, pos = [], 0
@@ -168,6 +170,10 @@ def _oracle_scenario(sc, g=None):
         for kind, who, val, t in sc["actions"].get(b, []):
             if kind == "stop":
                 g.stop_voice(voices[who], t)
+            elif kind == "remove":
+                g.remove_voice(voices[who])
+            elif kind == "stop_all":
+                g.stop_all_voices()
             elif kind == "volume":
                 g.set_voice_volume(voices[who], val, t)
             elif kind == "panning":
@@ -181,6 +187,8 @@ def _oracle_scenario(sc, g=None):
         o = np.zeros(2 * n, np.float32)
         w = g.write(o, pos)
         assert w in (0, 2 * n)
+        if returns is not None:
+            returns.append(w)
         outs.append(o)
         pos += n
     return np.concatenate(outs)
@@ -221,3 +229,35 @@ def test_gpu_graph_matches_independent_restatement(name):
     close(got, want)
     if name == "submixer_bypass":   # behind every gate of the long scenario both sides are exactly silent
         assert not np.any(got[2 * 23000:]) and not np.any(want[2 * 23000:])
+
+
+def test_non_transient_sources_write_returns():
+    """What MixedSource::write returns over the non-transient scenario (mixed.rs:664-670): the block's length for as long as the mixer holds a
+    source — also an exhausted one it keeps — and 0 once RemoveSource has taken the last: oracle and restatement agree call for call."""
+    import copy
+
+    sc = copy.deepcopy(rgr.SCENARIOS["non_transient"])
+    sc["returns"] = []
+    rgr.run_scenario(sc)
+    got = []
+    _oracle_scenario(rgr.SCENARIOS["non_transient"], returns=got)
+    assert got == sc["returns"]
+    assert got[:20] == [512] * 20 and got[20:] == [0] * 10     # voice 0 ended after 800 frames and was kept until block 20
+
+
+@pytest.mark.gpu
+def test_gpu_non_transient_sources_and_remove_voice():
+    """pg_voice_options::non_transient + pg_graph_remove_voice (MixerMessage::AddSource{is_transient: false} / RemoveSource, mixed.rs:117-123,
+    149-151,298-305,400-402,612-616,715) on the HIP graph and through the sharded handle: against the restatement's vectors, and the returns of
+    write call for call (a kept source keeps the mixer alive; once the last is removed write returns 0)."""
+    from phonic_amd.graph import Graph, ShardedGraph
+
+    want = IND_GR["non_transient"]
+    for g in (Graph(rgr.SR, 2, 512, 0), ShardedGraph([0, 0], rgr.SR, 2, 512)):
+        rets = []
+        got = _oracle_scenario(rgr.SCENARIOS["non_transient"], g, returns=rets)
+        close(got, want)
+        assert rets[:20] == [512] * 20 and rets[21:] == [0] * 9, rets
+        import phonic_amd
+        with pytest.raises(phonic_amd.PhonicError):
+            g.remove_voice(0)       # gone: PG_ERR_NOT_FOUND

@@ -168,6 +168,38 @@ def test_stream_voice_underrun_ring_full_stop_and_end():
     assert ei.value.code == _capi.PG_ERR_NOT_FOUND
 
 
+def test_seek_and_speed_are_refused_for_host_fed_voices():
+    """seek and speed exist on FilePlaybackHandle only (the reference's synth / streamed sources have neither): a host-fed voice refuses both
+    with a parameter error — on the plain graph and through the sharded handle — and plays on undisturbed (the device once rewound the
+    ring's read position over stale frames, and `consumed` went backwards); a mixer that is removed takes its fed voice's ring with it."""
+    import phonic_amd
+    from phonic_amd.graph import ShardedGraph
+
+    tone = pcm_for(5, SR, 0.2, 2)[:-2]
+    for g in (graph(), ShardedGraph([0, 0], SR, 2, 1024)):
+        v = g.add_stream_voice(0, 2, SR, 4096)
+        out = np.zeros(2048, np.float32)
+        g.feed_voice(v, tone[:2 * 2048])
+        assert g.write(out, 0) == 2048 and np.array_equal(out, tone[:2048])
+        for call in (lambda: g.seek_voice(v, 0.0, 1024), lambda: g.set_voice_speed(v, 2.0, 1024), lambda: g.set_voice_speed(v, 0.5, 1024, glide=12.0)):
+            with pytest.raises(phonic_amd.PhonicError) as ei:
+                call()
+            assert ei.value.code == _capi.PG_ERR_PARAMETER
+        assert g.write(out, 1024) == 2048 and np.array_equal(out, tone[2048:4096])     # ... and carries on where it was
+        assert g.stream_voice_consumed(v) == 2048
+        g.set_voice_volume(v, 0.5, 2048)                                                # (what the handle of any source takes)
+        g.feed_voice(v, tone[2 * 2048:2 * 3072])
+        assert g.write(out, 2048) == 2048 and np.abs(out).max() > 1e-3
+    g = graph()
+    m = g.add_mixer()
+    v = g.add_stream_voice(m, 2, SR, 2048)
+    g.feed_voice(v, tone[:2 * 512])
+    g.remove_mixer(m)
+    with pytest.raises(phonic_amd.PhonicError) as ei:
+        g.feed_voice(v, tone[:2 * 512])
+    assert ei.value.code == _capi.PG_ERR_NOT_FOUND
+
+
 def test_fed_voices_in_super_block_launches_equal_single_block_launches():
     """Host-fed voices are rendered by the fast kernels in steady state (the ring read is a copy), so a write of several blocks takes them through
     one super-block launch: the result must equal block-by-block launches bit for bit — voices that end inside the call, one that underruns
