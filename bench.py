@@ -340,7 +340,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ms, launches, blocks = g.kernel_stats(reset=True)
-        return dt, ms, launches, blocks
+        bus = g.bus_kernel_stats(reset=True)
+        return dt, ms, launches, blocks, bus
 
     def legs_for(seconds, per_call=None):
         """Timed legs of exactly --steps blocks until `seconds` of wall time are covered (at least 5, at most 2001; --repeats overrides):
@@ -365,7 +366,7 @@ def main():
         """Dominant kernel: algorithmic bytes of one launch / its average duration, per leg; a launch renders `blocks_per_launch` blocks of this
         rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches))."""
         per_leg = []
-        for (_, ms, launches, blocks) in legs:
+        for (_, ms, launches, blocks, _bus) in legs:
             if launches and ms > 0:
                 bpl = blocks / launches
                 per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches))   # (a launch renders bpl pieces of max_frames frames)
@@ -447,6 +448,24 @@ def main():
                 "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * mf * bpl_l,
             },
         }
+        # Which launch dominates by GPU time? Graphs whose work sits behind the sum (BASELINE configs 2 and 4) spend it in the main mixer's chain:
+        # one workgroup per effect, a latency chain — the line then names that launch, bound "latency", with its time per block
+        unit_ms = sum(l[1] * l[2] for l in legs)
+        bus_ms = sum(l[4][0] * l[4][1] for l in legs)
+        bus_blocks = sum(l[4][2] for l in legs)
+        if bus_ms > unit_ms and bus_blocks:
+            per_block_ms = bus_ms / bus_blocks
+            achieved_bus = B_ALG[name] * v_per_gpu * mf / (per_block_ms * 1e-3) / 1e9
+            out["roofline"].update({
+                "bound": "latency", "kernel": g.bus_kernel(), "achieved": achieved_bus, "frac": achieved_bus / HBM_PEAK_GBS,
+                "kernel_ms": bus_ms / max(1, sum(l[4][1] for l in legs)), "blocks_per_launch": bus_blocks / max(1, sum(l[4][1] for l in legs)),
+                "kernel_ms_per_block": per_block_ms, "kernel_ms_per_step": per_block_ms * block / mf, "launches": sum(l[4][1] for l in legs),
+                "latency_chain_us_per_block": per_block_ms * 1e3, "shader_cycles_per_block_at_2.4GHz": per_block_ms * 1e-3 * 2.4e9,
+                "unit_kernels": {"kernel": g.dominant_kernel(), "ms_per_block": (unit_ms / max(1, sum(l[3] for l in legs))), "share_of_timed_gpu_ms": unit_ms / (unit_ms + bus_ms)},
+                "note": "the launch that dominates by GPU time is the main mixer's effect chain behind the sum: a chain of per-frame recurrences on one workgroup per effect — "
+                        "bounded by that workgroup's latency chain, not by HBM (frac = the workload's algorithmic bytes over THIS launch's time, for the record)"})
+            for k in ("frac_min", "frac_max", "traffic", "algorithmic_bytes_per_launch"):
+                out["roofline"].pop(k, None)
         if rt_legs:
             rt_dt = rt_dts[int(np.argsort(rt_dts)[len(rt_dts) // 2])]
             rt_ach, (rt_ms, rt_bpl, rt_achieved, _) = roofline_of(rt_legs)

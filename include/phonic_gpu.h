@@ -389,6 +389,10 @@ double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches);
 /* The same measurement as sums: total device time (ms) of the timed launches, their count, and the number of max_frames blocks they
  * rendered (a super-block launch renders several blocks per unit). Waits for the timed launches (also on a caller's stream). */
 int pg_graph_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* launches, uint64_t* blocks);
+/* The same for the launches of the main mixer's effect chain (one workgroup per effect behind the sum: a latency chain — for graphs whose
+ * work is mostly on the bus, BASELINE configs 2 and 4, it is the launch that dominates by GPU time), and its name. */
+int pg_graph_bus_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* launches, uint64_t* blocks);
+const char* pg_graph_bus_kernel(pg_graph* g);
 /* The hipEvent pair behind pg_graph_kernel_ms costs ~8 us of stream time per round: time every n-th round only (default 1 = every
  * round, 0 = never). pg_graph_kernel_ms then averages over the timed rounds and reports their count. */
 int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds);

@@ -269,6 +269,10 @@ def load():
     lib.pg_graph_kernel_ms.argtypes = [vp, C.c_int, P(C.c_uint64)]
     lib.pg_graph_kernel_stats.restype = C.c_int
     lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
+    lib.pg_graph_bus_kernel_stats.restype = C.c_int
+    lib.pg_graph_bus_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
+    lib.pg_graph_bus_kernel.restype = C.c_char_p
+    lib.pg_graph_bus_kernel.argtypes = [vp]
     lib.pg_graph_set_max_blocks_per_launch.restype = C.c_int
     lib.pg_graph_set_max_blocks_per_launch.argtypes = [vp, C.c_int]
     lib.pg_sharded_create.restype = vp

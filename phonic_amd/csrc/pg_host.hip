@@ -330,6 +330,7 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->h_pinned) (void)pg_host_free(g->h_pinned);
   if (g->h_feedback) (void)pg_host_free(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : g->ev_bus_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -901,6 +902,13 @@ int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) {
     g->ev_pool.emplace_back(a, b);
     g->ev_blocks.push_back(1);
   }
+  while (g->timing_period > 0 && g->ev_bus_pool.size() < 512) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g->ev_bus_pool.emplace_back(a, b);
+    g->ev_bus_blocks.push_back(1);
+  }
   return PG_OK;
 }
 int pg_graph_set_staged(pg_graph* g, int mode) { g->staged_mode = (mode < 0 || mode > 2) ? 1 : mode; g->last_change_round = g->launch_counter; return PG_OK; }
@@ -946,6 +954,30 @@ int pg_graph_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* la
   if (blocks) *blocks = n_blocks;
   if (reset) g->ev_used = 0;
   return PG_OK;
+}
+// The same for the launches of the main mixer's bus chain (timed in the rounds whose unit launches are timed).
+int pg_graph_bus_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* launches, uint64_t* blocks) {
+  (void)hipSetDevice(g->device);
+  double total = 0.0;
+  uint64_t n_ok = 0, n_blocks = 0;
+  for (size_t i = 0; i < g->ev_bus_used; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g->ev_bus_pool[i].second) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, g->ev_bus_pool[i].first, g->ev_bus_pool[i].second) != hipSuccess) continue;
+    total += ms; n_ok += 1; n_blocks += g->ev_bus_blocks[i];
+  }
+  if (total_ms) *total_ms = total;
+  if (launches) *launches = n_ok;
+  if (blocks) *blocks = n_blocks;
+  if (reset) g->ev_bus_used = 0;
+  return PG_OK;
+}
+// Name of the bus launch as the last write issued it ("" when the main mixer has no effects)
+const char* pg_graph_bus_kernel(pg_graph* g) {
+  const size_t n_fx = g->mixers[0].fx.size();
+  if (n_fx == 0) return "";
+  return (n_fx >= 2 && n_fx <= PG_BUS_PIPELINE_MAX && g->bus_pipeline && g->max_blocks > 1) ? "pg_unit_kernel (main mixer's chain: one workgroup per effect, pipelined over the blocks)"
+                                                                                           : "pg_unit_kernel (main mixer's chain: one workgroup)";
 }
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
   double total = 0.0;
@@ -1177,7 +1209,9 @@ static int launch_bus(pg_graph* g, float* d_dst, LaunchSpan sp, int audible_slot
     B.bus = dst; B.bus_audible = g->d_audible + slot; B.audible_tab = nullptr;
     B.sched = nullptr;
     bus_pipeline_setup(g, B);
-    HIP_TRY(pg_launch_units(B, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (q.timed && g->ev_bus_used < g->ev_bus_pool.size()) { e0 = g->ev_bus_pool[g->ev_bus_used].first; e1 = g->ev_bus_pool[g->ev_bus_used].second; g->ev_bus_blocks[g->ev_bus_used] = (uint32_t)q.n_chunks; g->ev_bus_used++; }
+    HIP_TRY(pg_launch_units(B, stream, e0, e1));
     return PG_OK;
   };
   if (sp.n_cmds > 0 && sp.n_chunks > 1) {
@@ -1413,13 +1447,16 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     }
     if (!g->defer_bus && !g->mixers[0].fx.empty()) {
       // the bus unit's commands of the chunk's first piece (main-mixer effect events) ride on its bus launch
+      const bool bus_timed = g->timing_period > 0 && ((spans[0].round + 1) % (uint64_t)g->timing_period) == 0;
       if (n_full > 0) {
         LaunchSpan b = spans[0];
+        b.timed = bus_timed;
         b.n_chunks = (int)n_full;
         if (launch_bus(g, dst, b, slot0, stream)) return fail();
       }
       if (n_pieces > n_full) {
         LaunchSpan b = spans[(size_t)n_full];
+        b.timed = bus_timed;
         if (n_full > 0) { b.d_cmds = nullptr; b.n_cmds = 0; }
         if (launch_bus(g, dst + n_full * mf * 2, b, slot0 + (int)n_full, stream)) return fail();
       }

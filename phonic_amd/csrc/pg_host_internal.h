@@ -299,6 +299,11 @@ struct pg_graph {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<uint32_t> ev_blocks;  // max_frames blocks the timed launch rendered (super-block launches: several)
   size_t ev_used = 0;
+  // ... and of the main mixer's bus chain (one workgroup per effect: a latency chain — for graphs like BASELINE configs 2 and 4 it is the
+  // launch that dominates by GPU time, pg_graph_bus_kernel_stats)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_bus_pool;
+  std::vector<uint32_t> ev_bus_blocks;
+  size_t ev_bus_used = 0;
 };
 
 // ---- graph internals used by the sharded handle (pg_host.hip) -------------------------------------------------

@@ -83,6 +83,15 @@ class Graph(GraphHandle):
         self._check(self._lib.pg_graph_kernel_stats(self._h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(b)))
         return (ms.value / n.value if n.value else 0.0), n.value, b.value
 
+    def bus_kernel_stats(self, reset=True):
+        """The same for the launches of the main mixer's effect chain: (average ms per timed bus launch, timed launches, blocks they walked)."""
+        ms, n, b = C.c_double(0.0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.pg_graph_bus_kernel_stats(self._h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(b)))
+        return (ms.value / n.value if n.value else 0.0), n.value, b.value
+
+    def bus_kernel(self):
+        return self._lib.pg_graph_bus_kernel(self._h).decode()
+
     def set_timing_period(self, every_n_rounds):
         """Time every n-th round with a hipEvent pair (the pair costs ~8 us of stream time); 0 = never."""
         self._check(self._lib.pg_graph_set_timing_period(self._h, int(every_n_rounds)))

@@ -48,7 +48,8 @@ k = "pg_stage_fused_kernel"
 f, w = per_block("FETCH_SIZE", k), per_block("WRITE_SIZE", k)
 d = {"workload": "headline", "voices_per_gpu": 1024, "block_frames": 1024, "kernel": k, "source_hash": _capi.source_hash(),
      "FETCH_SIZE_KiB_per_block": f, "WRITE_SIZE_KiB_per_block": w,
-     "correction": "gfx950: FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM/rocprofv3 section): read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE exact",
+     "correction": "gfx950: FETCH_SIZE reports half of the bytes read (MI355X_MICROARCH.md, HBM/rocprofv3 section, calibrated there for 16-byte lanes): read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE exact",
+     "calibration": "the same factors hold for THIS kernel's access pattern (8-byte lanes, 128-frame sub-chunks, 2 KB granules): tools/ringstream with a known byte count reads FETCH_SIZE x 1.94-2.17 (the spread = whether the vibrato look-ahead of up to 15 frames per window is counted as read twice) and WRITE_SIZE x 0.98-0.99 (partial lines at window edges) - profiles/r04_ringstream_pmc.json",
      "traffic_bytes_per_block": (2 * f + w) * 1024 if f and w else None,
      "algorithmic_bytes_per_block": 423.4 * 1024 * 1024,
      "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --no-realtime (one pass per counter; per block = the 16-block dispatches / 16)"}
