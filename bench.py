@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
     ap.add_argument("--time-every", type=int, default=1, help="hipEvent-time the dominant kernel every n-th launch round (the event pair costs ~8 us of stream time: once per super-block by default)")
     ap.add_argument("--reduce-every", type=int, default=0, help="multi-GPU: blocks per RCCL master-bus reduce (default: the super-block; 1 = per block, the real-time setting)")
+    ap.add_argument("--strong-c5-voices", type=int, default=8192, help="voices of the BASELINE config 5 leg reported under config.strong_c5 (split over the GPUs; 0 = skip it)")
     ap.add_argument("--staged", type=int, default=1, help="reverb sub-mixers: 1 = staged kernel (default), 2 = one launch per stage, 0 = fused fast kernel")
     args = ap.parse_args()
 
@@ -256,138 +257,160 @@ def main():
     from phonic_amd.graph import Graph
     from phonic_amd.parallel import MasterBusRing, reduce_master_bus, shard_range
 
-    name = args.workload
-    if args.scaling == "strong":
-        total_voices = args.total_voices or (8192 if name == "c5" else DEFAULT_VOICES[name])
-        first_voice, v_per_gpu = shard_range(total_voices, rank, world)
-    else:
-        v_per_gpu = args.voices or DEFAULT_VOICES[name]
-        total_voices = v_per_gpu * world
-        first_voice = rank * v_per_gpu
     block = args.block
     mf = args.max_frames or min(block, 1024)   # the kernels' piece size; a step (and a real-time call) is `block` frames
-    bus_on_root = name in ("c2", "c4")  # bus effects: once, behind the sum (on the root after the reduce when there are several ranks)
     sb = max(1, args.superblock)
-    g = Graph(48000, 2, mf, local_rank)
-    if args.exact:
-        g.set_fast_math(0)
-    g.set_staged(args.staged)
-    g.set_timing_period(args.time_every)
-    g.set_max_blocks_per_launch(max(1, min(64, sb * block // mf)))
-    if world > 1 and bus_on_root:
-        g.set_defer_bus(True)
-    build_workload(g, name, v_per_gpu, first_voice, total_voices, 2.0)
-
-    n_samples = block * 2
-    # Master-bus buffers: a ring of N_BUS super-blocks of M blocks each. Offline rendering (the reference's WavOutput pull loop,
-    # src/output/wav.rs:210-250) has no deadline per block, so M consecutive blocks are rendered by ONE pg_graph_write_device call
-    # (the reference's MixedSource::write loops over its <= 4096-frame chunks the same way, src/source/mixed.rs:679-712) and their
-    # partial buses travel in ONE RCCL reduce (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own
-    # stream, ordered after the renders by an event) overlaps the renders of the following ones, and the render stream only waits
-    # when a buffer comes round again. --superblock 1 is the real-time setting (one call and one reduce per block).
-    M = sb if bus_on_root else max(sb, args.reduce_every or sb)  # (c2 / c4: reduce and bus chain once per call, see render)
-    M = (M + sb - 1) // sb * sb  # a reduce covers whole super-blocks
-    # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
-    # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
-    render_stream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(render_stream)
-    stream = render_stream.cuda_stream
-    ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0, force_distributed=force_dist)
-    if bus_on_root:
-        ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
-    pos = 0
-    calls = []   # blocks per write call, as issued (reported under config.blocks_per_call)
-
-    def render(n_blocks, per_call=None):
-        """n_blocks consecutive blocks: super-blocks of `per_call` (default: --superblock; one ABI call each), the remainder in one smaller call."""
-        nonlocal pos
-        done = 0
-        per_call = per_call or sb
-        while done < n_blocks:
-            left = n_blocks - done
-            parts = (left + per_call - 1) // per_call          # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
-            k = min((left + parts - 1) // parts, ring.m)       # every launch pays about one block time of ramp-up and drain
-            if k > ring.room():
-                ring.close()                                    # (the ring's super-block ends where the call does)
-            bus = ring.slots(k)
-            calls.append(k)
-            w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
-            if w != k * n_samples:
-                raise RuntimeError("graph write failed: " + str(w))
-            if world > 1 and bus_on_root:
-                reduce_master_bus(bus, root=0)
-                if rank == 0:
-                    g.process_bus_device(bus.data_ptr(), k * n_samples, pos, stream)
-            ring.submit(k)
-            pos += k * block
-            done += k
-
     dist_on = world > 1 or force_dist  # (a forced one-rank group goes through the same barriers and reductions)
 
-    def leg(n_blocks, per_call=None):
+    def measure(name, scaling, voices_arg, total_voices_arg, min_seconds, with_realtime):
+        """Builds the workload's graph on this rank, renders warm-up and timed legs; returns what the result line is made of."""
+        if scaling == "strong":
+            total_voices = total_voices_arg or (8192 if name == "c5" else DEFAULT_VOICES[name])
+            first_voice, v_per_gpu = shard_range(total_voices, rank, world)
+        else:
+            v_per_gpu = voices_arg or DEFAULT_VOICES[name]
+            total_voices = v_per_gpu * world
+            first_voice = rank * v_per_gpu
+        bus_on_root = name in ("c2", "c4")  # bus effects: once, behind the sum (on the root after the reduce when there are several ranks)
+        g = Graph(48000, 2, mf, local_rank)
+        if args.exact:
+            g.set_fast_math(0)
+        g.set_staged(args.staged)
+        g.set_timing_period(args.time_every)
+        g.set_max_blocks_per_launch(max(1, min(64, sb * block // mf)))
+        if world > 1 and bus_on_root:
+            g.set_defer_bus(True)
+        build_workload(g, name, v_per_gpu, first_voice, total_voices, 2.0)
+
+        n_samples = block * 2
+        # Master-bus buffers: a ring of N_BUS super-blocks of M blocks each. Offline rendering (the reference's WavOutput pull loop,
+        # src/output/wav.rs:210-250) has no deadline per block, so M consecutive blocks are rendered by ONE pg_graph_write_device call
+        # (the reference's MixedSource::write loops over its <= 4096-frame chunks the same way, src/source/mixed.rs:679-712) and their
+        # partial buses travel in ONE RCCL reduce (M x 8 KiB; SURVEY §8e "per super-block"): the reduce of super-block s (RCCL's own
+        # stream, ordered after the renders by an event) overlaps the renders of the following ones, and the render stream only waits
+        # when a buffer comes round again. --superblock 1 is the real-time setting (one call and one reduce per block).
+        M = sb if bus_on_root else max(sb, args.reduce_every or sb)  # (c2 / c4: reduce and bus chain once per call, see render)
+        M = (M + sb - 1) // sb * sb  # a reduce covers whole super-blocks
+        # a real (non-default) stream: pg_graph_write_device is asynchronous only on a caller's stream — the default stream's handle is
+        # NULL, which the ABI reads as "the graph's own stream, synchronous" (include/phonic_gpu.h). torch and RCCL ops order after it.
+        render_stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.synchronize()
-        g.kernel_ms(reset=True)
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        render(n_blocks, per_call)
+        torch.cuda.set_stream(render_stream)
+        stream = render_stream.cuda_stream
+        words_max = max(1, sb * block // mf)   # `audible` words of the largest call: one per piece of max_frames
+        ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0, force_distributed=force_dist, extra=words_max if bus_on_root else 0)
+        if bus_on_root:
+            ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
+        pos = 0
+        calls = []   # blocks per write call, as issued (reported under config.blocks_per_call)
+
+        def render(n_blocks, per_call=None):
+            """n_blocks consecutive blocks: super-blocks of `per_call` (default: --superblock; one ABI call each), the remainder in one smaller call."""
+            nonlocal pos
+            done = 0
+            per_call = per_call or sb
+            while done < n_blocks:
+                left = n_blocks - done
+                parts = (left + per_call - 1) // per_call          # equal super-blocks (100 blocks at 32 per call: 4 x 25, not 32 + 32 + 32 + 4):
+                k = min((left + parts - 1) // parts, ring.m)       # every launch pays about one block time of ramp-up and drain
+                if k > ring.room():
+                    ring.close()                                    # (the ring's super-block ends where the call does)
+                nw = (k * block + mf - 1) // mf if (world > 1 and bus_on_root) else 0
+                bus = ring.slots(k, extra=nw)
+                calls.append(k)
+                w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
+                if w != k * n_samples:
+                    raise RuntimeError("graph write failed: " + str(w))
+                if world > 1 and bus_on_root:
+                    # the ranks' `audible` words ride behind the samples: ONE sum-reduce carries both, and the root's chain bypasses itself over
+                    # silence as the one main mixer does (EffectProcessor's decisions per chunk, src/source/mixed/effect.rs:56-145)
+                    g.export_audible(bus.data_ptr() + 4 * k * n_samples, nw, stream)
+                    reduce_master_bus(bus, root=0)
+                    if rank == 0:
+                        g.process_bus_device(bus.data_ptr(), k * n_samples, pos, stream, flags_ptr=bus.data_ptr() + 4 * k * n_samples, n_words=nw)
+                ring.submit(k)
+                pos += k * block
+                done += k
+
+        def leg(n_blocks, per_call=None):
+            torch.cuda.synchronize()
+            g.kernel_ms(reset=True)
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            render(n_blocks, per_call)
+            ring.drain()
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ms, launches, blocks = g.kernel_stats(reset=True)
+            bus = g.bus_kernel_stats(reset=True)
+            return dt, ms, launches, blocks, bus
+
+        def legs_for(seconds, per_call=None):
+            """Timed legs of exactly --steps blocks until `seconds` of wall time are covered (at least 5, at most 2001; --repeats overrides):
+            a 20-step leg lasts 2 ms, single legs scatter with the clock state of the box. Returns (legs, per-leg seconds, MAX over ranks)."""
+            first = leg(args.steps, per_call)
+            d0 = first[0]
+            if dist_on:
+                t = torch.tensor([d0], dtype=torch.float64, device=f"cuda:{local_rank}")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank runs the same number of legs
+                d0 = float(t.item())
+            n = args.repeats if args.repeats > 0 else max(5, min(2001, int(1.2 * seconds / max(d0, 1e-6)) | 1))   # (+20 %: the first leg runs slower than the rest)
+            legs = [first] + [leg(args.steps, per_call) for _ in range(n - 1)]
+            dts = [l[0] for l in legs]
+            if dist_on:
+                t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts = [float(x) for x in t.tolist()]
+            torch.cuda.synchronize()
+            return legs, dts
+
+        def roofline_of(legs):
+            """Dominant kernel: algorithmic bytes of one launch / its average duration, per leg; a launch renders `blocks_per_launch` blocks of this
+            rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches))."""
+            per_leg = []
+            for (_, ms, launches, blocks, _bus) in legs:
+                if launches and ms > 0:
+                    bpl = blocks / launches
+                    per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches))   # (a launch renders bpl pieces of max_frames frames)
+            if not per_leg:
+                return [0.0], (0.0, 0.0, 0.0, 0)
+            return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
+
+        render(args.warmup)
         ring.drain()
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ms, launches, blocks = g.kernel_stats(reset=True)
-        bus = g.bus_kernel_stats(reset=True)
-        return dt, ms, launches, blocks, bus
+        del calls[:]
+        legs, dts = legs_for(min_seconds)
+        offline_calls = sorted(calls)
+        # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
+        # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
+        rt_legs, rt_dts = (legs_for(min_seconds / 2, 1) if (sb > 1 and world == 1 and with_realtime) else (None, None))
+        last = ring.last_block()
+        peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
 
-    def legs_for(seconds, per_call=None):
-        """Timed legs of exactly --steps blocks until `seconds` of wall time are covered (at least 5, at most 2001; --repeats overrides):
-        a 20-step leg lasts 2 ms, single legs scatter with the clock state of the box. Returns (legs, per-leg seconds, MAX over ranks)."""
-        first = leg(args.steps, per_call)
-        d0 = first[0]
-        if dist_on:
-            t = torch.tensor([d0], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank runs the same number of legs
-            d0 = float(t.item())
-        n = args.repeats if args.repeats > 0 else max(5, min(2001, int(1.2 * seconds / max(d0, 1e-6)) | 1))   # (+20 %: the first leg runs slower than the rest)
-        legs = [first] + [leg(args.steps, per_call) for _ in range(n - 1)]
-        dts = [l[0] for l in legs]
-        if dist_on:
-            t = torch.tensor(dts, dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dts = [float(x) for x in t.tolist()]
-        torch.cuda.synchronize()
-        return legs, dts
+        dev_err = g.device_errors()
+        if dev_err:
+            raise RuntimeError(f"kernel consistency flags raised: {dev_err}")
+        res = dict(name=name, scaling=scaling, v_per_gpu=v_per_gpu, total_voices=total_voices, M=M, dts=dts, legs=legs, rt_dts=rt_dts, rt_legs=rt_legs, peak=peak,
+                   offline_calls=offline_calls, kernel=g.dominant_kernel(), bus_kernel=g.bus_kernel(), roofline_of=roofline_of)
+        torch.cuda.set_stream(torch.cuda.default_stream(local_rank))
+        del ring
+        g.close()
+        return res
 
-    def roofline_of(legs):
-        """Dominant kernel: algorithmic bytes of one launch / its average duration, per leg; a launch renders `blocks_per_launch` blocks of this
-        rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches))."""
-        per_leg = []
-        for (_, ms, launches, blocks, _bus) in legs:
-            if launches and ms > 0:
-                bpl = blocks / launches
-                per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches))   # (a launch renders bpl pieces of max_frames frames)
-        if not per_leg:
-            return [0.0], (0.0, 0.0, 0.0, 0)
-        return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
-
-    render(args.warmup)
-    ring.drain()
-    del calls[:]
-    legs, dts = legs_for(args.min_seconds)
-    offline_calls = sorted(calls)
-    # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
-    # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
-    rt_legs, rt_dts = (legs_for(args.min_seconds / 2, 1) if (sb > 1 and world == 1 and not args.no_realtime) else (None, None))
-    last = ring.last_block()
-    peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
-
-    dev_err = g.device_errors()
-    if dev_err:
-        raise RuntimeError(f"kernel consistency flags raised: {dev_err}")
+    R = measure(args.workload, args.scaling, args.voices, args.total_voices, args.min_seconds, not args.no_realtime)
+    # BASELINE config 5 as north_star states it — 8192 voices with the full chain, voice-sharded over the GPUs of the node — rides along in
+    # the same line (config.strong_c5): the driver's 1 / 2 / 4 / 8-GPU runs then measure the >= 6x claim itself (SURVEY §8e), next to the
+    # weak-scaling `value` of the headline. --strong-c5-voices 0 switches it off.
+    S5 = None
+    if args.strong_c5_voices > 0 and not (args.workload == "c5" and args.scaling == "strong"):
+        S5 = measure("c5", "strong", 0, args.strong_c5_voices, min(args.min_seconds, 0.25), False)
+    name, v_per_gpu, total_voices, M = R["name"], R["v_per_gpu"], R["total_voices"], R["M"]
+    dts, legs, rt_dts, rt_legs, peak, offline_calls, roofline_of = R["dts"], R["legs"], R["rt_dts"], R["rt_legs"], R["peak"], R["offline_calls"], R["roofline_of"]
     if rank == 0:
         med = int(np.argsort(dts)[len(dts) // 2])
         dt = dts[med]
@@ -437,7 +460,7 @@ def main():
                 "frac_max": ach[-1] / HBM_PEAK_GBS,
                 "traffic": traffic * bpl_l if traffic else None,
                 "traffic_note": traffic_note,
-                "kernel": g.dominant_kernel(),
+                "kernel": R["kernel"],
                 "kernel_ms": ms_l,
                 "blocks_per_launch": bpl_l,
                 "kernel_ms_per_block": ms_l / bpl_l if bpl_l else 0.0,   # per piece of max_frames frames
@@ -457,11 +480,11 @@ def main():
             per_block_ms = bus_ms / bus_blocks
             achieved_bus = B_ALG[name] * v_per_gpu * mf / (per_block_ms * 1e-3) / 1e9
             out["roofline"].update({
-                "bound": "latency", "kernel": g.bus_kernel(), "achieved": achieved_bus, "frac": achieved_bus / HBM_PEAK_GBS,
+                "bound": "latency", "kernel": R["bus_kernel"], "achieved": achieved_bus, "frac": achieved_bus / HBM_PEAK_GBS,
                 "kernel_ms": bus_ms / max(1, sum(l[4][1] for l in legs)), "blocks_per_launch": bus_blocks / max(1, sum(l[4][1] for l in legs)),
                 "kernel_ms_per_block": per_block_ms, "kernel_ms_per_step": per_block_ms * block / mf, "launches": sum(l[4][1] for l in legs),
                 "latency_chain_us_per_block": per_block_ms * 1e3, "shader_cycles_per_block_at_2.4GHz": per_block_ms * 1e-3 * 2.4e9,
-                "unit_kernels": {"kernel": g.dominant_kernel(), "ms_per_block": (unit_ms / max(1, sum(l[3] for l in legs))), "share_of_timed_gpu_ms": unit_ms / (unit_ms + bus_ms)},
+                "unit_kernels": {"kernel": R["kernel"], "ms_per_block": (unit_ms / max(1, sum(l[3] for l in legs))), "share_of_timed_gpu_ms": unit_ms / (unit_ms + bus_ms)},
                 "note": "the launch that dominates by GPU time is the main mixer's effect chain behind the sum: a chain of per-frame recurrences on one workgroup per effect — "
                         "bounded by that workgroup's latency chain, not by HBM (frac = the workload's algorithmic bytes over THIS launch's time, for the record)"})
             for k in ("frac_min", "frac_max", "traffic", "algorithmic_bytes_per_launch"):
@@ -480,6 +503,17 @@ def main():
                 "kernel_ms_per_block": rt_ms / rt_bpl if rt_bpl else 0.0,
                 "repeats": len(rt_dts),
                 "timed_seconds": sum(rt_dts),
+            }
+        if S5:
+            d5 = S5["dts"][int(np.argsort(S5["dts"])[len(S5["dts"]) // 2])]
+            _, (ms5, bpl5, ach5, _l5) = S5["roofline_of"](S5["legs"])
+            out["config"]["strong_c5"] = {
+                "what": "BASELINE config 5: %d voices, per-voice Filter->Eq5->Delay->Reverb, split over the GPUs (strong scaling), master bus reduced per %d block(s); "
+                        "the 8-GPU value over the 1-GPU value of this field is the >= 6x claim" % (S5["total_voices"], S5["M"]),
+                "total_voices": S5["total_voices"], "voices_per_gpu": S5["v_per_gpu"], "n_gpus": world, "scaling": "strong",
+                "ms_per_step": d5 / args.steps * 1e3, "value": S5["total_voices"] * block * args.steps / d5, "unit": "voice-frames/s",
+                "roofline_frac": ach5 / HBM_PEAK_GBS, "kernel": S5["kernel"], "kernel_ms_per_block": ms5 / bpl5 if bpl5 else 0.0, "repeats": len(S5["dts"]),
+                "bus_peak": S5["peak"],
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, block)

@@ -302,6 +302,13 @@ int pg_graph_device_errors(pg_graph* g);
  * all ranks (RCCL) and then runs them once on the root with pg_graph_process_bus_device(). */
 int pg_graph_set_defer_bus(pg_graph* g, int defer);
 int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream);
+/* One process per GPU: the ranks' `audible` words ride with their partial buses. pg_graph_export_audible writes the words of the LAST
+ * pg_graph_write_device call of a deferred-bus graph — one per block of max_frames, a chunk's flag in the word of its last piece, all 0 when
+ * that call had nothing to render — as floats (0 / 1) to d_dst, e.g. right behind the call's samples: ONE sum-reduce then carries samples
+ * and words (OR = sum > 0). pg_graph_process_bus_device_flags is pg_graph_process_bus_device with those summed words: the root's bus chain
+ * takes EffectProcessor's decisions (bypass, tails; src/source/mixed/effect.rs:56-145) per chunk as the one main mixer would. */
+int pg_graph_export_audible(pg_graph* g, float* d_dst, int n_words, void* hip_stream);
+int pg_graph_process_bus_device_flags(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream, const float* d_flags, int n_words);
 /* Block until all work of the graph's stream has finished. */
 int pg_graph_synchronize(pg_graph* g);
 

@@ -1312,7 +1312,9 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   if (begin) { graph_begin_write(g, pos); g->call_end = pos + n_samples / 2; }
   if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
   if (!g->stream_voices.empty() && flush_stream_feeds(g, stream)) { g->failed = true; return 0; }
+  g->audible_valid = false;   // (a write that finds nothing to do launches nothing: the words an earlier call left are not this call's)
   if (graph_is_empty(g)) return 0;
+  g->audible_valid = true;
   const uint64_t frames = n_samples / 2, mf = g->max_frames, CH = PG_MAX_FRAMES;
   uint64_t done = 0;
   auto fail = [&]() -> size_t { g->failed = true; return 0; };
@@ -1591,10 +1593,40 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
   return PG_OK;
 }
 
+// One process per GPU (bench.py over RCCL): the ranks' `audible` words travel WITH their partial buses — as floats behind the samples, one
+// sum-reduce for both — and the root's bus chain takes its per-chunk decisions from the summed words as the one mixer would from its own.
+__global__ void pg_words_to_float_kernel(const int* __restrict__ w, float* __restrict__ f, int n, int valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = (valid && w[i] != 0) ? 1.0f : 0.0f;
+}
+__global__ void pg_float_to_words_kernel(const float* __restrict__ f, int* __restrict__ w, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = f[i] > 0.0f ? 1 : 0;
+}
+
 extern "C" {
 
 int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
   return process_bus_impl(g, d_bus, n_samples, pos_in_frames, hip_stream ? (hipStream_t)hip_stream : g->stream, nullptr);
+}
+int pg_graph_export_audible(pg_graph* g, float* d_dst, int n_words, void* hip_stream) {
+  if (n_words < 0 || (size_t)n_words > g->audible_slots) return set_error(PG_ERR_PARAMETER, "a write leaves at most %zu words", g->audible_slots);
+  if (n_words == 0) return PG_OK;
+  (void)hipSetDevice(g->device);
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
+  hipLaunchKernelGGL(pg_words_to_float_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, g->d_audible, d_dst, n_words, g->audible_valid ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return PG_OK;
+}
+int pg_graph_process_bus_device_flags(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream, const float* d_flags, int n_words) {
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
+  if (!d_flags) return process_bus_impl(g, d_bus, n_samples, pos_in_frames, s, nullptr);
+  const size_t need = (n_samples / 2 + g->max_frames - 1) / g->max_frames;
+  if (n_words < 0 || (size_t)n_words > g->audible_slots || (size_t)n_words < need) return set_error(PG_ERR_PARAMETER, "the bus chain needs one word per block of max_frames (%zu)", need);
+  (void)hipSetDevice(g->device);
+  hipLaunchKernelGGL(pg_float_to_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_flags, g->d_audible, n_words);
+  HIP_TRY(hipGetLastError());
+  return process_bus_impl(g, d_bus, n_samples, pos_in_frames, s, g->d_audible);
 }
 
 }  // extern "C"

@@ -243,6 +243,7 @@ struct pg_graph {
   size_t unit_out_blocks = 0;   // per-unit output tables as allocated: max(max_blocks, pieces of a chunk)
   size_t bus_frames = 0;        // frames the staging of pg_graph_write holds (whole chunks: >= PG_MAX_FRAMES)
   size_t audible_slots = 0;     // words of d_audible: one per block of a launch sequence / piece of a chunk
+  bool audible_valid = false;   // the last write rendered (its `audible` words are in d_audible)
   bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
   unsigned long long* d_bus_progress = nullptr;  // progress words of the pipelined bus chain (pg_bus_pipeline)

@@ -54,8 +54,16 @@ class Graph(GraphHandle):
     def set_defer_bus(self, defer):
         self._check(self._lib.pg_graph_set_defer_bus(self._h, 1 if defer else 0))
 
-    def process_bus_device(self, d_bus_ptr, n_samples, pos_in_frames, stream=None):
-        self._check(self._lib.pg_graph_process_bus_device(self._h, C.c_void_p(d_bus_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0)))
+    def process_bus_device(self, d_bus_ptr, n_samples, pos_in_frames, stream=None, flags_ptr=None, n_words=0):
+        """The main mixer's chain over a summed bus the caller holds; flags_ptr: the ranks' summed `audible` words (export_audible), one per block of max_frames."""
+        if flags_ptr:
+            self._check(self._lib.pg_graph_process_bus_device_flags(self._h, C.c_void_p(d_bus_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0), C.c_void_p(flags_ptr), n_words))
+        else:
+            self._check(self._lib.pg_graph_process_bus_device(self._h, C.c_void_p(d_bus_ptr), n_samples, pos_in_frames, C.c_void_p(stream or 0)))
+
+    def export_audible(self, d_dst_ptr, n_words, stream=None):
+        """The `audible` words of the last write_device call of a deferred-bus graph as floats (0 / 1): they ride with the partial bus in one reduce."""
+        self._check(self._lib.pg_graph_export_audible(self._h, C.c_void_p(d_dst_ptr), n_words, C.c_void_p(stream or 0)))
 
     def synchronize(self):
         self._check(self._lib.pg_graph_synchronize(self._h))

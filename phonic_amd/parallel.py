@@ -31,9 +31,11 @@ class MasterBusRing:
     runs on RCCL's own stream, ordered behind the render stream by an event, under the renders of the following super-blocks;
     `Work.wait()` only makes the current stream wait. Without a process group the ring is plain double buffering (world size 1)."""
 
-    def __init__(self, n_samples, blocks_per_reduce, device, n_buffers=4, root=0, group=None, force_distributed=False):
+    def __init__(self, n_samples, blocks_per_reduce, device, n_buffers=4, root=0, group=None, force_distributed=False, extra=0):
         self.n_samples, self.m, self.n_buffers, self.root, self.group = int(n_samples), max(1, int(blocks_per_reduce)), int(n_buffers), root, group
-        self.buffers = [torch.zeros(self.m * self.n_samples, dtype=torch.float32, device=device) for _ in range(self.n_buffers)]
+        # `extra` floats of room behind the last block of a buffer: a call's `audible` words travel right behind its samples (slots(k, extra))
+        self.extra = int(extra)
+        self.buffers = [torch.zeros(self.m * self.n_samples + self.extra, dtype=torch.float32, device=device) for _ in range(self.n_buffers)]
         self.pending = [None] * self.n_buffers
         self.step = 0  # next block (super-block aligned after drain())
         self._last = None
@@ -47,15 +49,17 @@ class MasterBusRing:
         """Blocks left in the super-block being filled."""
         return self.m - self.step % self.m
 
-    def slots(self, n_blocks=1):
-        """The [n_blocks * n_samples] view the next `n_blocks` consecutive blocks are rendered into (n_blocks <= room()); on the root
-        it later holds the sum over ranks."""
+    def slots(self, n_blocks=1, extra=0):
+        """The [n_blocks * n_samples (+ extra)] view the next `n_blocks` consecutive blocks are rendered into (n_blocks <= room()); on the root
+        it later holds the sum over ranks. extra: floats behind the samples for what rides along in the same reduce (the ranks' `audible`
+        words; the room is the next block's until that block is rendered)."""
         k, j = self._where()
         assert 1 <= n_blocks <= self.m - j, (n_blocks, j, self.m)
+        assert 0 <= extra <= min(self.extra, self.n_samples), (extra, self.extra)
         if j == 0 and self.pending[k] is not None:
             self.pending[k].wait()
             self.pending[k] = None
-        return self.buffers[k][j * self.n_samples : (j + n_blocks) * self.n_samples]
+        return self.buffers[k][j * self.n_samples : (j + n_blocks) * self.n_samples + extra]
 
     def slot(self):
         return self.slots(1)
@@ -66,7 +70,7 @@ class MasterBusRing:
         self.step += n_blocks
         self._last = (k, j + n_blocks - 1)
         if self.distributed and j + n_blocks == self.m:
-            self.pending[k] = dist.reduce(self.buffers[k], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending[k] = dist.reduce(self.buffers[k][: self.m * self.n_samples], dst=self.root, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return k, j
 
     def close(self):

@@ -246,6 +246,8 @@ def _run_bench(args, env_extra, launcher=None, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    if "--strong-c5-voices" not in args:
+        args = args + ["--strong-c5-voices", "0"]     # (the BASELINE config 5 leg of the default line: its own test below)
     cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + args
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
@@ -292,7 +294,23 @@ def test_bench_single_gpu_line_shape():
     # the real-time call pattern (one write call per block) is timed in the same run on the same graph
     rt = d["config"]["realtime"]
     assert rt["blocks_per_call"] == 1 and rt["ms_per_step"] > 0 and 0 < rt["roofline_frac"] < 1 and rt["repeats"] == 3
-    assert d["config"]["blocks_per_call"] == 32
+    assert d["config"]["blocks_per_call_requested"] == 32 and d["config"]["blocks_per_call"] == 20      # (as issued: a 20-step leg is one call of 20 blocks)
+    assert c["single_thread"]["cores"] == 1 and 0 < c["single_thread"]["value"] <= c["value"] * 1.5
+    assert "strong_c5" not in d["config"]
+
+
+def test_bench_line_carries_the_strong_scaling_leg_of_config_5():
+    """config.strong_c5 of the default line: BASELINE config 5 (per-voice Filter -> Eq5 -> Delay -> Reverb) with a FIXED voice count split over the
+    ranks, in the same run as the headline — what the driver's 1 / 2 / 4 / 8-GPU runs divide to get the >= 6x claim. Reduced voice
+    count here; one rank, then two ranks sharing GPU 0 over gloo (the leg's graph is built after the headline's has been released)."""
+    d = _run_bench(["--steps", "12", "--warmup", "4", "--repeats", "2", "--voices", "32", "--no-cpu-baseline", "--no-realtime", "--strong-c5-voices", "25"], {})
+    s5 = d["config"]["strong_c5"]
+    assert s5["total_voices"] == 25 and s5["voices_per_gpu"] == 25 and s5["scaling"] == "strong" and s5["value"] > 0 and s5["bus_peak"] > 1e-3
+    assert abs(s5["value"] - 25 * 1024 * 12 / (s5["ms_per_step"] * 12e-3)) / s5["value"] < 1e-6
+    assert d["config"]["total_voices"] == 32 and d["scaling"] == "weak"
+    d2 = _run_bench(["--gpus", "2", "--steps", "12", "--warmup", "4", "--repeats", "2", "--voices", "32", "--strong-c5-voices", "25"], {"PHONIC_BENCH_SHARED_GPU": "1"})
+    s5 = d2["config"]["strong_c5"]
+    assert d2["n_gpus"] == 2 and s5["total_voices"] == 25 and s5["voices_per_gpu"] == 13 and s5["n_gpus"] == 2 and s5["bus_peak"] > 1e-3
 
 
 def test_bench_legs_cover_the_requested_time_and_bus_workloads_use_superblocks():
@@ -327,7 +345,7 @@ def test_bench_fails_loudly_when_the_rccl_group_cannot_be_created():
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("PHONIC_BENCH_SHARED_GPU", None)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--voices", "8"], cwd=root, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--voices", "8", "--strong-c5-voices", "0"], cwd=root, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -360,7 +378,7 @@ def test_bench_two_ranks_on_one_gpu_control_flow(steps, warmup, reduce_every):
     env = dict(os.environ, PHONIC_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--voices", "64", "--reduce-every", str(reduce_every),
-           "--superblock", str(min(reduce_every, 4)), "--repeats", "2"]
+           "--superblock", str(min(reduce_every, 4)), "--repeats", "2", "--strong-c5-voices", "0"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
