@@ -15,6 +15,11 @@
 #include "pg_host_internal.h"
 
 #include <dlfcn.h>
+
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
 #include <rccl/rccl.h>  // types and enums only: the entry points are looked up at run time (pg_sharded_set_reduce), the library does not link RCCL
 
 // bus[i] = own[i] + sum of the peers' partials in shard order; audible_out[c] = OR over the shards of their flag for chunk c
@@ -64,7 +69,57 @@ static int rccl_load() {
   return PG_OK;
 }
 
+// One issuing thread per shard behind the first. A write enqueues every shard's launch sequence (tens of HIP calls each); from ONE host thread
+// that is ~20 us per shard one after the other — 170 us per 1024-frame block at eight shards, several times the block's GPU time on eight
+// devices (tools/exp_sharded_host_time.py) — so the caller's thread issues shard 0 and hands the others to their workers, which issue in
+// parallel on their own devices (hipSetDevice is per thread) and report back before the root's sum is enqueued. A worker spins for a short
+// while after a job (an offline pull loop calls back to back) and then sleeps on its condition variable (a real-time callback comes every
+// few milliseconds). PHONIC_SHARD_THREADS=0: the caller's thread issues everything (as before).
+struct ShardWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<uint64_t> posted{0}, finished{0};
+  std::function<int()> job;
+  int rc = 0;
+  std::string error;
+  bool quit = false;
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      int spins = 0;
+      while (posted.load(std::memory_order_acquire) == seen && spins < 20000) { ++spins; __builtin_ia32_pause(); }
+      if (posted.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return quit || posted.load(std::memory_order_acquire) != seen; });
+      }
+      if (quit) return;
+      seen = posted.load(std::memory_order_acquire);
+      rc = job();
+      if (rc) error = pg_last_error_message();
+      finished.store(seen, std::memory_order_release);
+    }
+  }
+  void post(std::function<int()> f) {
+    job = std::move(f);
+    { std::lock_guard<std::mutex> lock(m); posted.fetch_add(1, std::memory_order_release); }
+    cv.notify_one();
+  }
+  int wait() {  // (the caller needs the result before it can go on: it spins)
+    const uint64_t want = posted.load(std::memory_order_acquire);
+    while (finished.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+    if (rc) set_error(rc, "%s", error.c_str());
+    return rc;
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> lock(m); quit = true; }
+    cv.notify_one();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct pg_sharded_graph {
+  std::vector<std::unique_ptr<ShardWorker>> workers;   // [shard - 1]; empty: the caller's thread issues every shard
   std::vector<pg_graph*> shards;
   std::vector<int> load;                 // sub-mixers + main-mixer sources placed on each shard
   uint32_t sample_rate = 48000;
@@ -135,20 +190,31 @@ pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count
   const size_t flag_bytes = (size_t)n_devices * PG_AUDIBLE_SLOTS * sizeof(int);
   if (hipEventCreateWithFlags(&s->summed, hipEventDisableTiming) != hipSuccess || pg_malloc((void**)&s->d_flags, flag_bytes) != hipSuccess || sharded_alloc_buffers(s.get())) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
+    pg_sharded_destroy(s.release());   // (shards, events and what was allocated so far)
     return nullptr;
   }
   (void)pg_memset(s->d_flags, 0, flag_bytes);
   s->mixer_map.append(0);  // global mixer 0 = the main mixer (its chain lives on the root shard)
+  const char* e = getenv("PHONIC_SHARD_THREADS");
+  if (n_devices > 1 && !(e && e[0] == '0')) {
+    for (int i = 1; i < n_devices; ++i) {
+      s->workers.emplace_back(new ShardWorker());
+      ShardWorker* w = s->workers.back().get();
+      w->th = std::thread([w] { w->run(); });
+    }
+  }
   return s.release();
 }
 void pg_sharded_destroy(pg_sharded_graph* s) {
   if (!s) return;
+  for (auto& w : s->workers) w->stop();
+  s->workers.clear();
   (void)sharded_wait_all(s);
   sharded_drop_comms(s);
   for (size_t i = 0; i < s->shards.size(); ++i) {
     (void)hipSetDevice(s->shards[i]->device);
-    if (s->d_partial[i]) (void)pg_free(s->d_partial[i]);
-    (void)hipEventDestroy(s->done[i]);
+    if (i < s->d_partial.size() && s->d_partial[i]) (void)pg_free(s->d_partial[i]);
+    if (i < s->done.size()) (void)hipEventDestroy(s->done[i]);
   }
   (void)hipSetDevice(s->shards[0]->device);
   if (s->summed) (void)hipEventDestroy(s->summed);
@@ -350,7 +416,9 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_
   pg_graph* root = s->shards[0];
   const int n_chunks = (int)std::min<size_t>((n_samples / 2 + s->max_frames - 1) / s->max_frames, PG_AUDIBLE_SLOTS);
   const bool rccl = s->reduce_mode == PG_REDUCE_RCCL;
-  for (size_t i = 0; i < n; ++i) {
+  // every shard's launch sequence, its `audible` words and (peer-copy mode) the copies that carry both to the root: issued by the shard's own
+  // thread when the handle has workers (shard 0 by the caller's), else one after the other here
+  auto issue = [s, off_samples, n_samples, pos, n_chunks, rccl, cap, root](size_t i) -> int {
     pg_graph* g = s->shards[i];
     HIP_TRY(hipSetDevice(g->device));
     float* part = s->d_partial[i] + off_samples;
@@ -360,7 +428,7 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_
       HIP_TRY(hipMemsetAsync(part, 0, n_samples * sizeof(float), g->stream));
       HIP_TRY(hipMemsetAsync(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int), g->stream));
     }
-    if (rccl) continue;
+    if (rccl) return PG_OK;
     // the root's sum of the previous segment (or call) must have read the gather buffers before this shard overwrites them
     if (s->summed_recorded) HIP_TRY(hipStreamWaitEvent(g->stream, s->summed, 0));
     if (i > 0) {
@@ -370,6 +438,15 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_
     } else {
       HIP_TRY(hipMemcpyAsync(s->d_flags, g->d_audible, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, g->stream));
     }
+    return PG_OK;
+  };
+  if (!s->workers.empty()) {
+    for (size_t i = 1; i < n; ++i) s->workers[i - 1]->post([issue, i] { return issue(i); });
+    int rc = issue(0);
+    for (size_t i = 1; i < n; ++i) { const int r = s->workers[i - 1]->wait(); if (!rc) rc = r; }   // (every done[i] is recorded before the root waits for it)
+    if (rc) return rc;
+  } else {
+    for (size_t i = 0; i < n; ++i) { const int rc = issue(i); if (rc) return rc; }
   }
   HIP_TRY(hipSetDevice(root->device));
   if (rccl) {

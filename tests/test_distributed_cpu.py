@@ -206,3 +206,32 @@ def test_master_bus_ring_multi_block_slots_two_ranks():
         assert np.all(bufs[0][j * n:(j + 1) * n] == total(expect0[j])), (j, bufs[0])
         assert np.all(bufs[1][j * n:(j + 1) * n] == total(expect1[j])), (j, bufs[1])
     assert np.all(last_before == 23.0) and np.all(last_after == total(22))
+
+
+def test_master_bus_ring_schedule_at_eight_ranks():
+    """The same ring schedule — whole super-blocks, a super-block that ends early, a partly filled one reduced by drain(), buffer reuse behind
+    the reduce issued a ring round earlier — at the node's rank count: EIGHT ranks over gloo (rank counts above two had never run; one
+    GPU box cannot hold eight ranks on its card, the control flow does not need one)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_multi_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        bufs, last_before, last_after = q.get(timeout=300)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    n, m = 4, 6
+    total = lambda step: float((step + 1) * 7001)      # rank 0 writes (step + 1), the seven others (step + 1) * 1000
+    expect0 = [18, 19, 20, 21, 22, 5]
+    expect1 = [15, 16, 17, 9, 10, 11]
+    for j in range(m):
+        assert np.all(bufs[0][j * n:(j + 1) * n] == total(expect0[j])), (j, bufs[0])
+        assert np.all(bufs[1][j * n:(j + 1) * n] == total(expect1[j])), (j, bufs[1])
+    assert np.all(last_before == 23.0) and np.all(last_after == total(22))
