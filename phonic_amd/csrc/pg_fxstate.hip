@@ -57,7 +57,7 @@ static void build_dist_luts(float* luts /*[5][256]*/) {
 // vibrato rotation table of the reverb fast path: cos/sin(j * depth_i * vib_speed), j = 0..128, for the eight lines
 // (depths: src/effect/reverb.rs:137-144; increment depth*speed: reverb.rs:601-603). Read-only, shared by all instances.
 static std::mutex g_tables_mutex;  // the shared read-only tables are built once per device, from whichever thread gets there first;
-static std::map<int, double*> g_vib_tabs;  // they live until the process ends (a few KB per device)
+static std::map<int, double*>& g_vib_tabs = *new std::map<int, double*>();  // they live until the process ends (a few KB per device; the map is never destroyed: the tables stay reachable)
 static int get_vib_tab(int device, const double** out) {
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_vib_tabs.find(device);
@@ -76,7 +76,7 @@ static int get_vib_tab(int device, const double** out) {
   *out = it->second;
   return PG_OK;
 }
-static std::map<int, float*> g_dist_luts;  // per device
+static std::map<int, float*>& g_dist_luts = *new std::map<int, float*>();  // per device
 static int get_dist_luts(int device, const float** out) {
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   auto it = g_dist_luts.find(device);

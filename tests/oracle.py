@@ -25,9 +25,10 @@ def lib():
     global _LIB
     if _LIB is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
-        if not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        path = os.environ.get("PHONIC_ORACLE_LIB") or LIB_PATH     # (tests/test_sanitizers.py: the ASan / UBSan build of the same sources)
+        if path == LIB_PATH and (not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)):
             build()
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         _capi.declare(l, "po_")
         P, f32, sz = C.POINTER, C.c_float, C.c_size_t
         l.po_clear_buffer.argtypes = [P(f32), sz]
