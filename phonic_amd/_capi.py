@@ -220,13 +220,15 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    # PHONIC_LIB: another build of the SAME library (tools/ab_libs/*.so: A/B runs of kernel variants on one box) — still HIP, still no fallback
+    path = os.environ.get("PHONIC_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). phonic_amd has no CPU fallback."
         )
     _preload_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     declare(lib, "pg_")
     P = C.POINTER
     vp = C.c_void_p

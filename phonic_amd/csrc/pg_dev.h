@@ -365,5 +365,6 @@ struct PgPiece {
 };
 // PgLaunch::error_word bits: conditions the host's routing must make impossible; a set bit means wrong audio, never a crash.
 enum { PG_DEVERR_FAST_DECLINED = 1,   // a kernel without serial effect code met an effect state its time-parallel path does not take
-       PG_DEVERR_SUPER_DEFERRED = 2 };  // a unit wanted the generic kernel inside a super-block launch
+       PG_DEVERR_SUPER_DEFERRED = 2,  // a unit wanted the generic kernel inside a super-block launch
+       PG_DEVERR_BUS_STALLED = 4 };   // a stage of the pipelined bus chain gave up waiting for the stage in front of it
 constexpr int PG_STAGE_BUF_DOUBLES = 2 * 1024 + 128 + 8;

@@ -611,9 +611,13 @@ int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint
   const size_t ring_floats = capacity_frames * channels;
   void* d_ring = nullptr;
   float* h_ring = nullptr;
+  void* d_stage = nullptr;
+  auto release = [&]() { if (d_ring) (void)pg_free(d_ring); if (h_ring) (void)pg_host_free(h_ring); if (d_stage) (void)pg_free(d_stage); };   // (error returns below)
   if (pg_malloc(&d_ring, ring_floats * sizeof(float)) != hipSuccess || pg_memset(d_ring, 0, ring_floats * sizeof(float)) != hipSuccess ||
-      pg_host_malloc((void**)&h_ring, ring_floats * sizeof(float), hipHostMallocDefault) != hipSuccess)
+      pg_host_malloc((void**)&h_ring, ring_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    release();
     return -graph_fail(g, set_error(PG_ERR_DEVICE, "ring allocation failed"));
+  }
   v.pcm = (const float*)d_ring;
   v.channels = channels; v.src_rate = rate; v.out_rate = rate; v.ratio = 1.0f;
   v.stream_on = 1; v.stream_cap = (uint32_t)capacity_frames; v.stream_fed = 0;
@@ -626,18 +630,19 @@ int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint
   v.persistent = opt->non_transient != 0;
   v.current_speed = 1.0; v.target_speed = 1.0;
   v.sched_class = -1;
-  void* d_stage = nullptr;
   if (rate != g->sample_rate) {  // ConvertedSource::new -> ResampledSource::new(source, mixer rate, Default)  (converted.rs:15-45, resampled.rs:44-98)
     v.outer_on = 1;
     v.outer_ratio = (float)((double)rate / (double)g->sample_rate);
     const size_t stage_floats = 2 * 512 * (size_t)channels;
-    if (pg_malloc(&d_stage, stage_floats * sizeof(float)) != hipSuccess || pg_memset(d_stage, 0, stage_floats * sizeof(float)) != hipSuccess)
+    if (pg_malloc(&d_stage, stage_floats * sizeof(float)) != hipSuccess || pg_memset(d_stage, 0, stage_floats * sizeof(float)) != hipSuccess) {
+      release();
       return -graph_fail(g, set_error(PG_ERR_DEVICE, "hipMalloc(staging) failed"));
+    }
     v.stage_in = (float*)d_stage; v.stage_out = v.stage_in + 512 * channels;
   }
   int dev_index = -1;
   int rc = g->d_voices.push(v, &dev_index);
-  if (rc) return -graph_fail(g, rc);
+  if (rc) { release(); return -graph_fail(g, rc); }
   const int id = (int)g->voices.size();
   HostVoice hv;
   hv.mixer = mixer_id; hv.dev_index = dev_index; hv.start_time = opt->start_time; hv.d_pcm = d_ring; hv.d_stage = d_stage; hv.outer = rate != g->sample_rate;
@@ -866,7 +871,11 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
 size_t pg_debug_lds_bytes(int which, uint32_t n_frames, uint32_t kind_mask) {
   return which == 0 ? pg_stage_lds_bytes(0, n_frames) : pg_unit_lds_bytes(n_frames, pg_fast_scratch_bytes(kind_mask));
 }
-void pg_debug_fail_launch_round(int nth) { g_fail_round_countdown.store(nth > 0 ? nth : 0); }
+// (a process-wide fault injector has no business in a production process: it only arms when PHONIC_DEBUG_HOOKS=1 is in the environment)
+void pg_debug_fail_launch_round(int nth) {
+  static const bool armed = [] { const char* e = getenv("PHONIC_DEBUG_HOOKS"); return e && e[0] == '1'; }();
+  g_fail_round_countdown.store(armed && nth > 0 ? nth : 0);
+}
 void pg_debug_hip_calls(uint64_t out[4]) {
   out[0] = g_n_alloc.load(); out[1] = g_n_free.load(); out[2] = g_n_sync.load(); out[3] = g_n_blocking_copy.load();
 }

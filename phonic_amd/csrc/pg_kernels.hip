@@ -26,10 +26,11 @@ using namespace pgd;
 // A unit wanted the generic kernel inside a super-block launch: its later blocks stay unrendered. The sticky device word keeps the flag
 // for pg_graph_device_errors; the copy in the host-mapped feedback block lets the next write see it WITHOUT a synchronisation of its own and
 // fail the graph (GuardedSource semantics) instead of handing out wrong audio silently.
-__device__ __forceinline__ void pg_raise_super_deferred(const PgLaunch& L) {
-  if (L.error_word) atomicOr(L.error_word, PG_DEVERR_SUPER_DEFERRED);
-  if (L.host_feedback) { *(volatile unsigned long long*)(L.host_feedback + 2) = (unsigned long long)PG_DEVERR_SUPER_DEFERRED; __threadfence_system(); }
+__device__ __forceinline__ void pg_raise_device_error(const PgLaunch& L, int bit) {
+  if (L.error_word) atomicOr(L.error_word, bit);
+  if (L.host_feedback) { *(volatile unsigned long long*)(L.host_feedback + 2) = (unsigned long long)bit; __threadfence_system(); }
 }
+__device__ __forceinline__ void pg_raise_super_deferred(const PgLaunch& L) { pg_raise_device_error(L, PG_DEVERR_SUPER_DEFERRED); }
 
 // Where block c of the launch sits in the main mixer's chunk grid (PgLaunch::grid_off / grid_span, pg_dev.h).
 __device__ __forceinline__ PgPiece pg_piece(const PgLaunch& L, int c) {
@@ -722,7 +723,11 @@ __global__ void __launch_bounds__(256, PG_MID_WAVES) pg_unit_kernel_fast_mid(PgL
 // serial order (mixed.rs:627-655): audible_input of the block (L.bus_audible[c]) and whether an earlier effect of the chain was active on
 // it (travels with the progress word); MixedSource's shortcut `effects_bypassed && input_bypassed -> skip the chain` changes nothing an
 // effect would not decide for itself (a bypassed processor with silent input stays bypassed, effect.rs:88-101) and is kept as state only.
-// Workgroup f waits for workgroup f - 1 only: lower block indices are dispatched first, so the producer of a waiting workgroup is resident.
+// Workgroup f waits for workgroup f - 1 only. Residency: the launch has at most PG_BUS_PIPELINE_MAX (16) workgroups of 256 lanes, one per CU at
+// most, on a device with 256 CUs and nothing else in front of them on this stream — all of them are resident at once, whatever order the
+// dispatcher starts them in (the guide lists dispatch order as undefined: nothing here relies on it). Should a producer never publish
+// (a fault, a preempted queue), the consumer gives up after a bounded number of polls, raises PG_DEVERR_BUS_STALLED and passes its blocks
+// on unprocessed: a stuck stream would be invisible to the host, a raised flag disables the graph at the next write.
 template <int KMASK>
 __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
   const int f = (int)blockIdx.x, n_stages = (int)gridDim.x;
@@ -744,13 +749,21 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
   __syncthreads();
   const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
   int any_active = 0;
+  if (tid == 0) ctl[7] = 0;
   for (int c = 0; c < n_chunks; ++c) {
     int active_before = 0;
-    if (f > 0) {
+    if (f > 0 && !ctl[7]) {
       if (tid == 0) {
         unsigned long long w;
-        do { w = __hip_atomic_load(&L.bus_progress[f - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(w >> 32) != L.round || (int)(w & 0x7fffffffull) <= c);
-        ctl[6] = (int)((w >> 31) & 1ull);
+        unsigned polls = 0;
+        bool ok;
+        do {
+          w = __hip_atomic_load(&L.bus_progress[f - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (uint32_t)(w >> 32) == L.round && (int)(w & 0x7fffffffull) > c;
+          if (!ok) __builtin_amdgcn_s_sleep(8);   // (~0.2 us: the producer's block takes tens of microseconds)
+        } while (!ok && ++polls < (1u << 24));     // (seconds: far beyond any block time)
+        if (!ok) { pg_raise_device_error(L, PG_DEVERR_BUS_STALLED); ctl[7] = 1; }
+        ctl[6] = ok ? (int)((w >> 31) & 1ull) : 0;
       }
       __syncthreads();
       __threadfence();  // the producer's stores of block c are visible (the L1 is invalidated behind the acquire)

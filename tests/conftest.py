@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+os.environ.setdefault("PHONIC_DEBUG_HOOKS", "1")   # arms pg_debug_fail_launch_round (the fault-injection test); a production process leaves it unset
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -11,7 +11,8 @@ python bench.py --superblock 1 --steps 100 --warmup 20 --no-cpu-baseline > $O/${
 # kernel traces of the two bus-chain workloads (the bus kernel is their dominant one) and the ring-stream micro-benchmark (what the memory system
 # gives the mid stage's access stream without its arithmetic)
 for w in c2 c4; do bash tools/ktrace.sh --workload $w --repeats 3 --steps 64 --warmup 32 > $O/${R}_${w}_kernel_trace.txt 2>&1; done
-( cd tools/ringstream && for v in 0 1 2 3 4 5; do ./ringstream.bin 1024 16 $v 4; done; ./ringstream.bin 1024 16 0 2; ./ringstream.bin 1024 16 0 5; ./ringstream.bin 4096 8 0 4 ) > $O/${R}_ringstream.jsonl 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/ringstream/ringstream.bin tools/ringstream/ringstream.hip || { echo "ringstream build failed" >&2; exit 1; }
+( cd tools/ringstream && for v in 0 1 2 3 4 5; do ./ringstream.bin 1024 16 $v 4; done; ./ringstream.bin 1024 16 0 2; ./ringstream.bin 1024 16 0 5; ./ringstream.bin 4096 8 0 4 ) > $O/${R}_ringstream.jsonl
 bash tools/c3_round.sh c3tmp > /dev/null 2>&1
 cp gpurun_out/c3tmp/c3_rocprofv3_kernel_stats.csv $O/${R}_c3_rocprofv3_kernel_stats.csv
 cp gpurun_out/c3tmp/c3_pmc_util.csv $O/${R}_c3_pmc_util.csv
