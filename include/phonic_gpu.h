@@ -185,7 +185,13 @@ typedef struct pg_voice_options {
 void pg_voice_options_default(pg_voice_options* opt);
 
 /* MixedSource::new(channel_count, sample_rate) for the main mixer (src/source/mixed.rs:222-264).
- * max_frames bounds the frames of one write() call chunk (<= 4096, MAX_MIX_BUFFER_SAMPLES/2). */
+ * max_frames (1..=4096) is the kernels' PIECE size — how many frames a workgroup holds in LDS at a time (the staged kernels of reverb-terminated
+ * chains take pieces of <= 1024 frames) — and nothing else: a write of any length is walked in the reference's chunks, min(remaining, 4096)
+ * frames (MAX_MIX_BUFFER_SAMPLES / 2, src/source/mixed.rs:216) from the call's start and from every main-mixer event (mixed.rs:679-712),
+ * whatever max_frames is; a chunk is rendered as pieces of max_frames frames, and everything the reference decides once per chunk — the effect
+ * processors' bypass and tail counters (src/source/mixed/effect.rs:56-145), the sub-mixers' silence gate (submixer.rs:47-77), `audible_input`,
+ * an effect's own call-end bookkeeping, a source's fader arrival / end-of-file / is_exhausted — is decided once per chunk here too.
+ * 1024 is the size the kernels are tuned for; a host with 2048- or 4096-frame callbacks keeps it and gets the same chunk grid as the reference. */
 pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t max_frames, int device);
 void pg_graph_destroy(pg_graph* g);
 
@@ -225,7 +231,8 @@ int pg_graph_add_voice(pg_graph* g, int mixer_id, const float* pcm, size_t n_fra
  * stereo, volume, panning, start time (`opt`: volume, panning, start_time are used). A short ring read is a source that delivered
  * less (the rest of the block is silent); the voice ends when the host has ended the stream and everything fed has been played, or
  * at a stop. Device ring and pinned staging ring are reserved here: feed and write allocate nothing. Returns a voice id >= 0 (valid
- * for set_voice_volume / _panning / stop_voice like any other). In steady state such a voice is rendered by the same time-parallel kernels
+ * for set_voice_volume / _panning / stop_voice / remove_voice like any other; set_voice_speed and seek_voice return PG_ERR_PARAMETER: those
+ * exist on FilePlaybackHandle only, src/player/handles/file.rs). In steady state such a voice is rendered by the same time-parallel kernels
  * as a file voice (the ring read is a copy), also inside a write of several blocks. */
 int pg_graph_add_stream_voice(pg_graph* g, int mixer_id, uint32_t channels, uint32_t rate, size_t capacity_frames, const pg_voice_options* opt);
 /* The next n_frames frames of the host's source (interleaved). Owner thread, before the write that should play them; they reach the
@@ -273,12 +280,12 @@ size_t pg_graph_write_device(pg_graph* g, float* d_out, size_t n_samples, uint64
 /* Offline rendering (the reference's WavOutput pull loop, src/output/wav.rs:210-250, has no deadline per block): a write*() call that
  * spans several blocks of max_frames may render up to `n_blocks` of them in ONE launch sequence when nothing is scheduled inside them and
  * every unit is in steady state (MixedSource::write walks its chunks inside one call the same way, src/source/mixed.rs:679-712). All
- * per-block semantics (bypass counters, tails, silence gates) stay per block. Default 1; sizes the per-unit output table
- * (n_blocks x units x max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph.
- * max_frames plays the part of the reference's mix buffer (4096 frames there, mixed.rs:216): inside one write*() call the chunks run from the
- * call's start — and from every main-mixer event that falls inside the call — in steps of max_frames, exactly as MixedSource::write counts
- * them; a caller that wants the chunk grid of a block-by-block pull puts its events on call boundaries or pulls block by block.
- * (pg_graph_write with a host buffer hands the graph at most n_blocks x max_frames frames per call and loops over longer buffers.) */
+ * per-chunk semantics (bypass counters, tails, silence gates) stay per chunk of the reference's grid (see pg_graph_create): a launch sequence
+ * covers whole chunks, its blocks are their pieces. Default 1; sizes the per-unit output table (max(n_blocks, 4096 / max_frames) x units x
+ * max_frames x 8 bytes), allocated at the next graph mutation / first write — call it while building the graph. The result is bit-identical
+ * to the same calls without super-block launches.
+ * (pg_graph_write with a host buffer renders ONE write call whatever its length: its staging holds whole chunks — at least 4096 frames —
+ * and the call is copied out span by span.) */
 /* A unit that leaves the steady state while a super-block launch is in flight (the host only launches them for graphs it knows to be
  * steady: this is a consistency violation, PG_DEVERR_SUPER_DEFERRED) would miss its later blocks: the kernels mirror that flag to the host
  * and the NEXT write*() call disables the graph (returns 0 from then on, pg_last_error_message names the flag) — wrong audio is never
@@ -290,7 +297,8 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks);
  * allocates nothing and frees nothing, and on a caller's stream it never blocks the host. */
 void pg_debug_hip_calls(uint64_t out[4]);
 /* Test hook: the nth launch round from now (process-wide, any graph) fails the way a HIP launch failure does — the graph it hits becomes
- * silent for good: write returns 0, like the reference's GuardedSource after a panic (src/source/guarded.rs:87-107). 0 disarms. */
+ * silent for good: write returns 0, like the reference's GuardedSource after a panic (src/source/guarded.rs:87-107). 0 disarms. Armed only in
+ * a process with PHONIC_DEBUG_HOOKS=1 in its environment; a no-op otherwise. */
 void pg_debug_fail_launch_round(int nth);
 /* Build check hook (tools/check_kernel_resources.py): dynamic LDS bytes of the staged single launch (which 0) / of a fast unit kernel for the
  * effect kinds of kind_mask (which 1) at n_frames frames per block. */

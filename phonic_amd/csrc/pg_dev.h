@@ -149,6 +149,12 @@ struct PgFx {
   // watches for silence (unknown tail, effect.rs:128-144) — the peak of what it put out
   uint32_t call_frames;
   float call_max;
+  // ... and the branch the effect's process() took where the call began: FilterEffect and Eq5Effect test `value_need_ramp` once per call
+  // (filter.rs:167, eq5.rs:298-303) and keep recomputing their coefficients from the smoothers for the rest of it — a smoother that stops
+  // ramping inside the call then hands out its TARGET, while the other branch runs on the coefficients the last ramp frame left (from the
+  // smoother's `current`, up to the ramp threshold away): the branch must not change between the pieces of a call
+  uint32_t call_ramp;
+  uint32_t pad_call;
   union {
     PgGain gain; PgPan pan; PgFilter filter; PgEq5 eq5; PgDelay delay; PgReverb reverb; PgChorus chorus; PgComp comp; PgGate gate; PgDist dist;
   } u;

@@ -149,6 +149,14 @@ DEVO bool eq5_steady(const PgEq5& e) {
   return !ramp;
 }
 
+// Where a process call of the effect begins (the first piece of its chunk; every launch of a standalone effect): the per-call branch of the
+// two effects whose other branch runs on state the ramp left behind (PgFx::call_ramp). Lane 0.
+DEVO void fx_call_begin(PgFx& fx) {
+  if (fx.kind == 2) fx.call_ramp = (sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q)) ? 1u : 0u;
+  else if (fx.kind == 3) fx.call_ramp = eq5_steady(fx.u.eq5) ? 0u : 1u;
+  else fx.call_ramp = 0u;
+}
+
 // Must mirror the acceptance conditions of fx_fast_process exactly: the fast kernel has no serial code to fall back to.
 // staged_unit: the kernel that renders the unit in steady state carries no ramp paths (the staged kernels; the lean fast kernel of graphs that
 // hold nothing but Gain / Panning / Reverb).
@@ -156,8 +164,8 @@ DEVO bool fx_fast_eligible(const PgFx& fx, bool staged_unit) {
   switch (fx.kind) {
     case 0: return !staged_unit || !sm_need_ramp(fx.u.gain.gain);   // ramping: the sequence paths of fx_fast_process (kernel variants with the ramp paths)
     case 1: return !staged_unit || (!sm_need_ramp(fx.u.pan.pan) && !sm_need_ramp(fx.u.pan.width));
-    case 2: return !staged_unit || !(sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q: time-varying scan (not in the staged kernels)
-    case 3: return !staged_unit || eq5_steady(fx.u.eq5);  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
+    case 2: return !staged_unit || !(fx.call_ramp || sm_need_ramp(fx.u.filter.cutoff) || sm_need_ramp(fx.u.filter.q));  // ramping cutoff / Q (or a call that began so and still has pieces to go): time-varying scan (not in the staged kernels)
+    case 3: return !staged_unit || (!fx.call_ramp && eq5_steady(fx.u.eq5));  // ramping: eq5_ramp_fast (like the Filter's ramps: not in the staged kernels)
     case 4: return delay_fast_eligible(fx) || (!staged_unit && delay_ramp_eligible(fx));  // ramping: delay_ramp_fast (not in the staged kernels)
     case 5: return reverb_fast_eligible(fx) || (!staged_unit && reverb_wet_ramp_eligible(fx));  // wet ramping: reverb_wet_ramp_fast (not in the staged kernels)
     case 6: return chorus_fast_eligible(fx) || (!staged_unit && chorus_ramp_eligible(fx));
@@ -277,7 +285,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     }
     case 2: if constexpr ((KMASK >> 2) & 1) {  // FilterEffect, no ramp (filter.rs:193-200)
       PgFilter& f = fx.u.filter;
-      if (sm_need_ramp(f.cutoff) || sm_need_ramp(f.q)) {
+      if (fx.call_ramp) {  // (the branch the call began in: fx_call_begin)
         // bit 10: kernel variants that carry the ramp paths (the fused wide kernel and the generic kernel; the staged kernels keep
         // their register allocation — measured +3.5 % on C5 with this code in them — and hand a ramping unit over as before)
         if constexpr ((KMASK >> 10) & 1) {
@@ -291,7 +299,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
     } else return false;
     case 3: if constexpr ((KMASK >> 3) & 1) {  // Eq5Effect, no ramp (eq5.rs:297-326)
       PgEq5& e = fx.u.eq5;
-      if (!eq5_steady(e)) {
+      if (fx.call_ramp) {
         if constexpr ((KMASK >> 10) & 1) {
           if (fc.tmp_floats < 24) return false;
           eq5_ramp_fast(fx, sig, n, fc);

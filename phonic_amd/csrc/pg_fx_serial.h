@@ -67,7 +67,7 @@ DEVN void pan_serial(PgFx& fx, float* sig, int n) {
 // ---- FilterEffect::process  src/effect/filter.rs:166-201 -----------------------------------------
 DEVN void filter_serial(PgFx& fx, float* sig, int n) {
   PgFilter& f = fx.u.filter;
-  if (sm_need_ramp(f.cutoff) || sm_need_ramp(f.q)) {
+  if (fx.call_ramp) {  // (value_need_ramp where the call began: fx_call_begin)
     PgSmooth sc = f.cutoff, sq = f.q;
     PgBiquadCoef c = f.coef;
     double s0a = f.st[0].ic1eq, s0b = f.st[0].ic2eq, s1a = f.st[1].ic1eq, s1b = f.st[1].ic2eq;
@@ -101,8 +101,7 @@ DEV void eq5_update_filter_coefficients(PgFx& fx) {  // :172-188
 }
 DEVN void eq5_serial(PgFx& fx, float* sig, int n) {  // :297-326
   PgEq5& e = fx.u.eq5;
-  bool need_ramp = false;
-  for (int i = 0; i < 5; ++i) need_ramp = need_ramp || sm_need_ramp(e.freqs[i]) || sm_need_ramp(e.bws[i]) || sm_need_ramp(e.gains[i]);
+  const bool need_ramp = fx.call_ramp != 0;  // (any of the fifteen smoothers needed a ramp where the call began: fx_call_begin)
   int frames = n / 2;
   for (int f = 0; f < frames; ++f) {
     if (need_ramp) {  // ramp_filter_coefficients :190-207

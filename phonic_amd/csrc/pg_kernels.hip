@@ -289,6 +289,7 @@ __device__ __forceinline__ bool fx_processor_pre(PgFx& fx, bool input_bypassed, 
       if (should_bypass && !fx.bypassed) fx.bypassed = 1;                                                // process_stopped: no-op for stock effects
       else if (!should_bypass && fx.bypassed) { fx.bypassed = 0; fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0; }
       fx.call_frames = 0; fx.call_max = 0.0f;
+      fx_call_begin(fx);
     }
     ctl[0] = fx.bypassed;
   }
@@ -328,7 +329,7 @@ __device__ __forceinline__ void fx_processor_post(PgFx& fx, const float* sig, in
   } else if (pg_tid() == 0 && last) {
     fx.tail_counter = PG_USIZE_MAX; fx.silence_counter = 0;  // reset_tail_counters :148-152
   }
-  if (pg_tid() == 0) { if (last) { fx.call_frames = 0; fx.call_max = 0.0f; } else fx.call_frames += (uint32_t)(n / 2); }
+  if (pg_tid() == 0) { if (last) { fx.call_frames = 0; fx.call_max = 0.0f; fx.call_ramp = 0; } else fx.call_frames += (uint32_t)(n / 2); }
   __syncthreads();
 }
 template <bool FAST_ONLY, int KMASK>
@@ -621,7 +622,14 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           PgFx& fx = *lfx;
           PG_STAMP(L.diag, 8);
           bool is_active;
-          if (fx.standalone) { fx_process_wg<FAST_ONLY, KMASK>(fx, sseg, seg * 2, fc, L.fast, true); is_active = true; }
+          if (fx.standalone) {  // (plain Effect::process: every launch is one call)
+            __syncthreads();
+            if (tid == 0) fx_call_begin(fx);
+            __syncthreads();
+            fx_process_wg<FAST_ONLY, KMASK>(fx, sseg, seg * 2, fc, L.fast, true);
+            if (tid == 0) fx.call_ramp = 0;
+            is_active = true;
+          }
           else is_active = fx_processor_process<FAST_ONLY, KMASK>(fx, sseg, seg * 2, input_bypassed, seg_first, seg_last, L.sample_rate, fc, L.fast, ctl, red);
           if (is_active) { input_bypassed = false; all_bypassed = false; }
           __syncthreads();
@@ -936,7 +944,14 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
       __syncthreads();
       bool is_active;
       constexpr int KM = TAG == 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
-      if (lfx->standalone) { fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast, true); is_active = true; }
+      if (lfx->standalone) {
+        __syncthreads();
+        if (tid == 0) fx_call_begin(*lfx);
+        __syncthreads();
+        fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast, true);
+        if (tid == 0) lfx->call_ramp = 0;
+        is_active = true;
+      }
       else is_active = fx_processor_process<true, KM>(*lfx, sig, N * 2, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
       if (is_active) { input_bypassed = false; all_bypassed = false; }
       __syncthreads();

@@ -726,8 +726,13 @@ def _long_call_render(family, seed):
     return (lambda g: render_topology_plan(copy.deepcopy(plan), g)), [n for n, _ in plan["steps"]], (1e-5, 1e-4)
 
 
-@pytest.mark.parametrize("family", ["flat", "nested", "voices", "topology"])
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 10)))
+# what the first campaigns found (DESIGN §2 "Round 4: the chunk grid"): the fader's arrival test (voices 2, topology 3), is_exhausted of a ResampledSource
+# at a piece boundary (voices 37), the file's last frame (voices 46, 70), the per-call ramp branch of Eq5 / Filter (nested 1210)
+LONG_CALL_CASES = [(f, s) for f in ("flat", "nested", "voices", "topology") for s in range(FUZZ_BASE, FUZZ_BASE + (FUZZ_SEEDS // 4 or 10))] + (
+    [] if FUZZ_SEEDS else [("voices", 2), ("topology", 3), ("voices", 37), ("voices", 46), ("voices", 70), ("nested", 1210)])
+
+
+@pytest.mark.parametrize("family,seed", LONG_CALL_CASES)
 def test_random_graphs_in_long_calls(family, seed):
     """MixedSource::write walks a call in chunks of min(remaining, 4096) frames from the call's start and from every event (mixed.rs:216,679-712);
     sources, effect processors and sub-mixers are called once per chunk and take their per-call decisions there (bypass and tail counters,
