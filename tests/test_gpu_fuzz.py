@@ -181,15 +181,19 @@ def test_random_graph_superblock_writes(seed):
     oracle is pulled in the SAME calls."""
     from phonic_amd.graph import Graph
 
-    plan = make_plan(seed)
     rng = np.random.default_rng(11000 + seed)
-    plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+    sizes = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+    for salt in range(8):   # (make_plan draws until audible in ITS calls; in these the next plans are tried until one is)
+        plan = make_plan(seed + 100003 * salt)
+        plan["sizes"] = sizes
+        b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
+        if float(np.abs(b).max()) > 1e-3:
+            break
     g = Graph(SR, 2, 1024, 0)
     g.set_max_blocks_per_launch(4)
     a = render_plan(plan, g)
     a1 = render_plan(plan, Graph(SR, 2, 1024, 0))           # the same calls, one launch sequence per piece
     assert np.array_equal(a, a1), f"super-block render differs from the piece-by-piece one in {int(np.count_nonzero(a != a1))} samples, sizes {plan['sizes']}"
-    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all() and g.device_errors() == 0
     assert float(np.abs(b).max()) > 1e-4
     d = a.astype(np.float64) - b.astype(np.float64)
@@ -210,14 +214,20 @@ def test_random_graph_on_three_shards(seed):
     the reference's chunks)."""
     from phonic_amd.graph import ShardedGraph
 
-    plan = make_plan(seed)
     g = ShardedGraph([0, 0, 0], SR, 2, 1024)
+    sizes = None
     if seed % 2:   # odd seeds: whole-block calls of one to four blocks rendered as super-blocks (bus decisions per chunk, flags OR-ed over the shards)
         rng = np.random.default_rng(13000 + seed)
-        plan["sizes"] = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
+        sizes = [1024 * int(rng.integers(1, 5)) for _ in range(7)]
         g.set_max_blocks_per_launch(4)
+    for salt in range(8):   # (the first of the seed's plans that is audible in these calls)
+        plan = make_plan(seed + 100003 * salt)
+        if sizes:
+            plan["sizes"] = sizes
+        b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
+        if float(np.abs(b).max()) > 1e-3:
+            break
     a = render_plan(plan, g)
-    b = render_plan(plan, oracle.OracleGraph(SR, 2, 1024))
     assert np.isfinite(a).all() and g.device_errors() == 0
     assert float(np.abs(b).max()) > 1e-4
     d = a.astype(np.float64) - b.astype(np.float64)

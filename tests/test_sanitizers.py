@@ -32,18 +32,14 @@ def test_oracle_suites_under_asan_and_ubsan():
     assert "passed" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
 
 
-def test_host_side_of_the_library_under_asan_and_ubsan(tmp_path):
-    """The five translation units of libphonic_gpu compiled HOST-ONLY (hipcc --cuda-host-only: no device code) with -fsanitize=address,undefined and
-    linked against tests/host/hip_stub.cpp instead of the HIP runtime: the library's host logic — topology rebuilds, append-only id maps, the control
-    ring's drain, event queues and per-piece command lists, the chunk / piece walk of long writes and its staging spans, host-fed rings, the
-    sharded handle's routing and issuing threads, the effect handle — runs random plans through the C ABI (tests/host/host_fuzz.cpp) on the CPU.
-    "Device" memory is malloc'ed, so every upload and ring write of the host code is bounds-checked."""
+def _build_host_fuzz(tmp_path, sanitize):
+    """The library's five translation units host-only + the stub HIP runtime + the plan driver, linked into one sanitized executable."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "phonic_amd", "csrc")
-    flags = ["--cuda-host-only", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-             "-DPG_FAST_WAVES=2", "-Wno-unused", "-Wno-unused-command-line-argument"]
+    san = ["-fsanitize=" + sanitize] + (["-fno-sanitize-recover=undefined"] if "undefined" in sanitize else [])
+    flags = ["--cuda-host-only", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-DPG_FAST_WAVES=2", "-Wno-unused", "-Wno-unused-command-line-argument"] + san
     objs = []
     jobs = []
     for tu in ("pg_host", "pg_fxstate", "pg_effect", "pg_sharded", "pg_kernels"):
@@ -60,9 +56,29 @@ def test_host_side_of_the_library_under_asan_and_ubsan(tmp_path):
     fat = tmp_path / "fatbins.cpp"
     fat.write_text("".join(f"extern \"C\" const char {s}[16] = {{0}};\n" for s in sorted(set(u for u in undefined if u.startswith("__hip_fatbin_")))))
     exe = str(tmp_path / "host_fuzz")
-    link = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           os.path.join(ROOT, "tests", "host", "host_fuzz.cpp"), str(fat), stub] + objs + ["-o", exe, "-lpthread", "-ldl"], capture_output=True, text=True, timeout=600)
+    link = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g"] + san + [os.path.join(ROOT, "tests", "host", "host_fuzz.cpp"), str(fat), stub] + objs +
+                          ["-o", exe, "-lpthread", "-ldl"], capture_output=True, text=True, timeout=600)
     assert link.returncode == 0, link.stderr[-3000:]
+    return exe
+
+
+def test_host_side_of_the_library_under_asan_and_ubsan(tmp_path):
+    """The five translation units of libphonic_gpu compiled HOST-ONLY (hipcc --cuda-host-only: no device code) with -fsanitize=address,undefined and
+    linked against tests/host/hip_stub.cpp instead of the HIP runtime: the library's host logic — topology rebuilds, append-only id maps, the control
+    ring's drain, event queues and per-piece command lists, the chunk / piece walk of long writes and its staging spans, host-fed rings, the
+    sharded handle's routing and issuing threads, the effect handle — runs random plans through the C ABI (tests/host/host_fuzz.cpp) on the CPU.
+    "Device" memory is malloc'ed, so every upload and ring write of the host code is bounds-checked; LeakSanitizer watches the handles' lifetimes."""
+    exe = _build_host_fuzz(tmp_path, "address,undefined")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     run = subprocess.run([exe, "16", "220"], capture_output=True, text=True, timeout=900, env=env)
     assert run.returncode == 0 and "ok" in run.stdout, (run.stdout[-1000:], run.stderr[-4000:])
+
+
+def test_host_side_of_the_library_under_tsan(tmp_path):
+    """The same build under ThreadSanitizer: the sharded handle issues every shard from a thread of its own (job hand-over by an atomic sequence
+    number + condition variable, results read after the join), its id maps are append-only tables read without a lock, and per-device tables are
+    built under a mutex by whichever thread gets there first."""
+    exe = _build_host_fuzz(tmp_path, "thread")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    run = subprocess.run([exe, "10", "200"], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0 and "ok" in run.stdout and "ThreadSanitizer" not in run.stderr, (run.stdout[-1000:], run.stderr[-4000:])

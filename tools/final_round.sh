@@ -4,10 +4,10 @@ R=${1:-r02}
 O=gpurun_out/profiles_$R
 bash tools/profile_round.sh $R > /dev/null 2>&1
 bash tools/pmc_util.sh $R > /dev/null 2>&1
-python bench.py --workload c5 --scaling strong --total-voices 8192 --steps 32 --warmup 8 --no-cpu-baseline > $O/${R}_c5_8192v_bench.json 2>> $O/bench.err
-for w in c2 c3 c4 c5; do python bench.py --workload $w --steps 64 --warmup 16 --no-cpu-baseline > $O/${R}_${w}_bench.json 2>> $O/bench.err; done
-for v in 2048 4096; do python bench.py --voices $v --steps 64 --warmup 32 --repeats 3 --no-cpu-baseline > $O/${R}_headline_${v}v_bench.json 2>> $O/bench.err; done
-python bench.py --superblock 1 --steps 100 --warmup 20 --no-cpu-baseline > $O/${R}_headline_single_block_launches_bench.json 2>> $O/bench.err
+python bench.py --workload c5 --scaling strong --total-voices 8192 --steps 32 --warmup 8 --no-cpu-baseline --strong-c5-voices 0 > $O/${R}_c5_8192v_bench.json 2>> $O/bench.err
+for w in c2 c3 c4 c5; do python bench.py --workload $w --steps 64 --warmup 16 --no-cpu-baseline --strong-c5-voices 0 > $O/${R}_${w}_bench.json 2>> $O/bench.err; done
+for v in 2048 4096; do python bench.py --voices $v --steps 64 --warmup 32 --repeats 3 --no-cpu-baseline --strong-c5-voices 0 > $O/${R}_headline_${v}v_bench.json 2>> $O/bench.err; done
+python bench.py --superblock 1 --steps 100 --warmup 20 --no-cpu-baseline --strong-c5-voices 0 > $O/${R}_headline_single_block_launches_bench.json 2>> $O/bench.err
 # kernel traces of the two bus-chain workloads (the bus kernel is their dominant one) and the ring-stream micro-benchmark (what the memory system
 # gives the mid stage's access stream without its arithmetic)
 for w in c2 c4; do bash tools/ktrace.sh --workload $w --repeats 3 --steps 64 --warmup 32 > $O/${R}_${w}_kernel_trace.txt 2>&1; done

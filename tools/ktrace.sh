@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-realtime "$@" > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --strong-c5-voices 0 --no-realtime "$@" > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -5,7 +5,7 @@ i=0
 for c in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$i -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$i -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --strong-c5-voices 0 > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

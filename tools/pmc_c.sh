@@ -6,7 +6,7 @@ i=0
 for c in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmcw_$i
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcw_$i -- python3 bench.py --workload $W --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --no-realtime > /tmp/pmcw_$i.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcw_$i -- python3 bench.py --workload $W --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --strong-c5-voices 0 --no-realtime > /tmp/pmcw_$i.log 2>&1
   f=$(find /tmp/pmcw_$i -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

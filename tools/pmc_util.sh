@@ -11,7 +11,7 @@ i=0
 for c in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "VALUBusy" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
   rm -rf /tmp/pmcu_$i
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcu_$i -- python3 bench.py --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --no-realtime > /tmp/pmcu_$i.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcu_$i -- python3 bench.py --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --strong-c5-voices 0 --no-realtime > /tmp/pmcu_$i.log 2>&1
   f=$(find /tmp/pmcu_$i -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "# pass '$c' produced no counters" >> $OUT; continue; fi
   python3 - "$f" >> $OUT <<'PY'

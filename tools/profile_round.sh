@@ -6,7 +6,7 @@ O=gpurun_out/profiles_$R
 rm -rf $O; mkdir -p $O
 SB=16   # blocks per launch in the profiled runs (the counter passes need every steady-state dispatch to render the same number of blocks)
 : > $O/bench.err
-rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --no-realtime --repeats 3 --superblock $SB --steps 96 --warmup 32 > $O/${R}_headline_bench_under_rocprofv3.json 2>/tmp/kt.err
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --strong-c5-voices 0 --no-realtime --repeats 3 --superblock $SB --steps 96 --warmup 32 > $O/${R}_headline_bench_under_rocprofv3.json 2>/tmp/kt.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/${R}_headline_rocprofv3_kernel_stats.csv
 # per-dispatch durations of the dominant kernel: steady-state super-block dispatches only (the first rounds of a run are single blocks)
 python3 - $(find /tmp/kt -name "*kernel_trace.csv" | head -1) $SB > $O/${R}_headline_rocprofv3_dominant_kernel.json <<'PY'
@@ -21,7 +21,7 @@ print(json.dumps({"kernel": "pg_stage_fused_kernel", "dispatches": len(d), "supe
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 bench.py --superblock $SB --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --no-realtime > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 bench.py --superblock $SB --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --strong-c5-voices 0 --no-realtime > /tmp/pmc_$c.log 2>&1
   python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c $SB > $O/${R}_headline_pmc_$c.csv <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(list)
@@ -52,7 +52,7 @@ d = {"workload": "headline", "voices_per_gpu": 1024, "block_frames": 1024, "kern
      "calibration": "the same factors hold for THIS kernel's access pattern (8-byte lanes, 128-frame sub-chunks, 2 KB granules): tools/ringstream with a known byte count reads FETCH_SIZE x 1.94-2.17 (the spread = whether the vibrato look-ahead of up to 15 frames per window is counted as read twice) and WRITE_SIZE x 0.98-0.99 (partial lines at window edges) - profiles/r04_ringstream_pmc.json",
      "traffic_bytes_per_block": (2 * f + w) * 1024 if f and w else None,
      "algorithmic_bytes_per_block": 423.4 * 1024 * 1024,
-     "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --no-realtime (one pass per counter; per block = the 16-block dispatches / 16)"}
+     "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --superblock 16 --steps 64 --warmup 32 --repeats 2 --no-cpu-baseline --strong-c5-voices 0 --no-realtime (one pass per counter; per block = the 16-block dispatches / 16)"}
 json.dump(d, open(os.path.join(O, f"{R}_headline_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(d))
 PY
