@@ -40,7 +40,9 @@ int graph_quiesce(pg_graph* g) {
   (void)hipSetDevice(g->device);
   HIP_TRY(pg_stream_sync(g->stream));
   if (g->last_stream && g->last_stream != g->stream) HIP_TRY(pg_stream_sync(g->last_stream));
+  if (g->unit_stream) HIP_TRY(pg_stream_sync(g->unit_stream));   // (every launch there is awaited by a sum on the write's stream: drained already)
   g->cmds_since_sync = 0;
+  g->rows_free_fresh = false;
   return PG_OK;
 }
 
@@ -298,6 +300,12 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
   { const char* e = getenv("PHONIC_BUS_PIPELINE"); if (e && e[0] == '0') g->bus_pipeline = false; }
+  { const char* e = getenv("PHONIC_BUS_OVERLAP"); if (e && e[0] == '0') g->overlap_bus = false; }
+  { const char* e = getenv("PHONIC_BUS_GROUP"); if (e && atoi(e) > 0) g->bus_group = (uint64_t)atoi(e); }
+  if (hipStreamCreateWithFlags(&g->unit_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_units_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_rows_free, hipEventDisableTiming) != hipSuccess) {
+    g->overlap_bus = false;   // (not fatal: the launches stay on one stream)
+  }
   g->mixers.emplace_back();
   g->mixers[0].depth = 0;
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
@@ -331,6 +339,9 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->h_feedback) (void)pg_host_free(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : g->ev_bus_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (g->ev_units_done) (void)hipEventDestroy(g->ev_units_done);
+  if (g->ev_rows_free) (void)hipEventDestroy(g->ev_rows_free);
+  if (g->unit_stream) { (void)pg_stream_sync(g->unit_stream); (void)hipStreamDestroy(g->unit_stream); }
   (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -1319,8 +1330,9 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   if (g->last_stream && g->last_stream != stream) { if (pg_stream_sync(g->last_stream) != hipSuccess) { g->failed = true; return 0; } g->cmds_since_sync = 0; }
   g->last_stream = stream;
   if (begin) { graph_begin_write(g, pos); g->call_end = pos + n_samples / 2; }
-  if (g->topo_dirty && rebuild_topology(g, stream)) { g->failed = true; return 0; }
-  if (!g->stream_voices.empty() && flush_stream_feeds(g, stream)) { g->failed = true; return 0; }
+  if (g->topo_dirty) { g->rows_free_fresh = false; if (rebuild_topology(g, stream)) { g->failed = true; return 0; } }
+  if (!g->stream_voices.empty()) { g->rows_free_fresh = false; if (flush_stream_feeds(g, stream)) { g->failed = true; return 0; } }
+  if (g->overlap_stream != stream) { g->rows_free_fresh = false; g->overlap_stream = stream; }
   g->audible_valid = false;   // (a write that finds nothing to do launches nothing: the words an earlier call left are not this call's)
   if (graph_is_empty(g)) return 0;
   g->audible_valid = true;
@@ -1380,13 +1392,31 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       if (CH % mf == 0) k = (kmax * mf >= span && span % mf == 0) ? span / mf : (kmax / (CH / mf)) * (CH / mf);
       else k = (span % mf == 0 && span <= CH && span / mf <= kmax) ? span / mf : 0;
     }
+    // A small unit level in front of a bus chain (BASELINE configs 2 and 4: 64 / 256 voices, then a chain that takes four times as long as they
+    // do): launch sequences of a few chunks each, so that the chain of one runs over the unit kernels of the next INSIDE a call too
+    if (k > g->bus_group && CH % mf == 0 && g->overlap_bus && !g->defer_bus && !g->mixers[0].fx.empty() && g->n_graph_units <= 512) {
+      const uint64_t per_chunk = CH / mf;
+      k = std::max<uint64_t>(per_chunk, (g->bus_group / per_chunk) * per_chunk);
+    }
     if (k > 0) {
       LaunchSpan sp;
       sp.n = (uint32_t)mf; sp.t0 = now; sp.n_chunks = (int)k; sp.row_block = 0; sp.grid_off = 0; sp.grid_span = (uint32_t)std::min<uint64_t>(span, 0x7fffffffull);
       sp.round = g->launch_counter++;
       sp.generic_idle = true;  // (graph_super_ok: steady state, one level)
       sp.timed = g->timing_period > 0 && (g->launch_counter % (uint64_t)g->timing_period) == 0 && g->ev_used < g->ev_pool.size() && g->n_graph_units > 0;
-      if (launch_level(g, 0, sp, stream)) return fail();
+      // A bus chain behind the sum: this sequence's unit kernels go to the unit stream, UNDER the bus chain of the sequence before (they wait for
+      // its sum to have read the per-unit rows, not for its chain), and this sequence's sum waits for them
+      const bool overlap = g->overlap_bus && !g->defer_bus && !g->mixers[0].fx.empty() && k > 1;
+      if (overlap) {
+        if (!g->rows_free_fresh) HIP_TRY_FAIL(hipEventRecord(g->ev_rows_free, stream));   // (behind whatever the write's stream holds: one serialisation, then the pipeline runs)
+        HIP_TRY_FAIL(hipStreamWaitEvent(g->unit_stream, g->ev_rows_free, 0));
+        if (launch_level(g, 0, sp, g->unit_stream)) return fail();
+        HIP_TRY_FAIL(hipEventRecord(g->ev_units_done, g->unit_stream));
+        HIP_TRY_FAIL(hipStreamWaitEvent(stream, g->ev_units_done, 0));
+      } else {
+        if (launch_level(g, 0, sp, stream)) return fail();
+        g->rows_free_fresh = false;
+      }
       // where the blocks' `audible` words go: with the bus chain deferred to the caller, word c of the call belongs to its c-th block
       const int slot = g->defer_bus ? (int)std::min<uint64_t>(done / mf, (uint64_t)g->audible_slots - k) : 0;
       {
@@ -1394,11 +1424,13 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
         HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_out + done * 2, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
                                    g->d_audible + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride));
       }
+      if (overlap) { HIP_TRY_FAIL(hipEventRecord(g->ev_rows_free, stream)); g->rows_free_fresh = true; }
       if (!g->defer_bus && launch_bus(g, d_out + done * 2, sp, slot, stream)) return fail();
       done += k * mf;
       continue;
     }
     // ---- one chunk, piece by piece ----
+    g->rows_free_fresh = false;
     // A sub-mixer keeps one result bit per call of its parent: the chunk is bounded so that at most PG_MAX_CALLS - 1 call boundaries fall inside it
     if (g->levels.size() > 1) {
       std::vector<uint64_t> cuts;

@@ -244,6 +244,15 @@ struct pg_graph {
   size_t bus_frames = 0;        // frames the staging of pg_graph_write holds (whole chunks: >= PG_MAX_FRAMES)
   size_t audible_slots = 0;     // words of d_audible: one per block of a launch sequence / piece of a chunk
   bool audible_valid = false;   // the last write rendered (its `audible` words are in d_audible)
+  // Graphs with a bus chain, super-block launches: the unit kernels of launch sequence s + 1 run on a stream of their own UNDER the bus chain of
+  // sequence s (one workgroup per effect: the machine is all but idle while it walks the blocks). They need the sum of sequence s to have read
+  // the per-unit rows (ev_rows_free, recorded behind the mix launch, in front of the bus launch); the sum of s + 1 needs them done (ev_units_done).
+  hipStream_t unit_stream = nullptr;
+  hipEvent_t ev_units_done = nullptr, ev_rows_free = nullptr;
+  hipStream_t overlap_stream = nullptr;  // the write stream ev_rows_free was last recorded on
+  bool rows_free_fresh = false;  // ev_rows_free was recorded behind everything the caller's stream holds that the next unit launch must follow
+  uint64_t bus_group = 8;        // blocks per launch sequence of a small unit level in front of a bus chain (PHONIC_BUS_GROUP)
+  bool overlap_bus = true;       // PHONIC_BUS_OVERLAP=0 (read at create): everything on the caller's stream
   bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
   unsigned long long* d_bus_progress = nullptr;  // progress words of the pipelined bus chain (pg_bus_pipeline)

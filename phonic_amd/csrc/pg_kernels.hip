@@ -1162,6 +1162,12 @@ __device__ __forceinline__ void stage_fused_body(const PgLaunch& L) {
   __shared__ PgLaunch sL;  // for the out-of-line stage; the barriers in front of that stage make it visible
   if (threadIdx.x == 0) sL = L;
   const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
+#ifdef PG_STAGGER_US   // experiment: in a launch of ONE block every other workgroup starts PG_STAGGER_US microseconds late
+  if (n_chunks == 1 && (blockIdx.x & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(PG_STAGGER_US) * 100ull) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     PG_SLOT_STAMP(0);
     const int flags = stage1_run<TAG, true>(L, slot, si, chunk);
