@@ -391,17 +391,25 @@ __device__ __forceinline__ bool submixer_call_piece(PgUnit& unit, int* ur_call /
 }
 
 #define PG_MIN_ROW_FRAMES 64
+// What a workgroup of the fast kernels keeps from one block of a super-block launch to the next: the slot tables' entry and the unit record's
+// host-written words in registers; the LDS copies of the unit record, of the unit's voice and of its first two effects hold the state the block
+// left (every change also goes to global memory, as before). The later blocks then start without the two dependent trips to L2 at the head
+// of the body (slot tables -> records) and without re-staging what is already there — on a workgroup whose block is a latency chain
+// (C3: 6.5 K of 70 K cycles per block).
+struct PgUnitCarry { int4 si; int2 sf; uint32_t unit_w; int resident; int fx_valid; };   // fx_valid: the two effect slots were filled (the chain ran) in an earlier block
 template <bool FAST_ONLY, int KMASK>
-__device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, const int chunk = 0) {
+__device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, const int chunk, PgUnitCarry& carry) {
   if (slot >= L.n_units) return;
   const int tid = pg_tid(), nt = blockDim.x;
+  const bool resident = FAST_ONLY && chunk > 0 && carry.resident != 0;
   // Fast kernels: ONE trip names the unit, its first voice and its first two effects (slot_info / slot_fx, written by the host with the
   // topology); their records are then requested together — the unit record, the voice's state (one dword per lane) and the effect states (one
   // qword per lane each) used to be three dependent trips to L2 at the head of a kernel that is a latency chain.
   const bool tables = FAST_ONLY && L.slot_info != nullptr && L.slot_fx != nullptr;
   int4 si = make_int4(0, 0, 0, 0);
   int2 sf = make_int2(-1, -1);
-  if (tables) {
+  if (resident) { si = carry.si; sf = carry.sf; }
+  else if (tables) {
     si = L.slot_info[slot]; sf = L.slot_fx[slot];
     si.x = __builtin_amdgcn_readfirstlane(si.x); si.y = __builtin_amdgcn_readfirstlane(si.y); si.w = __builtin_amdgcn_readfirstlane(si.w);
     sf.x = __builtin_amdgcn_readfirstlane(sf.x); sf.y = __builtin_amdgcn_readfirstlane(sf.y);
@@ -413,7 +421,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   // whose block is a latency chain. What decides in front of the first barrier comes out of the register by v_readlane; the rest of the body
   // reads the copy in LDS (`ur`, visible behind that barrier): no register lives across the body for it.
   uint32_t unit_w = 0;
-  if ((tid & 63) < (int)(sizeof(PgUnit) / 4)) unit_w = ((const uint32_t*)&unit)[tid & 63];
+  if (resident) unit_w = carry.unit_w;   // (the words read in front of the first barrier are host-written: unchanged since the launch's first block)
+  else if ((tid & 63) < (int)(sizeof(PgUnit) / 4)) unit_w = ((const uint32_t*)&unit)[tid & 63];
 #define PG_UF(f) ((int)__builtin_amdgcn_readlane((int)unit_w, (int)(offsetof(PgUnit, f) / 4)))
 #define PG_UL(f) (ur[offsetof(PgUnit, f) / 4])
   const int u_static_defer = PG_UF(static_defer), u_maybe_ramping = PG_UF(maybe_ramping), u_fx0 = PG_UF(fx0), u_staged = PG_UF(staged), u_n_fx0 = PG_UF(n_fx), u_kind0 = PG_UF(kind);
@@ -421,7 +430,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   unsigned long long fx0_word = 0, fx1_word = 0;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
   static_assert(sizeof(PgFx) % 8 == 0 && sizeof(PgFx) / 8 <= 256, "PgFx must fit one qword per lane of the workgroup");
-  if (tables) {
+  if (tables && !resident) {
     if ((si.w & 0xffffff) > 0 && tid < (int)(sizeof(PgVoice) / 4)) voice_word = ((const uint32_t*)&L.voices[si.y])[tid];
     if (sf.x >= 0 && tid < n_fx_words / 2) fx0_word = ((const unsigned long long*)&L.fx[sf.x])[tid];
     if (sf.y >= 0 && tid < n_fx_words / 2) fx1_word = ((const unsigned long long*)&L.fx[sf.y])[tid];
@@ -436,11 +445,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   char* scratch = (char*)(tmp + 2 * NA);
   // fixed small areas at the start of scratch
   PgVoice* lv = (PgVoice*)scratch;                 scratch += (sizeof(PgVoice) + 15) & ~15ull;
-  PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
+  PgFx* lfx0 = (PgFx*)scratch;                     scratch += (sizeof(PgFx) + 15) & ~15ull;   // the chain's effects alternate between two slots: the first
+  PgFx* lfx1 = (PgFx*)scratch;                     scratch += (sizeof(PgFx) + 15) & ~15ull;   // two keep theirs (what a later block of the launch finds)
   int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
   int* ur = (int*)scratch;                         scratch += 128;  // copy of the unit record (sizeof(PgUnit) <= 128)
-  if (tid < (int)(sizeof(PgUnit) / 4)) ur[tid] = (int)unit_w;     // (read behind the barrier of the deferral decision / the block's first barrier)
+  if (!resident && tid < (int)(sizeof(PgUnit) / 4)) ur[tid] = (int)unit_w;     // (read behind the barrier of the deferral decision / the block's first barrier)
   SrcScratch S;
   src_carve(scratch, S);
   S.diag = L.diag;
@@ -451,7 +461,10 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   if (L.mode != 2) PG_STAMP(L.diag, 0);
 
   // ---- two-kernel protocol: the lean fast kernel defers units it cannot run to the generic kernel ----
-  if (FAST_ONLY) {
+  if (FAST_ONLY && resident) {
+    // (decided at the launch's first block: a super-block launch carries no commands, and nothing between its blocks changes what decides)
+  } else if (FAST_ONLY) {
+    carry.resident = 0; carry.fx_valid = 0;
     if (u_staged && u_staged <= L.staged_on) return;  // rendered by the stage kernels of this round
     if (tid == 0) {
       // Ramps only start with a parameter command, and commands are always rendered (and the ramp state re-evaluated at the
@@ -465,6 +478,9 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     }
     __syncthreads();
     if (!ctl[5]) return;
+    // the later blocks of this launch find the records where this one leaves them: one voice at most (its LDS copy), two effects at most (their slots)
+    carry.si = si; carry.sf = sf; carry.unit_w = unit_w;
+    carry.resident = (tables && L.n_chunks > 1 && (si.w & 0xffffff) <= 1 && u_n_fx0 <= 2) ? 1 : 0;
   } else if (L.mode == 2) {
     if (tid == 0) { ctl[5] = unit.deferred; unit.deferred = 0; }
     __syncthreads();
@@ -589,7 +605,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       int later = 0;
       for (int vi = 0; vi < PG_UL(n_voices); ++vi) {
         PgVoice* gv = &L.voices[vi == 0 ? PG_UL(voice0) : L.voice_index[PG_UL(voice_off) + vi]];
-        const int r = voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos, seg_first, seg_chunk_end);
+        const int r = voice_process<!FAST_ONLY, (FAST_ONLY && KMASK == (0x7ff & ~((1 << 5) | (1 << 7)))) ? 1 : 2>(gv, lv, sseg, tmp, seg, pos, S, L.sched, L.sched_bank, tables && vi == 0, voice_word, call_end_pos, seg_first, seg_chunk_end,
+                                                                                                                      resident && vi == 0);
         audible_input |= (r & 1) != 0;
         later |= r & 2;
       }
@@ -613,10 +630,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
         for (int fi = 0; fi < PG_UL(n_fx); ++fi) {
           // stage the effect's state block in LDS: the per-block bookkeeping of lane 0 (smoother checks, coefficient and
           // delay-length updates, ring positions) then costs LDS instead of HBM round trips; written back afterwards
-          PgFx& gfx = L.fx[L.fx_index[PG_UL(fx_off) + fi]];
+          PgFx& gfx = (resident && fi < 2) ? L.fx[fi == 0 ? sf.x : sf.y] : L.fx[L.fx_index[PG_UL(fx_off) + fi]];   // (resident: no trip through the index table)
+          PgFx* const lfx = (fi & 1) ? lfx1 : lfx0;
           __syncthreads();
-          if (fi == 0 && FAST_ONLY) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; }
-          else if (fi == 1 && tables && sf.y >= 0) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx1_word; }
+          if (resident && fi < 2 && carry.fx_valid) { /* the slot holds what an earlier block of the launch left */ }
+          else if (!resident && fi == 0 && FAST_ONLY) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx0_word; }
+          else if (!resident && fi == 1 && tables && sf.y >= 0) { if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fx1_word; }
           else for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];
           __syncthreads();
           PgFx& fx = *lfx;
@@ -635,6 +654,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           __syncthreads();
           for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
         }
+        carry.fx_valid = 1;
         __syncthreads();
         // (the chain's result counts from the next chunk on: the later pieces of this one still see the flag the chunk began with)
         if (tid == 0 && seg_last) { unit.effects_bypassed = all_bypassed ? 1 : 0; PG_UL(effects_bypassed) = all_bypassed ? 1 : 0; }   // (the segment loop ends in a barrier)
@@ -705,12 +725,16 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 // Super-block launches (L.n_chunks > 1): the workgroup renders its unit's consecutive blocks one after the other; everything a block
 // leaves behind (effect / voice / unit state) went to global memory and is read back by the same workgroup after a barrier.
 __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast(PgLaunch L) {
-  pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, 0);
-  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, c); }
+  PgUnitCarry carry;
+  carry.resident = 0; carry.fx_valid = 0;
+  pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, 0, carry);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_LEAN>(L, (int)blockIdx.x, c, carry); }
 }
 __global__ void __launch_bounds__(256, PG_FAST_WAVES) pg_unit_kernel_fast_wide(PgLaunch L) {
-  pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, 0);
-  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, c); }
+  PgUnitCarry carry;
+  carry.resident = 0; carry.fx_valid = 0;
+  pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, 0, carry);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_ALL>(L, (int)blockIdx.x, c, carry); }
 }
 // Chains without Reverb and Compressor (C3: Filter -> Chorus per voice): those two carry the large register footprints and LDS arenas.
 // Without them the same body compiles for four workgroups per CU (128 VGPRs) and its arena fits 40 KB.
@@ -720,8 +744,10 @@ static_assert(PG_KMASK_MID == (0x7ff & ~((1 << 5) | (1 << 7))), "pg_unit_body's 
 #define PG_MID_WAVES 4
 #endif
 __global__ void __launch_bounds__(256, PG_MID_WAVES) pg_unit_kernel_fast_mid(PgLaunch L) {
-  pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, 0);
-  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, c); }
+  PgUnitCarry carry;
+  carry.resident = 0; carry.fx_valid = 0;
+  pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, 0, carry);
+  for (int c = 1; c < L.n_chunks; ++c) { __syncthreads(); pg_unit_body<true, PG_KMASK_MID>(L, (int)blockIdx.x, c, carry); }
 }
 // The main mixer's effect chain behind a super-block launch as a PIPELINE over the blocks: workgroup f runs effect f of the chain over the
 // summed blocks 0, 1, 2 ... in order and hands block c on to workgroup f + 1 through the bus buffer itself (in place) and a progress word —
@@ -809,7 +835,9 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
       if (L.host_feedback) { *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n; __threadfence_system(); }
     }
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-      pg_unit_body<false, PG_KMASK_GENERIC>(L, L.defer_list[i]);
+      PgUnitCarry carry;
+      carry.resident = 0; carry.fx_valid = 0;
+      pg_unit_body<false, PG_KMASK_GENERIC>(L, L.defer_list[i], 0, carry);
       __syncthreads();
     }
     return;
@@ -819,7 +847,9 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
   for (int slot = (int)blockIdx.x; slot < L.n_units; slot += (int)gridDim.x) {
     for (int c = 0; c < n_chunks; ++c) {
-      pg_unit_body<false, PG_KMASK_GENERIC>(L, slot, c);
+      PgUnitCarry carry;
+      carry.resident = 0; carry.fx_valid = 0;
+      pg_unit_body<false, PG_KMASK_GENERIC>(L, slot, c, carry);
       __syncthreads();
     }
   }
@@ -1301,7 +1331,7 @@ size_t pg_fast_scratch_bytes(uint32_t kind_mask) {
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes) {
   if (n_frames < PG_MIN_ROW_FRAMES) n_frames = PG_MIN_ROW_FRAMES;
   static_assert(sizeof(PgUnit) <= 128, "pg_unit_body keeps a copy of the unit record in 128 bytes of LDS");
-  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64 + 128;
+  size_t fixed = ((sizeof(PgVoice) + 15) & ~15ull) + 2 * ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64 + 128;
   size_t scratch = pg_fast_scratch_bytes(0xffffffffu);  // the full arena: the largest any effect kind carves up
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);

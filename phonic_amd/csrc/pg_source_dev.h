@@ -967,13 +967,13 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
 template <bool GLIDE, int ADAPTERS = 2>
 DEVO int voice_process(PgVoice* gv, PgVoice* lv /*LDS*/, float* sig, float* tmp, int frames, uint64_t pos, const SrcScratch& S0,
                        const PgSchedEntry* sched, int sched_bank, bool have_word = false, uint32_t word = 0, uint64_t call_end = 0, bool chunk_first = true,
-                       uint64_t chunk_end = 0) {
+                       uint64_t chunk_end = 0, bool in_lds = false) {
   SrcScratch S = S0;
   const int tid = pg_tid(), nt = blockDim.x;
   static_assert(sizeof(PgVoice) / 4 <= 256, "one dword per lane");
   __syncthreads();
-  {  // stage the voice state into LDS (uniform reads, lane-0 writes); `word` = this lane's dword when the caller prefetched it
-    const uint32_t* src = (const uint32_t*)gv;
+  if (!in_lds) {  // stage the voice state into LDS (uniform reads, lane-0 writes); `word` = this lane's dword when the caller prefetched it
+    const uint32_t* src = (const uint32_t*)gv;      // (in_lds: the copy is what the launch's previous block left there)
     uint32_t* dst = (uint32_t*)lv;
     if (have_word) { if (tid < (int)(sizeof(PgVoice) / 4)) dst[tid] = word; }
     else for (int i = tid; i < (int)(sizeof(PgVoice) / 4); i += nt) dst[i] = src[i];
