@@ -6,16 +6,18 @@ from phonic_amd.graph import Graph
 from phonic_amd import _capi
 import workloads
 V=int(sys.argv[1]) if len(sys.argv)>1 else 1024
+K=int(sys.argv[2]) if len(sys.argv)>2 else 1    # blocks per call: > 1 = super-block launches (the stamps are those of the launch's LAST block)
 g=Graph(48000,2,1024,0)
+g.set_max_blocks_per_launch(max(K,1))
 workloads.build_c3(g,V,0,V)
 lib=_capi.load()
 lib.pg_graph_diag.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.c_int]
 buf=(C.c_uint64*64)()
 lib.pg_graph_diag(g._h,buf,64)
-bus=torch.zeros(2048,device='cuda:0')
+bus=torch.zeros(2048*K,device='cuda:0')
 pos=0
 for i in range(20):
-    g.write_device(bus.data_ptr(),2048,pos); pos+=1024
+    g.write_device(bus.data_ptr(),2048*K,pos); pos+=1024*K
 g.synchronize()
 lib.pg_graph_diag(g._h,buf,64)
 t=[int(buf[i]) for i in range(64)]
