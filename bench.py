@@ -87,6 +87,28 @@ def pmc_traffic(name, v_per_gpu, block):
     return None, (f"no PMC pass recorded for source hash {have}" + (f" (latest: {stale}, other build)" if stale else ""))
 
 
+def effective_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup's CPU quota (a GPU box of the pool shows 256 CPUs
+    and grants 16 of them: cpu.max = "1600000 100000") — the thread count of the all-core CPU baseline and the `cores` it reports."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(name, block, seconds_budget=12.0):
     """Times the CPU oracle on a bounded sample of the same workload: (a) with all host cores (one graph per core), about `seconds_budget`
     seconds, and (b) on ONE thread (one graph), about a third of that. A short run calibrates each block count on this host.
@@ -99,7 +121,7 @@ def cpu_baseline(name, block, seconds_budget=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
 
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     lib, flags = oracle.lib_native()
     per_graph = {"headline": 4, "c2": 16, "c3": 8, "c4": 32, "c5": 2}[name]
 
