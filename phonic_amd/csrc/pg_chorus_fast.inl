@@ -59,6 +59,20 @@ DEVO bool chorus_fast_eligible(const PgFx& fx) {
   return floorf(2.0f + delay_in_samples) >= 66.0f && (2.0f + delay_in_samples + 2.0f * depth_in_samples) < (float)(c.mask - 8);
 }
 
+// The same test made by a whole wave (every wave of the workgroup calls it and gets the same answer): lane l looks at smoother l mod 8 — the
+// eight sit side by side in PgChorus — instead of every lane walking all eight one after the other (1.5 K cycles at the head of a chorus whose
+// unit's block is a latency chain).
+DEVO bool chorus_fast_eligible_wave(const PgFx& fx) {
+  const PgChorus& c = fx.u.chorus;
+  const PgSmooth* sm = &c.rate;
+  static_assert(offsetof(PgChorus, res) - offsetof(PgChorus, rate) == 7 * sizeof(PgSmooth), "the eight smoothers of PgChorus are contiguous");
+  if (__ballot(sm_need_ramp(sm[pg_tid() & 7]) ? 1 : 0) != 0ull) return false;
+  const float delay_in_samples = c.delay.target * (float)fx.sample_rate * 0.001f;
+  const float depth_in_samples = c.lfo_range * c.depth.target;
+  if (!(depth_in_samples >= 0.0f)) return false;
+  return floorf(2.0f + delay_in_samples) >= 66.0f && (2.0f + delay_in_samples + 2.0f * depth_in_samples) < (float)(c.mask - 8);
+}
+
 // ---- ChorusEffect while parameters ramp (chorus.rs:311-394 with any of its eight smoothers moving) ------------------------------------------
 // As for the Delay: single lanes lay out the per-frame value sequences of a piece with the serial loop's own calls — delay (spring), depth,
 // feedback, wet; the two LFO values incl. update_lfos while rate / phase ramp (chorus.rs:223-231: the oscillators are re-seated on
@@ -213,7 +227,7 @@ DEVO bool chorus_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
 }
 
 DEVO bool chorus_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
-  if (!chorus_fast_eligible(fx)) return false;
+  if (!chorus_fast_eligible_wave(fx)) return false;
   PgChorus& c = fx.u.chorus;
   const int tid = pg_tid(), nt = blockDim.x;
   const int frames = n_samples / 2;

@@ -356,6 +356,8 @@ extern __shared__ __attribute__((aligned(16))) char pg_smem[];
 __device__ __forceinline__ bool submixer_call_piece(PgUnit& unit, int* ur_call /* LDS copy of {call_max, call_frames} */, const float* sig, float* out, int a, int b, bool closes,
                                                      uint32_t sample_rate, size_t table_stride, int piece_frames, int* ctl, float* red) {
   const int tid = pg_tid(), nt = blockDim.x;
+  // (the piece's samples go out while its peak is found: a call that closes below the gate — 2 s of silence, once — takes them back below)
+  for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = sig[i];
   const float max_sample = wg_max_abs(sig + 2 * a, 2 * (b - a), red);
   if (tid == 0) {
     const float peak = fmaxf(max_sample, __int_as_float(ur_call[0]));
@@ -374,8 +376,7 @@ __device__ __forceinline__ bool submixer_call_piece(PgUnit& unit, int* ur_call /
   }
   __syncthreads();
   const bool audible = ctl[3] != 0;
-  if (audible) { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = sig[i]; }
-  else { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = 0.0f; }
+  if (!audible) { for (int i = 2 * a + tid; i < 2 * b; i += nt) out[i] = 0.0f; }
   int back = ctl[4];
   if (back > 0 && a == 0) {  // (a call that began in an earlier piece reaches this one at its frame 0)
     float* row = out;
