@@ -385,10 +385,10 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       }
       __syncthreads();
     }
-    // 1. taps + interpolation (delay.rs:118-134)
-    for (int s = tid; s < 2 * T; s += nt) {
+    // 1. taps + interpolation (delay.rs:118-134). Four items per lane and trip: their eight line reads are in flight together — one item per
+    // trip made the block's eight trips eight consecutive round trips through the loaded memory system (the staged kernels' stage 1 is a latency chain)
+    auto tap = [&](int s, uint32_t& i1, uint32_t& i2) -> double {   // read position of item s: line index of the two taps, returns the fraction
       const int nn = s >> 1, ch = s & 1;
-      const gdouble* line = (const gdouble*)d.line[ch];
       const uint32_t wp = (wp0[ch] + (uint32_t)nn) & mask;
       float delay_samples_n = delay_samples;
       if (time_depth != 0.0f) {  // delay.rs:349-352
@@ -398,13 +398,34 @@ DEVO bool delay_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       }
       const double read_pos = (double)wp - (double)delay_samples_n;
       const double read_pos_floor = floor(read_pos);
-      const double fraction = read_pos - read_pos_floor;
       const long long index1 = (long long)read_pos_floor;
-      const uint32_t i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
-      const uint32_t i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
-      if (fc.idx_log) fc.idx_log[(done + nn) * 2 + ch] = (int32_t)i1;  // test hook: read_idx1 of InterpolatedDelayLine::process (dsp/delay.rs:120-133)
-      const double v1 = line[i1], v2 = line[i2];
-      buf[REV_IDX(nn, ch)] = (double)(float)(v1 + (v2 - v1) * fraction);
+      i1 = (uint32_t)((unsigned long long)index1 & (unsigned long long)mask);
+      i2 = (uint32_t)((unsigned long long)(index1 + 1) & (unsigned long long)mask);
+      return read_pos - read_pos_floor;
+    };
+    for (int sb = tid; sb < 2 * T; sb += 4 * nt) {
+      double v1[4], v2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s = sb + q * nt;
+        v1[q] = 0.0; v2[q] = 0.0;
+        if (s < 2 * T) {
+          uint32_t i1, i2;
+          (void)tap(s, i1, i2);
+          const gdouble* line = (const gdouble*)d.line[s & 1];
+          if (fc.idx_log) fc.idx_log[(done + (s >> 1)) * 2 + (s & 1)] = (int32_t)i1;  // test hook: read_idx1 of InterpolatedDelayLine::process (dsp/delay.rs:120-133)
+          v1[q] = line[i1]; v2[q] = line[i2];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s = sb + q * nt;
+        if (s < 2 * T) {
+          uint32_t i1, i2;
+          const double fraction = tap(s, i1, i2);   // (recomputed: cheaper than four f64 fractions kept live under the loads)
+          buf[REV_IDX(s >> 1, s & 1)] = (double)(float)(v1[q] + (v2[q] - v1[q]) * fraction);
+        }
+      }
     }
     __syncthreads();
     // 2. wet path

@@ -356,6 +356,8 @@ struct PgLaunch {
   unsigned long long* bus_progress;  // mode 3 (pipelined bus chain): [n_fx] words (round << 32 | any effect active << 31 | blocks done), device memory
   const int2* slot_fx;    // [n_units] per launch slot: device indices of the unit's first two effects (-1: none) — with slot_info the fast kernels
                           // request unit record, first voice and the first two effect states side by side instead of one after the other
+  const int4* slot_lead;  // [n_units] per launch slot, staged units: device indices of the first three effects in FRONT of the reverb (-1: none) —
+                          // stage 1 requests their state blocks when the workgroup starts (LDS-DMA), under the source stage
   uint64_t bus_unit_stride;  // floats between the external buffers of consecutive units of the launch (a standalone effect with more than two
                              // channels runs one stereo unit per channel pair); 0 for the bus
   // Chunk grid of the main mixer (see PG_MAX_FRAMES): block 0 of the launch starts grid_off frames behind a chunk start, chunks of

@@ -48,11 +48,14 @@ DEVO void biquad_chain_fast(float* sig, int n_samples, const PgBiquadCoef* coefs
   for (int done = 0; done < frames; done += 1024) {
     const int T = frames - done < 1024 ? frames - done : 1024;
     __syncthreads();
+    if (n_stages == 1) PG_STAMP(fc.diag, 43);
     for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
     if (tid < 2 * n_stages) lst[tid] = st[(tid & 1) * st_stride + (tid >> 1)];
     __syncthreads();
+    if (n_stages == 1) PG_STAMP(fc.diag, 44);
     for (int k = 0; k < n_stages; ++k) rev_biquad_scan_t<true>(coefs[k], lst + 2 * k, buf, T, xchg + 4 * (k & 1));  // (a lane's pass 1 reads what its own pass 2 wrote)
     __syncthreads();
+    if (n_stages == 1) PG_STAMP(fc.diag, 45);
     if (tid < 2 * n_stages) st[(tid & 1) * st_stride + (tid >> 1)] = lst[tid];
     for (int s = tid; s < 2 * T; s += nt) sig[2 * done + s] = (float)buf[REV_IDX(s >> 1, s & 1)];
   }

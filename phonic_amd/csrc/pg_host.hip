@@ -172,6 +172,13 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
       sfx.push_back(make_int2(u.n_fx > 0 ? fidx[u.fx_off] : -1, u.n_fx > 1 ? fidx[u.fx_off + 1] : -1));
     }
     if ((rc = g->d_slot_fx.upload_async(sfx, stream))) return rc;
+    std::vector<int4> lead;
+    for (int slot : g->order) {
+      const PgUnit& u = topo[slot];
+      auto at = [&](int k) { return (u.staged && k + 1 < u.n_fx) ? fidx[u.fx_off + k] : -1; };
+      lead.push_back(make_int4(at(0), at(1), at(2), 0));
+    }
+    if ((rc = g->d_slot_lead.upload_async(lead, stream))) return rc;
   }
   g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
   for (Level& lv : g->levels) {
@@ -208,7 +215,7 @@ static size_t graph_table_blocks(const pg_graph* g) { return std::max<size_t>(g-
 static int graph_reserve(pg_graph* g) {
   int rc;
   const size_t n_units = g->h_units.size(), n_voices = g->voices.size(), n_fx = g->fx.size(), n_mixers = g->mixers.size();
-  if ((rc = g->d_topo.reserve(n_units)) || (rc = g->d_order.reserve(n_units)) || (rc = g->d_slot_info.reserve(n_units)) || (rc = g->d_slot_fx.reserve(n_units)) ||
+  if ((rc = g->d_topo.reserve(n_units)) || (rc = g->d_order.reserve(n_units)) || (rc = g->d_slot_info.reserve(n_units)) || (rc = g->d_slot_fx.reserve(n_units)) || (rc = g->d_slot_lead.reserve(n_units)) ||
       (rc = g->d_voice_index.reserve(n_voices)) || (rc = g->d_fx_index.reserve(n_fx)) || (rc = g->d_child_rows.reserve(n_mixers)))
     return rc;
   if (!g->d_cmd_ring) {
@@ -322,7 +329,7 @@ void pg_graph_destroy(pg_graph* g) {
   for (auto& v : g->voices) { if (v.d_pcm) (void)pg_free(v.d_pcm); if (v.d_stage) (void)pg_free(v.d_stage); if (v.h_ring) (void)pg_host_free(v.h_ring); }
   for (auto& f : g->fx) if (f->d_mem) (void)pg_free(f->d_mem);
   g->d_units.release(); g->d_voices.release(); g->d_fx.release(); g->d_voice_index.release(); g->d_fx_index.release(); g->d_order.release();
-  g->d_sched.release(); g->d_slot_info.release(); g->d_slot_fx.release(); g->d_child_rows.release(); g->d_topo.release();
+  g->d_sched.release(); g->d_slot_info.release(); g->d_slot_fx.release(); g->d_slot_lead.release(); g->d_child_rows.release(); g->d_topo.release();
   if (g->d_cmd_ring) (void)pg_free(g->d_cmd_ring);
   if (g->d_cmd_overflow) (void)pg_free(g->d_cmd_overflow);
   if (g->h_cmd_ring) (void)pg_host_free(g->h_cmd_ring);
@@ -878,8 +885,9 @@ int pg_graph_set_max_blocks_per_launch(pg_graph* g, int n_blocks) {
   return graph_reserve(g);  // the per-unit output table grows here, never inside write
 }
 // dynamic LDS of the launches whose occupancy is budgeted (tools/check_kernel_resources.py): which 0 = the staged single launch, 1 = a fast unit
-// kernel for the effect kinds of `kind_mask`
+// kernel for the effect kinds of `kind_mask`, 2 = the wide staged single launch
 size_t pg_debug_lds_bytes(int which, uint32_t n_frames, uint32_t kind_mask) {
+  if (which == 2) return pg_stage_lds_bytes(0, n_frames, true);   // the wide staged single launch
   return which == 0 ? pg_stage_lds_bytes(0, n_frames) : pg_unit_lds_bytes(n_frames, pg_fast_scratch_bytes(kind_mask));
 }
 // (a process-wide fault injector has no business in a production process: it only arms when PHONIC_DEBUG_HOOKS=1 is in the environment)
@@ -1111,7 +1119,7 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
   L.n_units = lv.cnt; L.unit_order = g->d_order.d + lv.off;
   L.unit_out = g->d_unit_out + (size_t)sp.row_block * (size_t)L.chunk_stride + (size_t)lv.off * g->stride;
   L.audible_tab = g->d_audible_tab + (size_t)sp.row_block * g->unit_out_rows + lv.off; L.audible_stride = g->unit_out_rows;
-  L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off;
+  L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off; L.slot_lead = g->d_slot_lead.d + lv.off;
   if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
   g->defer_phase++;
   // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units

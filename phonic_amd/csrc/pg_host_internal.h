@@ -28,6 +28,7 @@ using namespace pgh;
 size_t pg_fast_scratch_bytes(uint32_t kind_mask);
 size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames);
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide);  // wide: the staged kernel that renders effects in front of the reverb (their state slots)
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
@@ -231,6 +232,7 @@ struct pg_graph {
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceTable<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}
   DeviceTable<int2> d_slot_fx;    // per launch slot: {first effect, second effect} (device indices, -1: none)
+  DeviceTable<int4> d_slot_lead;  // per launch slot, staged units: the first three effects in front of the reverb (device indices, -1: none)
   DeviceTable<int2> d_child_rows; // nested sub-mixers: {output row, unit slot}, indexed by PgUnit::child_off
   DeviceTable<PgUnit> d_topo;     // topology fields of every unit, patched into d_units by pg_patch_units_kernel
   std::vector<Level> levels;    // deepest first

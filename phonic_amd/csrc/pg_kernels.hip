@@ -881,6 +881,7 @@ __device__ __forceinline__ void stage_load_image(double* lds, const double* g, i
   const int n2 = (stage_image_doubles(T) + 1) >> 1;
   for (int i = pg_tid(); i < n2; i += blockDim.x) ((double2*)lds)[i] = ((const double2*)g)[i];
 }
+constexpr int PG_STAGE_LEAD = 3;  // state blocks of effects in front of the reverb that stage 1 requests ahead (slot_lead)
 constexpr size_t STAGE_ARENA_PREFIX = (size_t)REV_BUF_DOUBLES * 8 + 16 * sizeof(RevRec) + 16 * 8 + 13 * sizeof(RevDesc) + 4 * 8;  // bufA .. xchg
 constexpr size_t STAGE_FIXED = ((sizeof(PgFx) + 15) & ~15ull) + 128 + 64;
 constexpr size_t STAGE1_UNION = ((SRC_SCRATCH_BYTES > STAGE_ARENA_PREFIX ? SRC_SCRATCH_BYTES : STAGE_ARENA_PREFIX) + 15) & ~15ull;
@@ -924,6 +925,25 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   float* sig = (float*)(m0.arena + STAGE1_UNION);
   float* tmp = sig + 2 * N;
   PgVoice* lv = (PgVoice*)(tmp + 2 * N);
+  // The effects in front of the reverb (wide kernel; C5: Filter -> Eq5 -> Delay): their state blocks used to be fetched one after the other,
+  // each behind the index table and behind the write-back of the one before — two dependent trips through the loaded memory system per
+  // effect on a workgroup whose stage 1 is a latency chain. The host names the first three in the slot table; they travel global -> LDS
+  // directly (no registers, nothing waits here) while the source stage runs, into slots behind the voice record (pg_stage_lds_bytes).
+  PgFx* const lead = (PgFx*)((char*)lv + ((sizeof(PgVoice) + 15) & ~15ull));
+  int lead0 = -1, lead1 = -1, lead2 = -1;
+  if (TAG == 3) {
+    const int4 sl = L.slot_lead[slot];
+    lead0 = __builtin_amdgcn_readfirstlane(sl.x); lead1 = __builtin_amdgcn_readfirstlane(sl.y); lead2 = __builtin_amdgcn_readfirstlane(sl.z);
+#pragma unroll
+    for (int k = 0; k < PG_STAGE_LEAD; ++k) {
+      const int li = k == 0 ? lead0 : k == 1 ? lead1 : lead2;
+      if (li < 0) continue;
+      const float* src = (const float*)&L.fx[li];
+      float* dst = (float*)(lead + k);
+#pragma unroll
+      for (int w = 0; w < n_fx_words; w += 256) if (w + tid < n_fx_words) lds_dma_dword(src + w + tid, dst + w + (tid & ~63));
+    }
+  }
   SrcScratch S;
   src_carve(m0.arena, S);
   S.diag = L.diag;
@@ -941,7 +961,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     ctl[5] = ok;
   }
   __syncthreads();
-  if (!ctl[5]) return -1;
+  if (!ctl[5]) { if (TAG == 3) lds_dma_wait(); return -1; }   // (nothing may still be on its way into LDS when the workgroup moves on)
   // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
   const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
   const int chunk_audible_input = unit.chunk_audible_input;
@@ -961,6 +981,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   if (pc.first) { audible_input = audible_input || later != 0; if (tid == 0) unit.chunk_audible_input = audible_input ? 1 : 0; }
   else audible_input = chunk_audible_input != 0;
   PG_STAMP(L.diag, 1);
+  if (TAG == 3) lds_dma_wait();   // the leading effects' state blocks (requested in front of the source stage: long there); the loop's first barrier publishes them
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
   if (pc.first) flags |= PG_STAGE_FIRST;
   if (pc.last) flags |= PG_STAGE_LAST;
@@ -969,24 +990,30 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   else {
     bool all_bypassed = true;
     for (int fi = 0; fi + 1 < n_fx; ++fi) {  // leading effects
-      PgFx& g1 = L.fx[L.fx_index[fx_off + fi]];
+      const int li = fi == 0 ? lead0 : fi == 1 ? lead1 : fi == 2 ? lead2 : -1;
+      const bool pre = TAG == 3 && li >= 0;
+      PgFx& g1 = L.fx[pre ? li : L.fx_index[fx_off + fi]];
+      PgFx* const cfx = pre ? lead + fi : lfx;
       __syncthreads();
-      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&g1)[i];
+      if (!pre) for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)cfx)[i] = ((const uint32_t*)&g1)[i];
       __syncthreads();
+      if (fi == 0) PG_STAMP(L.diag, 46);
       bool is_active;
       constexpr int KM = TAG == 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
-      if (lfx->standalone) {
+      if (cfx->standalone) {
         __syncthreads();
-        if (tid == 0) fx_call_begin(*lfx);
+        if (tid == 0) fx_call_begin(*cfx);
         __syncthreads();
-        fx_process_wg<true, KM>(*lfx, sig, N * 2, fc, L.fast, true);
-        if (tid == 0) lfx->call_ramp = 0;
+        fx_process_wg<true, KM>(*cfx, sig, N * 2, fc, L.fast, true);
+        if (tid == 0) cfx->call_ramp = 0;
         is_active = true;
       }
-      else is_active = fx_processor_process<true, KM>(*lfx, sig, N * 2, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
+      else is_active = fx_processor_process<true, KM>(*cfx, sig, N * 2, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
       if (is_active) { input_bypassed = false; all_bypassed = false; }
       __syncthreads();
-      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&g1)[i] = ((const uint32_t*)lfx)[i];
+      if (fi == 0) PG_STAMP(L.diag, 47);
+      for (int i = tid; i < n_fx_words; i += nt) ((uint32_t*)&g1)[i] = ((const uint32_t*)cfx)[i];
+      PG_STAMP(L.diag, 40 + fi);
     }
     __syncthreads();
     if (tid < n_fx_words / 2) ((unsigned long long*)lfx)[tid] = fxr_word;
@@ -1337,8 +1364,10 @@ size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes) {
   if (scratch_bytes && scratch_bytes < scratch) scratch = scratch_bytes < SRC_SCRATCH_BYTES ? SRC_SCRATCH_BYTES : scratch_bytes;
   return (size_t)n_frames * 16 + fixed + ((scratch + 15) & ~15ull);
 }
-size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) {
-  const size_t s1 = STAGE_FIXED + STAGE1_UNION + (size_t)n_frames * 16 + ((sizeof(PgVoice) + 15) & ~15ull);
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide);
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames) { return pg_stage_lds_bytes(stage, n_frames, false); }
+size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide) {
+  const size_t s1 = STAGE_FIXED + STAGE1_UNION + (size_t)n_frames * 16 + ((sizeof(PgVoice) + 15) & ~15ull) + (wide ? PG_STAGE_LEAD * sizeof(PgFx) : 0);  // (wide kernel: + the leading effects' state slots)
   const size_t s2 = STAGE_FIXED + ((FAST_SCRATCH_BYTES + 15) & ~15ull);
   const size_t s3 = STAGE_FIXED + ((STAGE_ARENA_PREFIX + 15) & ~15ull) + (size_t)n_frames * 8;
   if (stage == 1) return s1;
@@ -1374,7 +1403,7 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
     // ev0/ev1 (only passed when exactly one of the two launches happens): start / stop timestamps taken from the dispatch itself —
     // no marker packets in the stream, which cost ~7 us per round with hipEventRecord
     if (lean) hipExtLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, ev0, ev1, 0, L);
-    if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, lean ? nullptr : ev0, lean ? nullptr : ev1, 0, L);
+    if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, lean ? nullptr : ev0, lean ? nullptr : ev1, 0, L);
   } else {
     hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
     hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);
