@@ -301,6 +301,7 @@ struct PgCmd {
   uint64_t value64;
 };
 
+#define PG_BUS_PIPELINE_MAX 16  // effects of a bus chain the pipelined launch takes (one workgroup each); longer chains stay one workgroup
 struct PgLaunch {
   PgUnit* units;
   PgVoice* voices;
@@ -353,7 +354,8 @@ struct PgLaunch {
   // chain behind a super-block launch sees every block's own flag. nullptr: not collected (standalone effects, bus launches).
   int32_t* audible_tab;
   uint64_t audible_stride;
-  unsigned long long* bus_progress;  // mode 3 (pipelined bus chain): [n_fx] words (round << 32 | any effect active << 31 | blocks done), device memory
+  unsigned long long* bus_progress;  // mode 3 (pipelined bus chain): [PG_BUS_PIPELINE_MAX] words (round << 32 | `active` flags of the last 24 blocks << 8 | blocks done), then
+                                     // [PG_BUS_PIPELINE_MAX] words with one `active` flag per block of the launch; device memory
   const int2* slot_fx;    // [n_units] per launch slot: device indices of the unit's first two effects (-1: none) — with slot_info the fast kernels
                           // request unit record, first voice and the first two effect states side by side instead of one after the other
   const int4* slot_lead;  // [n_units] per launch slot, staged units: device indices of the first three effects in FRONT of the reverb (-1: none) —

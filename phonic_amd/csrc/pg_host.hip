@@ -299,7 +299,7 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
     return nullptr;
   }
   (void)pg_memset(g->d_audible, 0, g->audible_slots * sizeof(int));
-  if (pg_malloc((void**)&g->d_bus_progress, PG_BUS_PIPELINE_MAX * 8) == hipSuccess) (void)pg_memset(g->d_bus_progress, 0xff, PG_BUS_PIPELINE_MAX * 8); else g->d_bus_progress = nullptr;
+  if (pg_malloc((void**)&g->d_bus_progress, 2 * PG_BUS_PIPELINE_MAX * 8) == hipSuccess) (void)pg_memset(g->d_bus_progress, 0xff, 2 * PG_BUS_PIPELINE_MAX * 8); else g->d_bus_progress = nullptr;
   if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     g->h_feedback[0] = ~0ull;  // nothing reported yet
@@ -1004,8 +1004,9 @@ int pg_graph_bus_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t
 const char* pg_graph_bus_kernel(pg_graph* g) {
   const size_t n_fx = g->mixers[0].fx.size();
   if (n_fx == 0) return "";
-  return (n_fx >= 2 && n_fx <= PG_BUS_PIPELINE_MAX && g->bus_pipeline && g->max_blocks > 1) ? "pg_unit_kernel (main mixer's chain: one workgroup per effect, pipelined over the blocks)"
-                                                                                           : "pg_unit_kernel (main mixer's chain: one workgroup)";
+  const bool pipelined = n_fx <= PG_BUS_PIPELINE_MAX && g->bus_pipeline && g->max_blocks > 1;
+  if (pipelined && n_fx >= 2) return "pg_unit_kernel (main mixer's chain: one workgroup per effect, pipelined over the blocks)";
+  return pipelined ? "pg_unit_kernel (main mixer's chain: one workgroup, the effect's state resident over the blocks)" : "pg_unit_kernel (main mixer's chain: one workgroup)";
 }
 double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
   double total = 0.0;
@@ -1060,11 +1061,11 @@ static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream
 }
 
 
-// A bus launch that walks several blocks with a chain of two or more effects and nothing to apply: one workgroup per effect, pipelined over
-// the blocks (pg_bus_pipeline). The progress words carry the launch's round number, so they never need clearing.
+// A bus launch that walks several blocks with nothing to apply: one workgroup per effect of the chain, pipelined over the blocks
+// (pg_bus_pipeline; a chain of ONE effect too: its state stays in LDS over the blocks and each block's input is requested a block ahead). The progress words carry the launch's round number, so they never need clearing.
 static void bus_pipeline_setup(pg_graph* g, PgLaunch& B) {
   const size_t n_fx = g->mixers[0].fx.size();
-  if (B.n_chunks > 1 && B.n_cmds == 0 && n_fx >= 2 && n_fx <= PG_BUS_PIPELINE_MAX && g->d_bus_progress && g->bus_pipeline) {
+  if (B.n_chunks > 1 && B.n_chunks <= 64 && B.n_cmds == 0 && n_fx >= 1 && n_fx <= PG_BUS_PIPELINE_MAX && g->d_bus_progress && g->bus_pipeline) {
     B.mode = 3; B.n_units = (int)n_fx; B.bus_progress = g->d_bus_progress;
     B.round = ++g->bus_epoch;  // (the words of an earlier launch never match; 0xffffffff is what the words are created with)
     if (B.round == 0xffffffffu) B.round = g->bus_epoch = 1;
@@ -1402,9 +1403,14 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     }
     // A small unit level in front of a bus chain (BASELINE configs 2 and 4: 64 / 256 voices, then a chain that takes four times as long as they
     // do): launch sequences of a few chunks each, so that the chain of one runs over the unit kernels of the next INSIDE a call too
-    if (k > g->bus_group && CH % mf == 0 && g->overlap_bus && !g->defer_bus && !g->mixers[0].fx.empty() && g->n_graph_units <= 512) {
+    // (the first sequence behind a serialisation has no chain to run under: it is one chunk, so that only that chunk's unit kernels are exposed)
+    if (CH % mf == 0 && g->overlap_bus && !g->defer_bus && !g->mixers[0].fx.empty() && g->n_graph_units <= 512) {
       const uint64_t per_chunk = CH / mf;
-      k = std::max<uint64_t>(per_chunk, (g->bus_group / per_chunk) * per_chunk);
+      // (a chain to run under: one was enqueued by the sequence before AND the stream has not drained since — a caller that waited for its
+      // last call finds an idle device)
+      const bool under_chain = g->rows_free_fresh && hipStreamQuery(stream) == hipErrorNotReady;
+      const uint64_t group = under_chain ? std::max<uint64_t>(per_chunk, (g->bus_group / per_chunk) * per_chunk) : std::max<uint64_t>(per_chunk, 2);
+      if (k > group) k = group;
     }
     if (k > 0) {
       LaunchSpan sp;

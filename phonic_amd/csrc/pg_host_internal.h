@@ -36,7 +36,6 @@ hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, fl
 
 // ---- errors ---------------------------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);  // records the thread's last error message (pg_last_error_message) and returns `code`
-#define PG_BUS_PIPELINE_MAX 16  // effects of a bus chain the pipelined launch takes (one workgroup each); longer chains stay one workgroup
 #define PG_AUDIBLE_SLOTS 64  // >= the largest pg_graph_set_max_blocks_per_launch
 #define PG_CMD_RING 65536   // commands in flight between two points at which the host knows the stream drained (2 MB device + 2 MB pinned)
 #define PG_CTRL_RING 65536  // control messages waiting for the next write (the reference: 4096 per mixer; here one ring per graph)
@@ -253,7 +252,7 @@ struct pg_graph {
   hipEvent_t ev_units_done = nullptr, ev_rows_free = nullptr;
   hipStream_t overlap_stream = nullptr;  // the write stream ev_rows_free was last recorded on
   bool rows_free_fresh = false;  // ev_rows_free was recorded behind everything the caller's stream holds that the next unit launch must follow
-  uint64_t bus_group = 8;        // blocks per launch sequence of a small unit level in front of a bus chain (PHONIC_BUS_GROUP)
+  uint64_t bus_group = 16;       // blocks per launch sequence of a small unit level in front of a bus chain (PHONIC_BUS_GROUP)
   bool overlap_bus = true;       // PHONIC_BUS_OVERLAP=0 (read at create): everything on the caller's stream
   bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)

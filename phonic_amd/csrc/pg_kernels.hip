@@ -766,13 +766,15 @@ __global__ void __launch_bounds__(256, PG_MID_WAVES) pg_unit_kernel_fast_mid(PgL
 template <int KMASK>
 __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
   const int f = (int)blockIdx.x, n_stages = (int)gridDim.x;
+  const bool last_stage = f == n_stages - 1;
   PgUnit& unit = L.units[L.unit_base];
   const int tid = pg_tid(), nt = blockDim.x;
   const int N = (int)L.n_frames;
   const int NA = N < PG_MIN_ROW_FRAMES ? PG_MIN_ROW_FRAMES : N;
   float* sig = (float*)pg_smem;
   float* tmp = sig + 2 * NA;
-  char* scratch = (char*)(tmp + 2 * NA);
+  float* nxt = tmp + 2 * NA;   // the NEXT block's input, on its way global -> LDS while this block is processed (pg_launch_units adds the room in mode 3)
+  char* scratch = (char*)(nxt + 2 * NA);
   scratch += (sizeof(PgVoice) + 15) & ~15ull;
   PgFx* lfx = (PgFx*)scratch;                      scratch += (sizeof(PgFx) + 15) & ~15ull;
   int* ctl = (int*)scratch;                        scratch += 128;
@@ -784,9 +786,12 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
   __syncthreads();
   const int n_chunks = L.n_chunks > 1 ? L.n_chunks : 1;
   int any_active = 0;
+  int prefetched = -1;   // the block whose input was requested into `nxt` (uniform)
+  unsigned long long hist = 0, mask = 0;   // `an effect up to this one was active` per block: the last 24 blocks / all (<= 64) blocks of the launch
   if (tid == 0) ctl[7] = 0;
   for (int c = 0; c < n_chunks; ++c) {
     int active_before = 0;
+    int next_ready = (f == 0 && c + 1 < n_chunks) ? 1 : 0;   // stage 0 reads the mixer sum: complete before this launch began
     if (f > 0 && !ctl[7]) {
       if (tid == 0) {
         unsigned long long w;
@@ -794,19 +799,40 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
         bool ok;
         do {
           w = __hip_atomic_load(&L.bus_progress[f - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (uint32_t)(w >> 32) == L.round && (int)(w & 0x7fffffffull) > c;
+          ok = (uint32_t)(w >> 32) == L.round && (int)(w & 0xffull) > c;
           if (!ok) __builtin_amdgcn_s_sleep(8);   // (~0.2 us: the producer's block takes tens of microseconds)
         } while (!ok && ++polls < (1u << 24));     // (seconds: far beyond any block time)
         if (!ok) { pg_raise_device_error(L, PG_DEVERR_BUS_STALLED); ctl[7] = 1; }
-        ctl[6] = ok ? (int)((w >> 31) & 1ull) : 0;
+        // `an earlier effect was active on THIS block`: the producer may be several blocks ahead, so the word carries the flags of its last 24
+        // blocks (bit 8 = the latest); further back, the producer's per-block mask word (stored before the count was released)
+        const int cnt = ok ? (int)(w & 0xffull) : 0, back = cnt - 1 - c;
+        int act = 0;
+        if (ok) act = back < 24 ? (int)((w >> (8 + back)) & 1ull)
+                                : (int)((__hip_atomic_load(&L.bus_progress[PG_BUS_PIPELINE_MAX + f - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> c) & 1ull);
+        ctl[6] = act;
+        ctl[5] = cnt;   // blocks the producer has published
       }
       __syncthreads();
-      __threadfence();  // the producer's stores of block c are visible (the L1 is invalidated behind the acquire)
+      __threadfence();  // the producer's stores of the published blocks are visible (the L1 is invalidated behind the acquire)
       active_before = ctl[6];
+      next_ready = (ctl[5] > c + 1 && c + 1 < n_chunks) ? 1 : 0;
     }
     float* blk = L.bus + (size_t)c * 2 * (size_t)N;
-    for (int i = tid; i < 2 * N; i += nt) sig[i] = __builtin_nontemporal_load(blk + i);
-    __syncthreads();
+    if (prefetched == c) {   // requested while the block before was processed: in LDS by now, or nearly
+      lds_dma_wait();
+      __syncthreads();
+      float* t = sig; sig = nxt; nxt = t;
+    } else {
+      for (int i = tid; i < 2 * N; i += nt) sig[i] = __builtin_nontemporal_load(blk + i);
+      __syncthreads();
+    }
+    // The next block's input: one dword per lane and trip, global -> LDS directly (no registers; nothing waits for it until the next trip
+    // of this loop) — the load at the top of a block was a round trip on a workgroup whose block is a latency chain.
+    if (next_ready) {
+      const float* nb = blk + 2 * (size_t)N;
+      for (int k = 0; k * 256 < 2 * N; ++k) { const int i = tid + k * 256; if (i < 2 * N) lds_dma_dword(nb + i, nxt + k * 256 + (tid & ~63)); }
+      prefetched = c + 1;
+    }
     // (per chunk of the main mixer: the flag of its summed input sits in the word of its last piece, the processor decides at its first)
     const PgPiece pc = pg_piece(L, c);
     const bool audible_input = L.bus_audible ? (L.bus_audible[pc.c_last] != 0) : true;
@@ -815,13 +841,21 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
     __syncthreads();
     if (is_active) for (int i = tid; i < 2 * N; i += nt) blk[i] = sig[i];
     any_active = (active_before || is_active) ? 1 : 0;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&L.bus_progress[f], ((unsigned long long)L.round << 32) | ((unsigned long long)any_active << 31) | (unsigned long long)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    hist = ((hist << 1) | (unsigned long long)any_active) & 0xffffffull;
+    mask |= (unsigned long long)any_active << c;
+    if (!last_stage) {   // (nobody reads the last stage's words: its stores are complete when the kernel ends)
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(&L.bus_progress[PG_BUS_PIPELINE_MAX + f], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ordered before the release below)
+        __hip_atomic_store(&L.bus_progress[f], ((unsigned long long)L.round << 32) | (hist << 8) | (unsigned long long)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
+  if (prefetched >= n_chunks) lds_dma_wait();   // (never: the last block requests nothing)
   __syncthreads();
   for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
-  if (f == n_stages - 1 && tid == 0) unit.effects_bypassed = any_active ? 0 : 1;  // of the last block, as the serial order leaves it
+  if (last_stage && tid == 0) unit.effects_bypassed = any_active ? 0 : 1;  // of the last block, as the serial order leaves it
 }
 
 // The generic kernel holds one workgroup per CU (its register footprint): the grid is capped at the CU count and every workgroup
@@ -1414,6 +1448,7 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   size_t lds = pg_unit_lds_bytes(L.n_frames, L.mode == 1 ? L.fast_scratch_bytes : 0);  // (the generic kernel renders any chain: full arena)
+  if (L.mode == 3) lds += (size_t)(L.n_frames < PG_MIN_ROW_FRAMES ? PG_MIN_ROW_FRAMES : L.n_frames) * 8;   // pg_bus_pipeline: the next block's input buffer
   { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
   if (L.mode == 1 && L.wide == 2) hipExtLaunchKernelGGL(pg_unit_kernel_fast_mid, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);
   else if (L.mode == 1 && L.wide) hipExtLaunchKernelGGL(pg_unit_kernel_fast_wide, dim3(L.n_units), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);

@@ -40,6 +40,7 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { static unsigned n = 0; (void)s; return (++n & 1) ? hipErrorNotReady : hipSuccess; }   // (both answers get exercised)
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
