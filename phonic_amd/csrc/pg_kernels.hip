@@ -719,7 +719,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 // keeps the hot loop free of spills; the wide one adds Filter, Eq5 and Distortion. The host picks by the kinds present.
 #define PG_KMASK_LEAN ((1 << 0) | (1 << 1) | (1 << 5))
 #define PG_KMASK_ALL 0x7ff  // bits 0..9: effect kinds; bit 10: the ramp paths (FilterEffect cutoff / Q)
-#define PG_KMASK_GENERIC 0xfff  // ... bit 11: the generic kernel's lone workgroups (two reverb sub-chunks per trip: registers to spare, latency to hide)
+#define PG_KMASK_GENERIC 0xfff  // ... bit 11: the generic kernel's lone workgroups (four reverb sub-chunks per trip: registers to spare, latency to hide)
 #define PG_KMASK_GAINPAN ((1 << 0) | (1 << 1))
 // leading effects of the wide staged kernel: every kind with a time-parallel path whose LDS needs fit stage 1's arena (no Chorus)
 #define PG_KMASK_LEADING ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 9))
@@ -780,7 +780,7 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
   int* ctl = (int*)scratch;                        scratch += 128;
   float* red = (float*)scratch;                    scratch += 64;
   FastCtx fc;
-  fc.tmp = tmp; fc.tmp_floats = 2 * NA; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = nullptr; fc.err = L.error_word; fc.idx_log = nullptr;
+  fc.tmp = tmp; fc.tmp_floats = 2 * NA; fc.scratch = scratch; fc.ctl = ctl; fc.red = red; fc.diag = L.diag; fc.err = L.error_word; fc.idx_log = nullptr;   // (diag: stamps of stage 0 in diagnostic builds, tools/diag_stamps.py bus)
   PgFx& gfx = L.fx[L.fx_index[unit.fx_off + f]];
   for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)lfx)[i] = ((const uint32_t*)&gfx)[i];  // the effect's state stays in LDS over all blocks
   __syncthreads();
@@ -817,6 +817,7 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
       active_before = ctl[6];
       next_ready = (ctl[5] > c + 1 && c + 1 < n_chunks) ? 1 : 0;
     }
+    PG_STAMP(L.diag, 60);
     float* blk = L.bus + (size_t)c * 2 * (size_t)N;
     if (prefetched == c) {   // requested while the block before was processed: in LDS by now, or nearly
       lds_dma_wait();
@@ -833,14 +834,17 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
       for (int k = 0; k * 256 < 2 * N; ++k) { const int i = tid + k * 256; if (i < 2 * N) lds_dma_dword(nb + i, nxt + k * 256 + (tid & ~63)); }
       prefetched = c + 1;
     }
+    PG_STAMP(L.diag, 61);
     // (per chunk of the main mixer: the flag of its summed input sits in the word of its last piece, the processor decides at its first)
     const PgPiece pc = pg_piece(L, c);
     const bool audible_input = L.bus_audible ? (L.bus_audible[pc.c_last] != 0) : true;
     const bool input_bypassed = !audible_input && !active_before;
     const bool is_active = fx_processor_process<false, KMASK>(*lfx, sig, 2 * N, input_bypassed, pc.first, pc.last, L.sample_rate, fc, L.fast, ctl, red);
     __syncthreads();
+    PG_STAMP(L.diag, 62);
     if (is_active) for (int i = tid; i < 2 * N; i += nt) blk[i] = sig[i];
     any_active = (active_before || is_active) ? 1 : 0;
+    PG_STAMP(L.diag, 63);
     hist = ((hist << 1) | (unsigned long long)any_active) & 0xffffffull;
     mask |= (unsigned long long)any_active << c;
     if (!last_stage) {   // (nobody reads the last stage's words: its stores are complete when the kernel ends)

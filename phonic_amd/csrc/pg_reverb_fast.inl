@@ -372,6 +372,26 @@ DEVO bool reverb_fast_eligible(const PgFx& fx) {
   const PgReverb& r = fx.u.reverb;
   return !sm_need_ramp(r.room) && !sm_need_ramp(r.wet) && reverb_geometry_ok(fx);
 }
+// The same test made by the wave (all lanes of the workgroup call, every wave gets the same answer): lane l looks at ring l mod 16 of the twelve
+// and one ballot joins the answers — the serial walk is twelve dependent LDS reads and f64 conversions in a row, ~3 K cycles at the head of every
+// block of a reverb on the unit kernels and on the main mixer's chain (tools/diag_bus_chain.py).
+DEVO bool reverb_fast_eligible_wave(const PgFx& fx) {
+  const PgReverb& r = fx.u.reverb;
+  const double rs = (double)r.room.target;
+  const double size = (rs * rs * 75.0) + 25.0;
+  bool ok = !sm_need_ramp(r.room) && !sm_need_ramp(r.wet) && d2u64(29.0 * size) >= 64 && d2u64(47.0 * size) >= 64 + 17;
+  const int i = (int)(threadIdx.x & 15u);
+  if (i < 12) {
+    // 79 73 71 67 61 59 53 47 | 43 41 37 31 (reverb.rs:196-213), picked without a table (a private array indexed per lane lives in scratch)
+    const int kk = i == 0 ? 79 : i == 1 ? 73 : i == 2 ? 71 : i == 3 ? 67 : i == 4 ? 61 : i == 5 ? 59 : i == 6 ? 53 : i == 7 ? 47 : i == 8 ? 43 : i == 9 ? 41 : i == 10 ? 37 : 31;
+    const uint32_t dl = (uint32_t)d2u64((double)kk * size);
+    const uint32_t frames = i < 8 ? r.line[i < 8 ? i : 0].frames : r.ap[i < 8 ? 0 : i - 8].frames;
+    const uint32_t pos = i < 8 ? r.line[i < 8 ? i : 0].count : r.ap[i < 8 ? 0 : i - 8].write_pos;
+    const uint32_t mx = frames - 1;
+    if (pos > (dl < mx ? dl : mx)) ok = false;
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
 // `wet` ramping, room size at rest (reverb_wet_ramp_fast below): the ring geometry stands still, only the wet gain and the three low-pass
 // cutoffs (10000 - room * wet * 3000 Hz, reverb.rs:413-424) move per frame
 DEVO bool reverb_wet_ramp_eligible(const PgFx& fx) {
@@ -575,8 +595,8 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
     PG_STAMP(diag, 4);
     // ---- sub-chunks of nt/2 frames ----
     // ITEMS consecutive 128-frame sub-chunks per trip (each with its own anchor): every lane carries ITEMS (frame, channel) items through the
-    // reads -> barrier -> writes sequence. 1 in the kernels that share a CU four ways (128 VGPRs); 2 in the generic kernel, whose lone
-    // workgroups (the main mixer's chain, units on the exact lane) are latency chains with registers to spare: half the dependent round trips.
+    // reads -> barrier -> writes sequence. 1 in the kernels that share a CU four ways (128 VGPRs); 4 in the generic kernel, whose lone
+    // workgroups (the main mixer's chain, units on the exact lane) are latency chains with registers to spare: a quarter of the dependent round trips.
     for (int base = 0; base < T; base += ITEMS * (nt / 2)) {
 #pragma clang fp contract(fast)  // the only place mul+add pairs may fuse: measured faster, error ~1e-16 relative (the parity gate is 1e-5 RMS)
       int lane_frame = tid >> 1;
@@ -755,7 +775,8 @@ DEVO bool reverb_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
   PgReverb& r = fx.u.reverb;
   // per-frame delay sizes / coefficients while a smoother moves, or a ring position still above a ring end the room left behind when it
   // shrank (the mid stage's ring arithmetic has no case for it): exact serial path
-  if (!reverb_fast_eligible(fx)) return false;
+  // (ITEMS >= 2: the generic kernel — lone workgroups, registers to spare; inlined into the wide fast kernel the wave's test cost it its three-per-CU budget)
+  if (!(ITEMS >= 2 ? reverb_fast_eligible_wave(fx) : reverb_fast_eligible(fx))) return false;
   const int frames = n_samples / 2;
   if (frames == 0) return true;
   const RevLds m = rev_lds(fc.scratch);
