@@ -16,6 +16,8 @@ for w in c2 c4; do bash tools/ktrace.sh --workload $w --repeats 3 --steps 64 --w
 bash tools/c3_round.sh c3tmp > /dev/null 2>&1
 cp gpurun_out/c3tmp/c3_rocprofv3_kernel_stats.csv $O/${R}_c3_rocprofv3_kernel_stats.csv
 cp gpurun_out/c3tmp/c3_pmc_util.csv $O/${R}_c3_pmc_util.csv
+bash tools/bus_group_sweep.sh > $O/${R}_bus_group_sweep.txt 2>&1   # C2 / C4 over the bus chain's sequence length
+bash tools/pmc_c.sh c5 "VALUBusy" "SQ_INSTS_VALU SQ_INSTS_SALU" > $O/${R}_c5_pmc_util.txt 2>&1
 ls -la $O
 python - $O $R <<'PY'
 import json, sys, os, glob
