@@ -1406,9 +1406,9 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     // (the first sequence behind a serialisation has no chain to run under: it is one chunk, so that only that chunk's unit kernels are exposed)
     if (CH % mf == 0 && g->overlap_bus && !g->defer_bus && !g->mixers[0].fx.empty() && g->n_graph_units <= 512) {
       const uint64_t per_chunk = CH / mf;
-      // (a chain to run under: one was enqueued by the sequence before AND the stream has not drained since — a caller that waited for its
-      // last call finds an idle device)
-      const bool under_chain = g->rows_free_fresh && hipStreamQuery(stream) == hipErrorNotReady;
+      // (a chain to run under: one was enqueued by the sequence before — in this call, or in the call before and the stream has not drained
+      // since: a caller that waited for its last call finds an idle device)
+      const bool under_chain = g->rows_free_fresh && (done > 0 || hipStreamQuery(stream) == hipErrorNotReady);
       const uint64_t group = under_chain ? std::max<uint64_t>(per_chunk, (g->bus_group / per_chunk) * per_chunk) : std::max<uint64_t>(per_chunk, 2);
       if (k > group) k = group;
     }

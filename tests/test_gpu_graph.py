@@ -950,6 +950,58 @@ def test_superblock_launch_is_bit_identical_to_single_blocks():
     assert np.abs(sup[-2 * N:]).max() > 1e-3
 
 
+def test_bus_pipeline_keeps_the_chain_flags_per_block_when_a_stage_runs_far_ahead(monkeypatch):
+    """The pipelined bus chain (pg_bus_pipeline): `an earlier effect of the chain was active on THIS block` travels from stage to stage per block —
+    the progress word holds the flags of the producer's last 24 blocks, a second word one flag per block of the launch. A Gain in front of a Reverb is
+    a producer that runs far ahead (microseconds per block against the reverb's tens): in a 60-block launch sequence (PHONIC_BUS_GROUP=64) the
+    reverb's workgroup finds the Gain tens of blocks ahead and must still see block c's flag, not the latest one. The flag flips in the MIDDLE of such a
+    sequence, in steady state: the voices sit on a sub-mixer whose silence gate closes 2 s after they played out (submixer.rs:47-77) — from that
+    block on the main mixer's input is inaudible, the Gain's processor (no tail) bypasses itself, and the reverb starts counting silence; were
+    it told so tens of blocks early it would bypass itself (exact zeros instead of its denormal guard's trickle) inside the rendered span.
+    Bit-identical to single-block launches, within tolerance of the oracle pulled in the same calls."""
+    from phonic_amd.graph import Graph
+
+    monkeypatch.setenv("PHONIC_BUS_GROUP", "64")     # (read when a graph is created)
+    N, per_call, calls = 1024, 64, 4
+
+    def build(g):
+        m = g.add_mixer()
+        for i in range(4):   # one-shots, 12-20 blocks long; non-transient: a played-out source stays, nothing rebuilds the topology inside the calls
+            g.add_voice(m, workloads.tone_buffer(i, 48000, 0.25 + 0.06 * i), 2, 48000, volume=0.3, panning=workloads.voice_pan(i), non_transient=1)
+        return [g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.8}), g.add_effect(0, _capi.FX_REVERB, params={"room": 0.2}, reverb_seeds=workloads.reverb_seeds(3))]
+
+    outs = []
+    for mode in ("single", "super", "oracle"):
+        g = oracle.OracleGraph(SR, 2, N) if mode == "oracle" else Graph(SR, 2, N, 0)
+        if mode == "super":
+            g.set_max_blocks_per_launch(per_call)
+        if mode != "oracle":
+            g.set_timing_period(1)
+        build(g)
+        chunks, pos = [], 0
+        for c in range(calls):
+            o = np.zeros(per_call * 2 * N, np.float32)
+            assert g.write(o, pos) in (0, o.size)
+            chunks.append(o)
+            pos += per_call * N
+            if mode == "super":
+                _, launches, blocks = g.bus_kernel_stats(reset=True)
+                # the first call renders the voices' fades chunk by chunk; from the second on a one-chunk sequence opens the call and ONE sequence takes the other 60 blocks
+                assert blocks == per_call and (c == 0 or launches <= 3), (c, launches, blocks)
+        outs.append(np.concatenate(chunks))
+        if mode != "oracle":
+            assert g.device_errors() == 0
+    single, sup, ref = outs
+    assert np.array_equal(single, sup), int(np.count_nonzero(single != sup))
+    compare(sup, ref)
+    per_block = np.abs(ref.reshape(-1, 2 * N)).max(axis=1)
+    # the block from which the chain is bypassed (exact zeros; until then the reverb's denormal guard trickles) is the oracle's, not one of tens of blocks earlier
+    zero_ref = (ref.reshape(-1, 2 * N) == 0.0).all(axis=1), (sup.reshape(-1, 2 * N) == 0.0).all(axis=1)
+    assert np.array_equal(zero_ref[0], zero_ref[1])
+    first_zero = int(np.argmax(zero_ref[0]))
+    assert per_block[3] > 1e-2 and zero_ref[0][-1] and per_call + 4 < first_zero < calls * per_call, first_zero      # (inside one of the 60-block sequences)
+
+
 @pytest.mark.parametrize("bus", ["limiter", "eq5_reverb"])
 def test_superblock_launch_with_a_bus_chain_is_bit_identical_to_single_blocks(bus):
     """Super-block launches for graphs whose MAIN mixer has effects (BASELINE configs 2 and 4): the mixer sum of all blocks is one launch
