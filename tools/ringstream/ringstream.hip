@@ -12,6 +12,9 @@
 //     variant 3: windows through LDS: every ring's window of the sub-chunk (128 + 16 frames) is fetched with linear 16-byte-per-lane loads into
 //                LDS, taps are read from LDS, writes as in variant 2 (16 bytes per lane, 128 lanes busy)
 //     variant 4: read-only of variant 0 (no writes)      variant 5: write-only of variant 0 (no reads)
+//     variant 6: rings laid out [channel][position] (two planes per ring, one guard element behind each plane mirroring position 0): lane = (frame,
+//                channel) as in variant 0, but the two taps of a line are ONE 16-byte load (adjacent positions of the lane's channel plane), the allpass
+//                reads and all writes stay 8 bytes per lane (a lane writing position 0 also writes the guard) — 12 load instructions per item instead of 20
 // Reported: algorithmic bytes (12 rings x 32 B per voice-frame, as DESIGN.md counts them) / kernel time.
 #include <hip/hip_runtime.h>
 
@@ -81,6 +84,31 @@ __global__ void __launch_bounds__(256, 4) ring_kernel(Voice* voices, int n_block
 #pragma unroll
             for (int i = 0; i < 12; ++i) ((gdouble*)base[i])[wrap(pos[i] + (uint32_t)n, m[i]) * 2 + ch] = sum[it] * 0.03 + (double)i;
           } else acc += sum[it];
+        }
+      } else if (VARIANT == 6) {
+        const int t = tid_();
+        const int n = s0 + (t >> 1), ch = t & 1;
+        d2v tap[8]; double ap[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t plane = (m[i] + 1u) * (uint32_t)ch;                                   // plane of the lane's channel (m + 1 entries: the guard)
+          const uint32_t p1 = wrap(wrap(pos[i] + (uint32_t)n, m[i]) + (uint32_t)c_off[i][ch], m[i]);
+          tap[i] = *(const gdouble2*)((const gdouble*)base[i] + plane + p1);                   // positions p1 and p1 + 1 (the guard stands in for the wrap), 8-byte aligned
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ap[i] = ((const gdouble*)base[8 + i])[(m[8 + i] + 1u) * (uint32_t)ch + wrap(pos[8 + i] + (uint32_t)n + 1, m[8 + i])];
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += tap[i].x + tap[i].y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum += ap[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const uint32_t plane = (m[i] + 1u) * (uint32_t)ch, p = wrap(pos[i] + (uint32_t)n, m[i]);
+          const double v = sum * 0.03 + (double)i;
+          ((gdouble*)base[i])[plane + p] = v;
+          if (p == 0) ((gdouble*)base[i])[plane + m[i]] = v;   // the guard mirrors position 0
         }
       } else if (VARIANT == 2) {
         const int t = tid_();
@@ -173,6 +201,7 @@ int main(int argc, char** argv) {
       case 2: hipLaunchKernelGGL(ring_kernel<2>, dim3(voices), dim3(256), lds, 0, d, blocks, frames); break;
       case 3: hipLaunchKernelGGL(ring_kernel<3>, dim3(voices), dim3(256), lds, 0, d, blocks, frames); break;
       case 4: hipLaunchKernelGGL(ring_kernel<4>, dim3(voices), dim3(256), lds, 0, d, blocks, frames); break;
+      case 6: hipLaunchKernelGGL(ring_kernel<6>, dim3(voices), dim3(256), lds, 0, d, blocks, frames); break;
       default: hipLaunchKernelGGL(ring_kernel<5>, dim3(voices), dim3(256), lds, 0, d, blocks, frames); break;
     }
   };
@@ -182,6 +211,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute((const void*)ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute((const void*)ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute((const void*)ring_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute((const void*)ring_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   for (int w = 0; w < 3; ++w) launch();
   CHECK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0.f;
