@@ -155,6 +155,168 @@ def cpu_baseline(name, block, seconds_budget=12.0):
     }
 
 
+class ClockSampler:
+    """Clock / power / temperature of THIS rank's GPU while the timed legs run: a thread polls the card's sysfs hwmon files (sclk = freq1_input,
+    mclk = freq2_input, socket power = power1_input, junction / memory temperature = temp2_input / temp3_input; readable by an ordinary user on
+    the pool's boxes, tools/probe_clocks.sh) every `period` seconds — the files are plain reads of the driver's cached metrics table, no child
+    process, no re-exec. Sampled while the GPU is busy: an idle card reads its deep-sleep clock (~100 MHz) and says nothing about the legs.
+    The card is found by the device's PCI address (torch's device properties), so the other seven GPUs of the host — other tenants — are not
+    what is read. Why it is here: boxes of the pool differ by up to 12 % on the dominant kernel and a single run spans 0.47-0.63 of the
+    roofline; the per-leg fractions are reported next to the clocks they ran at (`roofline.by_sclk`)."""
+
+    def __init__(self, local_rank, period=0.004):
+        import glob
+        import threading
+
+        self.period, self.samples, self.note = period, [], ""
+        self._stop = threading.Event()
+        self._thread = None
+        self.card = self.hwmon = None
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(local_rank)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception as e:  # noqa: BLE001
+            want = None
+            self.note = f"no PCI address from torch ({type(e).__name__})"
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            cards.append(d)
+            if want and os.path.basename(os.path.realpath(d)).lower().startswith(want):
+                self.card = d
+        if self.card is None and len(cards) == 1:
+            self.card = cards[0]
+        if self.card is None:
+            self.note = self.note or f"no drm card at PCI address {want} ({len(cards)} amdgpu cards visible)"
+            return
+        hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*")))
+        self.hwmon = hw[0] if hw else None
+        if self.hwmon is None:
+            self.note = "card has no hwmon directory"
+        self.pci = os.path.basename(os.path.realpath(self.card))
+
+    @staticmethod
+    def _read(path, scale):
+        try:
+            return float(open(path).read().strip()) / scale
+        except (OSError, ValueError):
+            return None
+
+    def read_metrics(self):
+        """The driver's gpu_metrics table (sysfs binary, version 1.8 as the pool's MI355X boxes expose it: 3872 bytes, header {size, format 1,
+        content 8}; offsets checked against a dump taken under load, tools/probe_metrics.py): accumulation_counter (1 ms ticks) and
+        ppt_residency_acc — ticks during which the PACKAGE POWER TRACKING limit throttled the chip — the eight XCDs' current shader clocks,
+        the memory clock, socket power, memory-controller activity. None for any other table version."""
+        import struct
+
+        try:
+            b = open(os.path.join(self.card, "gpu_metrics"), "rb").read()
+        except OSError:
+            return None
+        if len(b) < 340 or b[2] != 1 or b[3] != 8 or int.from_bytes(b[0:2], "little") != len(b):
+            return None
+        hot, mem, vr, power, gfx_act, umc_act = struct.unpack_from("<6H", b, 4)
+        acc, prochot, ppt, sock_thm, vr_thm, hbm_thm = struct.unpack_from("<6I", b, 40)
+        xcd = struct.unpack_from("<8H", b, 296)
+        uclk = struct.unpack_from("<H", b, 336)[0]
+        return {"acc": acc, "ppt": ppt, "socket_thm": sock_thm, "hbm_thm": hbm_thm, "prochot": prochot, "xcd_mhz": xcd, "uclk_mhz": uclk, "power_w": power, "umc_activity": umc_act,
+                "temp_hotspot_c": hot, "temp_mem_c": mem}
+
+    def read_once(self):
+        h = self.hwmon
+        return (time.perf_counter(), self._read(h + "/freq1_input", 1e6), self._read(h + "/freq2_input", 1e6), self._read(h + "/power1_input", 1e6),
+                self._read(h + "/temp2_input", 1e3), self._read(h + "/temp3_input", 1e3), self.read_metrics())
+
+    def start(self):
+        import threading
+
+        if self.hwmon is None or self._thread is not None:
+            return
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append(self.read_once())
+                self._stop.wait(self.period)
+
+        self._stop.clear()
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def dpm_state(self):
+        """The DPM tables' current entries (pp_dpm_*: the line marked `*`) and the performance level — one read, for the record."""
+        out = {}
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk", "power_dpm_force_performance_level"):
+            try:
+                txt = open(os.path.join(self.card, name)).read().strip().splitlines()
+            except OSError:
+                continue
+            cur = [ln for ln in txt if ln.rstrip().endswith("*")]
+            out[name] = (cur[0].rstrip(" *") if cur else txt[0]) if txt else None
+        return out
+
+    def ppt_share_at(self, t, half_window=0.05):
+        """Share of the 1 ms ticks around perf_counter time t (+- half_window s) during which the power limit throttled the chip."""
+        gm = [(smp[0], smp[6]) for smp in self.samples if smp[6] and abs(smp[0] - t) <= half_window]
+        if len(gm) < 2:
+            return None
+        d_acc = (gm[-1][1]["acc"] - gm[0][1]["acc"]) & 0xFFFFFFFF
+        return (((gm[-1][1]["ppt"] - gm[0][1]["ppt"]) & 0xFFFFFFFF) / d_acc) if d_acc else None
+
+    def sclk_at(self, t):
+        """sclk (MHz) of the sample nearest to perf_counter time t."""
+        best = None
+        for smp in self.samples:
+            if smp[1] is not None and (best is None or abs(smp[0] - t) < abs(best[0] - t)):
+                best = smp
+        return best[1] if best else None
+
+    @staticmethod
+    def _dist(vals):
+        v = sorted(x for x in vals if x is not None)
+        if not v:
+            return None
+        q = lambda f: v[min(len(v) - 1, int(f * len(v)))]
+        return {"min": v[0], "p10": q(0.10), "p50": q(0.50), "p90": q(0.90), "max": v[-1]}
+
+    def summary(self, windows):
+        """Distribution of the samples that fall inside the timed windows [(t0, t1), ...] (all samples when none does)."""
+        if self.hwmon is None:
+            return {"source": None, "note": self.note}
+        inside = [smp for smp in self.samples if any(a <= smp[0] <= b for a, b in windows)] or self.samples
+        gm = [smp[6] for smp in inside if smp[6]]
+        metrics = None
+        if len(gm) >= 2:
+            d_acc = (gm[-1]["acc"] - gm[0]["acc"]) & 0xFFFFFFFF
+            res = lambda k: (((gm[-1][k] - gm[0][k]) & 0xFFFFFFFF) / d_acc) if d_acc else None
+            metrics = {"source": "gpu_metrics v1.8 (sysfs)", "ticks": d_acc,
+                       "ppt_throttled_share": res("ppt"), "socket_thermal_throttled_share": res("socket_thm"), "hbm_thermal_throttled_share": res("hbm_thm"), "prochot_share": res("prochot"),
+                       "xcd_sclk_mhz": {"min": min(min(m["xcd_mhz"]) for m in gm), "p50": self._dist(sum(m["xcd_mhz"]) / 8.0 for m in gm)["p50"], "max": max(max(m["xcd_mhz"]) for m in gm)},
+                       "uclk_mhz": self._dist(m["uclk_mhz"] for m in gm), "umc_activity_pct": self._dist(m["umc_activity"] for m in gm), "temp_hotspot_c": self._dist(m["temp_hotspot_c"] for m in gm)}
+        return {"gpu_metrics": metrics, "source": "sysfs hwmon, polled every %g ms by a thread of bench.py while the legs ran" % (self.period * 1e3), "pci": self.pci, "samples": len(inside),
+                "sclk_mhz": self._dist(s[1] for s in inside), "mclk_mhz": self._dist(s[2] for s in inside), "socket_power_w": self._dist(s[3] for s in inside),
+                "temp_junction_c": self._dist(s[4] for s in inside), "temp_memory_c": self._dist(s[5] for s in inside), "dpm": self.dpm_state()}
+
+
+def dist_of(vals, scale=1.0):
+    v = sorted(vals)
+    if not v:
+        return {}
+    q = lambda f: v[min(len(v) - 1, int(f * len(v)))] * scale
+    return {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90)}
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment, exactly what torch.distributed.run sets) BEFORE this process imports torch or touches HIP — a process that has
@@ -203,6 +365,108 @@ def spawn_ranks(n, argv):
         raise SystemExit(f"bench.py: {failed or 'a rank failed'}; rank exit codes {rcs}")
 
 
+def measure_dyn(args, local_rank, block, mf, sb):
+    """bench.py --workload dyn: the headline's voices OFF the steady state — what the reference's real life looks like (events at sample times,
+    src/source/mixed.rs:679-712,761-924; voices that end and start, :558-624; auto-bypassed effects and silent sub-mixers,
+    src/source/mixed/effect.rs:56-145). One GPU. The same process first times the steady headline graph (all voices audible, no events) with the
+    same call pattern; then `--dyn-seconds` of audio of the dynamic graph: per second of audio `--churn` % of the voices end and restart at
+    random sample times, `--events` commands (reverb `wet`, source volume, source panning — equal shares) land at random sample times on random
+    audible voices, `--silent` % of the voices have run past their tails. Reported: ms per step (offline calls of --superblock blocks, and one
+    call per block), the ratio to the steady graph, the share of unit-blocks that left the time-parallel kernels and the generic kernel's time."""
+    import numpy as np
+    import torch
+
+    from phonic_amd import workloads
+    from phonic_amd.graph import Graph
+
+    V = args.voices or 1024
+    sr = 48000
+    audio_s = args.dyn_seconds
+    warm_s = 12.0 if args.silent > 0 else 1.0   # (silent voices: reverb tail 5.6 s + the sub-mixer's 2 s gate must have passed)
+    warm_blocks = int(warm_s * sr / block) // sb * sb + sb
+    steps = max(sb, int(audio_s * sr / block) // sb * sb)
+    stream_t = torch.cuda.Stream(device=local_rank)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(stream_t)
+    stream = stream_t.cuda_stream
+    out_buf = torch.zeros(sb * block * 2, dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def make(dynamic):
+        g = Graph(sr, 2, mf, local_rank)
+        g.set_timing_period(1)
+        g.set_max_blocks_per_launch(max(1, min(64, sb * block // mf)))
+        if dynamic:
+            # the dynamic span is rendered twice (offline calls, then one call per block): restarts are planned over both spans
+            plan = workloads.build_dyn(g, V, 2 * audio_s + 1.0, args.churn, args.silent, first_frame=warm_blocks * block, seed=args.dyn_seed)
+        else:
+            workloads.build_headline(g, V)
+            plan = None
+        return g, plan
+
+    def run(g, drv, n_blocks, per_call, pos):
+        """n_blocks blocks in calls of per_call; before every call the commands that fall into it are scheduled (workloads.DynDriver)."""
+        n_cmds = 0
+        done = 0
+        while done < n_blocks:
+            k = min(per_call, n_blocks - done)
+            if drv:
+                n_cmds += drv.schedule(g, pos, pos + k * block)
+            w = g.write_device(out_buf.data_ptr(), k * block * 2, pos, stream)
+            if w != k * block * 2:
+                raise RuntimeError("graph write failed: " + str(w))
+            pos += k * block
+            done += k
+        return pos, n_cmds
+
+    def timed(g, drv, n_blocks, per_call, pos):
+        torch.cuda.synchronize()
+        g.kernel_stats(reset=True)
+        g.dynamic_stats(reset=True)
+        t0 = time.perf_counter()
+        pos, n_cmds = run(g, drv, n_blocks, per_call, pos)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches, blocks = g.kernel_stats(reset=True)
+        st = g.dynamic_stats(reset=True)
+        return pos, dt, n_cmds, st, (ms, launches, blocks)
+
+    res = {}
+    for dynamic in (False, True):
+        g, plan = make(dynamic)
+        drv = workloads.DynDriver(plan, args.events, args.dyn_seed + 1, kinds=[int(c) for c in args.dyn_kinds]) if dynamic else None
+        pos, _ = run(g, None, warm_blocks if dynamic else 2 * sb, sb, 0)   # warm-up: no commands
+        legs = {}
+        for tag, per_call in (("offline", sb), ("realtime", 1)):
+            pos, dt, n_cmds, st, ks = timed(g, drv, steps, per_call, pos)
+            legs[tag] = {"ms_per_step": dt / steps * 1e3, "commands": n_cmds, "commands_per_block": n_cmds / steps,
+                         "unit_blocks": st["unit_blocks"], "deferred_unit_blocks": st["deferred_unit_blocks"],
+                         "deferred_share": st["deferred_unit_blocks"] / max(1, st["unit_blocks"]),
+                         "generic_launches": st["generic_launches"], "generic_launches_with_work": st["generic_launches_with_work"],
+                         "generic_ms_per_step": (st["generic_ms"] / max(1, st["generic_timed"])) * st["generic_launches"] / steps,
+                         "generic_ms_per_launch": st["generic_ms"] / max(1, st["generic_timed"]),
+                         "fast_kernel_ms_per_block": (ks[0] * ks[1] / ks[2]) if ks[2] else 0.0, "fast_blocks_per_launch": (ks[2] / ks[1]) if ks[1] else 0.0}
+        err = g.device_errors()
+        if err:
+            raise RuntimeError(f"kernel consistency flags raised: {err}")
+        peak = float(out_buf[: 2 * block].abs().max().item())
+        res["dynamic" if dynamic else "steady"] = {"legs": legs, "bus_peak": peak}
+        g.close()
+    torch.cuda.set_stream(torch.cuda.default_stream(local_rank))
+    d, s0 = res["dynamic"]["legs"], res["steady"]["legs"]
+    line = {
+        "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample", "value": V * block / (d["offline"]["ms_per_step"] * 1e-3), "unit": "voice-frames/s",
+        "n_gpus": 1, "steps": steps, "warmup": warm_blocks, "ms_per_step": d["offline"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "dyn: the headline's voices off the steady state (events, voices that end and restart, auto-bypassed voices)", "voices_per_gpu": V,
+                   "block_frames": block, "max_frames": mf, "blocks_per_call": sb, "churn_pct_per_s": args.churn, "events_per_s": args.events, "silent_pct": args.silent,
+                   "audio_seconds": steps * block / sr, "seed": args.dyn_seed},
+        "dyn": {"offline": d["offline"], "realtime": d["realtime"], "steady_offline_ms_per_step": s0["offline"]["ms_per_step"], "steady_realtime_ms_per_step": s0["realtime"]["ms_per_step"],
+                "ratio_offline": d["offline"]["ms_per_step"] / s0["offline"]["ms_per_step"], "ratio_realtime": d["realtime"]["ms_per_step"] / s0["realtime"]["ms_per_step"],
+                "bus_peak": res["dynamic"]["bus_peak"], "steady_bus_peak": res["steady"]["bus_peak"]},
+    }
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +474,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=0, help="timed legs of exactly --steps blocks each, the median leg is reported (default: as many as --min-seconds needs, "
                     "at least 5 — a 20-step leg lasts 2 ms and single legs scatter by +-8 % with the clock state of the box)")
-    ap.add_argument("--workload", default="headline", choices=sorted(B_ALG))
+    ap.add_argument("--workload", default="headline", choices=sorted(B_ALG) + ["dyn"])
+    ap.add_argument("--churn", type=float, default=0.0, help="--workload dyn: %% of the voices that end and restart per second of audio, at random sample times")
+    ap.add_argument("--events", type=float, default=0.0, help="--workload dyn: parameter / volume / panning commands per second of audio, at random sample times")
+    ap.add_argument("--silent", type=float, default=0.0, help="--workload dyn: %% of the voices that have run past their tails (auto-bypassed)")
+    ap.add_argument("--dyn-seconds", type=float, default=10.0, help="--workload dyn: seconds of audio per timed span")
+    ap.add_argument("--dyn-seed", type=int, default=1234)
+    ap.add_argument("--dyn-kinds", default="012", help="--workload dyn: which commands --events draws from: 0 = the reverb's `wet`, 1 = source volume, 2 = source panning")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --voices per GPU; strong: --total-voices split over the GPUs")
     ap.add_argument("--voices", type=int, default=0, help="weak scaling: voices PER GPU (default: the config's count)")
     ap.add_argument("--total-voices", type=int, default=0, help="strong scaling: voices of the whole job (default: c5 8192, else the config's count)")
@@ -219,6 +489,7 @@ def main():
                     "reference's <= 4096-frame chunks whatever this is; the staged kernels take pieces of <= 1024 frames)")
     ap.add_argument("--superblock", type=int, default=32, help="blocks rendered per pg_graph_write_device call (offline pull loop; 1 = one call per block, the real-time setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clocks", action="store_true", help="do not poll the card's sysfs clock / power / temperature files during the legs (config.clocks)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the second set of legs (one write call per block) behind config.realtime")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed legs are repeated until this much wall time is covered (unless --repeats is given)")
     ap.add_argument("--exact", action="store_true", help="disable the time-parallel paths (exact serial evaluation)")
@@ -282,9 +553,13 @@ def main():
     block = args.block
     mf = args.max_frames or min(block, 1024)   # the kernels' piece size; a step (and a real-time call) is `block` frames
     sb = max(1, args.superblock)
+    # a launch sequence renders at most 64 pieces of max_frames, and a deferred-bus call (several ranks, bus chain on the root) leaves at most
+    # max(64, 4096 / max_frames) `audible` words, one per piece (include/phonic_gpu.h): calls are sized to stay within both
+    pieces_per_block = (block + mf - 1) // mf
+    sb = max(1, min(sb, 64 // pieces_per_block))
     dist_on = world > 1 or force_dist  # (a forced one-rank group goes through the same barriers and reductions)
 
-    def measure(name, scaling, voices_arg, total_voices_arg, min_seconds, with_realtime):
+    def measure(name, scaling, voices_arg, total_voices_arg, min_seconds, with_realtime, sampler=None):
         """Builds the workload's graph on this rank, renders warm-up and timed legs; returns what the result line is made of."""
         if scaling == "strong":
             total_voices = total_voices_arg or (8192 if name == "c5" else DEFAULT_VOICES[name])
@@ -319,7 +594,7 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.set_stream(render_stream)
         stream = render_stream.cuda_stream
-        words_max = max(1, sb * block // mf)   # `audible` words of the largest call: one per piece of max_frames
+        words_max = max(1, sb * pieces_per_block)   # `audible` words of the largest call: one per piece of max_frames
         ring = MasterBusRing(n_samples, M, f"cuda:{local_rank}", n_buffers=4, root=0, force_distributed=force_dist, extra=words_max if bus_on_root else 0)
         if bus_on_root:
             ring.distributed = False  # c2 / c4: the reduce is issued per block below, in front of the root's bus effects
@@ -337,13 +612,15 @@ def main():
                 k = min((left + parts - 1) // parts, ring.m)       # every launch pays about one block time of ramp-up and drain
                 if k > ring.room():
                     ring.close()                                    # (the ring's super-block ends where the call does)
-                nw = (k * block + mf - 1) // mf if (world > 1 and bus_on_root) else 0
+                nw = k * pieces_per_block if (world > 1 and bus_on_root) else 0
                 bus = ring.slots(k, extra=nw)
                 calls.append(k)
                 w = g.write_device(bus.data_ptr(), k * n_samples, pos, stream)
                 if w != k * n_samples:
                     raise RuntimeError("graph write failed: " + str(w))
                 if world > 1 and bus_on_root:
+                    if g.audible_words() != nw:   # (no events in the bench: an event-free call leaves one word per piece)
+                        raise RuntimeError(f"deferred-bus write left {g.audible_words()} words, expected {nw}")
                     # the ranks' `audible` words ride behind the samples: ONE sum-reduce carries both, and the root's chain bypasses itself over
                     # silence as the one main mixer does (EffectProcessor's decisions per chunk, src/source/mixed/effect.rs:56-145)
                     g.export_audible(bus.data_ptr() + 4 * k * n_samples, nw, stream)
@@ -367,10 +644,11 @@ def main():
             if dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            dt = t1 - t0
             ms, launches, blocks = g.kernel_stats(reset=True)
             bus = g.bus_kernel_stats(reset=True)
-            return dt, ms, launches, blocks, bus
+            return dt, ms, launches, blocks, bus, t0, t1
 
         def legs_for(seconds, per_call=None):
             """Timed legs of exactly --steps blocks until `seconds` of wall time are covered (at least 5, at most 2001; --repeats overrides):
@@ -393,16 +671,19 @@ def main():
 
         def roofline_of(legs):
             """Dominant kernel: algorithmic bytes of one launch / its average duration, per leg; a launch renders `blocks_per_launch` blocks of this
-            rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches))."""
+            rank's voices (super-block launches loop over the blocks inside the kernel). Returns (sorted GB/s, median leg's (ms, blocks per launch, GB/s, launches), [(leg mid time, GB/s)])."""
             per_leg = []
-            for (_, ms, launches, blocks, _bus) in legs:
+            for (_, ms, launches, blocks, _bus, lt0, lt1) in legs:
                 if launches and ms > 0:
                     bpl = blocks / launches
-                    per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches))   # (a launch renders bpl pieces of max_frames frames)
+                    per_leg.append((ms, bpl, B_ALG[name] * v_per_gpu * mf * bpl / (ms * 1e-3) / 1e9, launches, 0.5 * (lt0 + lt1)))   # (a launch renders bpl pieces of max_frames frames)
             if not per_leg:
-                return [0.0], (0.0, 0.0, 0.0, 0)
-            return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2]
+                return [0.0], (0.0, 0.0, 0.0, 0), []
+            by_time = [(p[4], p[2]) for p in per_leg]   # (leg mid time, GB/s): what the clock samples are matched against
+            return sorted(p[2] for p in per_leg), sorted(per_leg, key=lambda p: p[2])[len(per_leg) // 2][:4], by_time
 
+        if sampler:
+            sampler.start()
         render(args.warmup)
         ring.drain()
         del calls[:]
@@ -411,6 +692,8 @@ def main():
         # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
         # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
         rt_legs, rt_dts = (legs_for(min_seconds / 2, 1) if (sb > 1 and world == 1 and with_realtime) else (None, None))
+        if sampler:
+            sampler.stop()
         last = ring.last_block()
         peak = float(last.abs().max().item()) if last is not None else 0.0  # the last rendered block only (on the root: the sum over ranks)
 
@@ -424,7 +707,10 @@ def main():
         g.close()
         return res
 
-    R = measure(args.workload, args.scaling, args.voices, args.total_voices, args.min_seconds, not args.no_realtime)
+    if args.workload == "dyn":
+        return measure_dyn(args, local_rank, block, mf, sb)
+    sampler = ClockSampler(local_rank) if rank == 0 and not args.no_clocks else None
+    R = measure(args.workload, args.scaling, args.voices, args.total_voices, args.min_seconds, not args.no_realtime, sampler)
     # BASELINE config 5 as north_star states it — 8192 voices with the full chain, voice-sharded over the GPUs of the node — rides along in
     # the same line (config.strong_c5): the driver's 1 / 2 / 4 / 8-GPU runs then measure the >= 6x claim itself, next to the
     # weak-scaling `value` of the headline. --strong-c5-voices 0 switches it off.
@@ -437,7 +723,7 @@ def main():
         med = int(np.argsort(dts)[len(dts) // 2])
         dt = dts[med]
         value = total_voices * block * args.steps / dt
-        ach, (ms_l, bpl_l, achieved, launches_l) = roofline_of(legs)
+        ach, (ms_l, bpl_l, achieved, launches_l), legs_by_time = roofline_of(legs)
         traffic, traffic_note = pmc_traffic(name, v_per_gpu, mf)
         out = {
             "metric": "sample-frames/sec (48 kHz stereo) through mixer+FX+resample",
@@ -480,6 +766,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_min": ach[0] / HBM_PEAK_GBS,
                 "frac_max": ach[-1] / HBM_PEAK_GBS,
+                **{"frac_" + k: v for k, v in dist_of(ach, 1.0 / HBM_PEAK_GBS).items()},   # the per-leg distribution: frac_p10 / p50 / p90
                 "traffic": traffic * bpl_l if traffic else None,
                 "traffic_note": traffic_note,
                 "kernel": R["kernel"],
@@ -493,6 +780,29 @@ def main():
                 "algorithmic_bytes_per_launch": B_ALG[name] * v_per_gpu * mf * bpl_l,
             },
         }
+        if sampler:
+            # the clocks the legs ran at, and the legs' fractions by the shader clock of the nearest sample (100 MHz bins)
+            out["config"]["clocks"] = sampler.summary([(l[5], l[6]) for l in legs])
+            bins = {}
+            pairs = []
+            for (t, gbs) in legs_by_time:
+                f = sampler.sclk_at(t)
+                if f is not None:
+                    bins.setdefault(int(f // 100) * 100, []).append(gbs / HBM_PEAK_GBS)
+                    pairs.append((f, gbs / HBM_PEAK_GBS))
+            ppt_pairs = [(sampler.ppt_share_at(t), gbs / HBM_PEAK_GBS) for (t, gbs) in legs_by_time]
+            ppt_pairs = [p for p in ppt_pairs if p[0] is not None]
+            if len(ppt_pairs) > 2:
+                lo = [f for (sh, f) in ppt_pairs if sh < 0.25]
+                hi = [f for (sh, f) in ppt_pairs if sh >= 0.25]
+                out["roofline"]["by_power_throttle"] = {"legs_below_25pct_throttled": {"legs": len(lo), **dist_of(lo)}, "legs_above": {"legs": len(hi), **dist_of(hi)}}
+            if bins:
+                out["roofline"]["by_sclk"] = {str(k): {"legs": len(v), **dist_of(v)} for k, v in sorted(bins.items())}
+                if len(pairs) > 2:
+                    xs, ys = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+                    out["roofline"]["corr_frac_sclk"] = float(np.corrcoef(xs, ys)[0, 1]) if xs.std() > 0 and ys.std() > 0 else 0.0
+            if rt_legs:
+                out["config"]["clocks"]["realtime_legs"] = {k: v for k, v in sampler.summary([(l[5], l[6]) for l in rt_legs]).items() if k in ("samples", "sclk_mhz", "socket_power_w", "temp_junction_c", "gpu_metrics")}
         # Which launch dominates by GPU time? Graphs whose work sits behind the sum (BASELINE configs 2 and 4) spend it in the main mixer's chain:
         # one workgroup per effect, a latency chain — the line then names that launch, bound "latency", with its time per block
         unit_ms = sum(l[1] * l[2] for l in legs)
@@ -513,7 +823,7 @@ def main():
                 out["roofline"].pop(k, None)
         if rt_legs:
             rt_dt = rt_dts[int(np.argsort(rt_dts)[len(rt_dts) // 2])]
-            rt_ach, (rt_ms, rt_bpl, rt_achieved, _) = roofline_of(rt_legs)
+            rt_ach, (rt_ms, rt_bpl, rt_achieved, _), _rt_bt = roofline_of(rt_legs)
             out["config"]["realtime"] = {
                 "what": f"one pg_graph_write_device call per {block}-frame block (src/output/wav.rs:210-250, cpal), same graph, same run",
                 "blocks_per_call": 1,
@@ -522,13 +832,14 @@ def main():
                 "roofline_frac": rt_achieved / HBM_PEAK_GBS,
                 "roofline_frac_min": rt_ach[0] / HBM_PEAK_GBS,
                 "roofline_frac_max": rt_ach[-1] / HBM_PEAK_GBS,
+                **{"roofline_frac_" + k: v for k, v in dist_of(rt_ach, 1.0 / HBM_PEAK_GBS).items()},
                 "kernel_ms_per_block": rt_ms / rt_bpl if rt_bpl else 0.0,
                 "repeats": len(rt_dts),
                 "timed_seconds": sum(rt_dts),
             }
         if S5:
             d5 = S5["dts"][int(np.argsort(S5["dts"])[len(S5["dts"]) // 2])]
-            _, (ms5, bpl5, ach5, _l5) = S5["roofline_of"](S5["legs"])
+            _, (ms5, bpl5, ach5, _l5), _bt5 = S5["roofline_of"](S5["legs"])
             out["config"]["strong_c5"] = {
                 "what": "BASELINE config 5: %d voices, per-voice Filter->Eq5->Delay->Reverb, split over the GPUs (strong scaling), master bus reduced per %d block(s); "
                         "the 8-GPU value over the 1-GPU value of this field is the >= 6x claim" % (S5["total_voices"], S5["M"]),

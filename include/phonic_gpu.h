@@ -311,11 +311,22 @@ int pg_graph_device_errors(pg_graph* g);
 int pg_graph_set_defer_bus(pg_graph* g, int defer);
 int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream);
 /* One process per GPU: the ranks' `audible` words ride with their partial buses. pg_graph_export_audible writes the words of the LAST
- * pg_graph_write_device call of a deferred-bus graph — one per block of max_frames, a chunk's flag in the word of its last piece, all 0 when
- * that call had nothing to render — as floats (0 / 1) to d_dst, e.g. right behind the call's samples: ONE sum-reduce then carries samples
- * and words (OR = sum > 0). pg_graph_process_bus_device_flags is pg_graph_process_bus_device with those summed words: the root's bus chain
- * takes EffectProcessor's decisions (bypass, tails; src/source/mixed/effect.rs:56-145) per chunk as the one main mixer would. */
+ * pg_graph_write_device call of a deferred-bus graph — ONE PER PIECE the call was rendered in, in order: a chunk of the reference's grid
+ * (min(remaining, 4096) frames from the call's start and from every main-mixer event, src/source/mixed.rs:216,679-712) is ceil(chunk / max_frames)
+ * pieces, a chunk's flag sits in the word of its last piece; all 0 when that call had nothing to render — as floats (0 / 1) to d_dst, e.g. right
+ * behind the call's samples: ONE sum-reduce then carries samples and words (OR = sum > 0). pg_graph_audible_words = how many words the last
+ * call left (an event-free call of n frames: one per block of max_frames when max_frames divides 4096); a deferred-bus call leaves at most
+ * max(64, 4096 / max_frames) words — a call that would need more is rendered up to there and returns the samples it rendered (the caller goes on
+ * with another call). pg_graph_process_bus_device_flags is pg_graph_process_bus_device with those summed words, consumed in the same order: the
+ * root's bus chain takes EffectProcessor's decisions (bypass, tails; src/source/mixed/effect.rs:56-145) per chunk as the one main mixer would.
+ * The chain walks the SAME chunk grid as the write: it restarts at the main mixer's effect events (queued by the write) and at the offsets where
+ * any other main-mixer event cut this graph's own deferred write of the same position. Ranks whose main-mixer SOURCES take events the root's
+ * graph does not hold must end their calls there on every rank: pg_graph_next_main_event (drains the control ring — writing thread only —
+ * and returns the sample time of the first main-mixer event behind pos_in_frames, UINT64_MAX when there is none) is what a caller min-reduces
+ * over the ranks to size the next call (phonic_amd/parallel.py: next_call_frames). */
 int pg_graph_export_audible(pg_graph* g, float* d_dst, int n_words, void* hip_stream);
+int pg_graph_audible_words(pg_graph* g);
+uint64_t pg_graph_next_main_event(pg_graph* g, uint64_t pos_in_frames);
 int pg_graph_process_bus_device_flags(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream, const float* d_flags, int n_words);
 /* Block until all work of the graph's stream has finished. */
 int pg_graph_synchronize(pg_graph* g);
@@ -382,7 +393,9 @@ int pg_sharded_stop_all_voices(pg_sharded_graph* s);
 int pg_sharded_remove_voice(pg_sharded_graph* s, int voice_id);
 int pg_sharded_is_voice_playing(pg_sharded_graph* s, int voice_id);
 /* Source::write: host buffer (waits for the result) / buffer on the root device (asynchronous on the shards' streams, several calls may be
- * enqueued before pg_sharded_synchronize; at most max_blocks x max_frames frames per call). Both return the samples written, or 0 when
+ * enqueued before pg_sharded_synchronize). A call of ANY length is ONE write of the one main mixer — messages processed once on every shard,
+ * one call end — walked on the reference's chunk grid (min(remaining, 4096) frames from the call's start and from every main-mixer event of
+ * any shard, src/source/mixed.rs:216,679-712) whatever max_blocks x max_frames is. Both return the samples written, or 0 when
  * the main mixer has nothing to do (mixed.rs:664-670: no playing source, sub-mixer or pending event on any shard and no effect on
  * mixer 0; the host learns that sources have ended from the device after a pg_sharded_write, as pg_graph_write does). */
 size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames);
@@ -407,6 +420,11 @@ int pg_graph_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* la
 /* The same for the launches of the main mixer's effect chain (one workgroup per effect behind the sum: a latency chain — for graphs whose
  * work is mostly on the bus, BASELINE configs 2 and 4, it is the launch that dominates by GPU time), and its name. */
 int pg_graph_bus_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* launches, uint64_t* blocks);
+/* What a workload off the steady state costs (events, voices that start and end, ramps): out[0] = unit-blocks rendered since the last reset
+ * (units x blocks of max_frames), out[1] = unit-blocks that left the time-parallel kernels for the generic kernel, out[2] = generic launches
+ * issued, out[3] = those that found work; *generic_ms / *generic_timed = GPU time and count of the generic launches that were hipEvent-timed
+ * (pg_graph_set_timing_period). Waits for the graph's stream. Measurement only (bench.py --workload dyn). */
+int pg_graph_dynamic_stats(pg_graph* g, int reset, uint64_t out[4], double* generic_ms, uint64_t* generic_timed);
 const char* pg_graph_bus_kernel(pg_graph* g);
 /* The hipEvent pair behind pg_graph_kernel_ms costs ~8 us of stream time per round: time every n-th round only (default 1 = every
  * round, 0 = never). pg_graph_kernel_ms then averages over the timed rounds and reports their count. */

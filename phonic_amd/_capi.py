@@ -273,8 +273,14 @@ def load():
     lib.pg_graph_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
     lib.pg_graph_export_audible.restype = C.c_int
     lib.pg_graph_export_audible.argtypes = [vp, vp, C.c_int, vp]
+    lib.pg_graph_audible_words.restype = C.c_int
+    lib.pg_graph_audible_words.argtypes = [vp]
+    lib.pg_graph_next_main_event.restype = C.c_uint64
+    lib.pg_graph_next_main_event.argtypes = [vp, C.c_uint64]
     lib.pg_graph_process_bus_device_flags.restype = C.c_int
     lib.pg_graph_process_bus_device_flags.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp, vp, C.c_int]
+    lib.pg_graph_dynamic_stats.restype = C.c_int
+    lib.pg_graph_dynamic_stats.argtypes = [vp, C.c_int, P(C.c_uint64), P(C.c_double), P(C.c_uint64)]
     lib.pg_graph_bus_kernel_stats.restype = C.c_int
     lib.pg_graph_bus_kernel_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)]
     lib.pg_graph_bus_kernel.restype = C.c_char_p

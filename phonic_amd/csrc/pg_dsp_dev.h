@@ -91,6 +91,23 @@ DEV float sm_next(PgSmooth& s) {  // :21-28
   if (sm_need_ramp(s)) { sm_ramp(s); return s.current; }
   return s.target;
 }
+// n successive values of sm_next into dst (one lane; the callers hand the sequence to all lanes). The exponential smoother — the one every
+// source volume / panning uses — as a tight loop: the ramp test and the ramp step share their one expression (smoothing.rs:198-214).
+DEV void sm_sequence(PgSmooth& s, float* dst, int n) {
+  if (s.kind == SM_EXP) {
+    float c = s.current;
+    const float t = s.target, a = s.a, comp = s.comp;
+    for (int i = 0; i < n; ++i) {
+      const float add = (t - c) * a * comp;
+      const bool ramp = fabsf(add) > F32_EPS100;
+      c = ramp ? c + add : c;
+      dst[i] = ramp ? c : t;
+    }
+    s.current = c;
+    return;
+  }
+  for (int i = 0; i < n; ++i) dst[i] = sm_next(s);
+}
 DEV void sm_init(PgSmooth& s, float v) {
   s.target = v; s.current = v;
   if (s.kind == SM_LIN) s.pending = 0;

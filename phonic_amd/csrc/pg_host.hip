@@ -43,6 +43,19 @@ int graph_quiesce(pg_graph* g) {
   if (g->unit_stream) HIP_TRY(pg_stream_sync(g->unit_stream));   // (every launch there is awaited by a sum on the write's stream: drained already)
   g->cmds_since_sync = 0;
   g->rows_free_fresh = false;
+  // Sources that were removed (RemoveSource, RemoveAllPendingEvents, their mixer's removal) and whose removal a topology upload has carried to the
+  // device since: no unit names them any more and nothing is in flight — their PCM / ring / staging memory goes back now (a host that cycles
+  // add_stream_voice / remove_voice would otherwise grow without bound until pg_graph_destroy; round-4 advisor finding). The reference drops a
+  // removed source on its collector thread (src/player.rs:1178-1196), never on the audio thread: this is a graph-changing call, not a write.
+  for (int id : g->retired_ready) {
+    HostVoice& hv = g->voices[id];
+    if (hv.d_pcm) (void)pg_free(hv.d_pcm);
+    if (hv.d_stage) (void)pg_free(hv.d_stage);
+    if (hv.h_ring) (void)pg_host_free(hv.h_ring);
+    hv.d_pcm = nullptr; hv.d_stage = nullptr; hv.h_ring = nullptr;
+    if (hv.stream) g->stream_voices.erase(std::remove(g->stream_voices.begin(), g->stream_voices.end(), id), g->stream_voices.end());
+  }
+  g->retired_ready.clear();
   return PG_OK;
 }
 
@@ -203,6 +216,9 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
   if ((size_t)std::max(g->n_graph_units, 1) > g->unit_out_rows || g->unit_out_blocks < std::max<size_t>(g->max_blocks, (PG_MAX_FRAMES + g->max_frames - 1) / g->max_frames))
     return set_error(PG_ERR_STATE, "per-unit buffers were not reserved by the mutating call");
   g->topo_dirty = false;
+  // (the removals collected so far travel with this upload: once the stream has drained no launch can reach those sources' memory)
+  g->retired_ready.insert(g->retired_ready.end(), g->retired_voices.begin(), g->retired_voices.end());
+  g->retired_voices.clear();
   g->last_change_round = g->launch_counter;  // the patch kernel marked every unit: the generic kernel must look at them again
   return PG_OK;
 }
@@ -300,7 +316,7 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   }
   (void)pg_memset(g->d_audible, 0, g->audible_slots * sizeof(int));
   if (pg_malloc((void**)&g->d_bus_progress, 2 * PG_BUS_PIPELINE_MAX * 8) == hipSuccess) (void)pg_memset(g->d_bus_progress, 0xff, 2 * PG_BUS_PIPELINE_MAX * 8); else g->d_bus_progress = nullptr;
-  if (pg_malloc((void**)&g->d_error, 16) == hipSuccess) (void)pg_memset(g->d_error, 0, 16); else g->d_error = nullptr;
+  if (pg_malloc((void**)&g->d_error, 32) == hipSuccess) (void)pg_memset(g->d_error, 0, 32); else g->d_error = nullptr;   // [0] flags, [2..3] u64 deferred unit-blocks, [4..5] u64 generic launches with work
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     g->h_feedback[0] = ~0ull;  // nothing reported yet
     g->h_feedback[1] = 0; g->h_feedback[2] = 0;  // [1] status word (graph_enqueue_status), [2] consistency flags the kernels mirror here
@@ -425,6 +441,7 @@ static void apply_remove_pending(pg_graph* g, uint64_t pos) {
         mx.messages.erase(std::remove_if(mx.messages.begin(), mx.messages.end(), [v](const PgCmd& c) { return c.param == v; }), mx.messages.end());
         g->voices[v].mixer = -1;
         g->voice_alive_tab.set((size_t)v, 0);
+        g->retired_voices.push_back(v);
         mx.voices.erase(mx.voices.begin() + i);
         if (&mx == &g->mixers[0] && g->main_active_voices > 0) g->main_active_voices -= 1;
         g->topo_dirty = true;
@@ -451,7 +468,7 @@ int pg_graph_remove_mixer(pg_graph* g, int mixer_id) {
     HostMixer& mx = g->mixers[gone[i]];
     for (int c : mx.children) gone.push_back(c);
     for (int f : mx.fx) { g->fx_mixer[f] = -1; g->fx_kind_tab.set((size_t)f, -1); }
-    for (int v : mx.voices) { g->voices[v].mixer = -1; g->voice_alive_tab.set((size_t)v, 0); }
+    for (int v : mx.voices) { g->voices[v].mixer = -1; g->voice_alive_tab.set((size_t)v, 0); g->retired_voices.push_back(v); }
     mx.children.clear(); mx.fx.clear(); mx.voices.clear(); mx.events.clear(); mx.messages.clear(); mx.bus_events.clear();
     mx.removed = true;
   }
@@ -785,7 +802,11 @@ int pg_graph_stop_voice(pg_graph* g, int voice_id, uint64_t sample_time) {  // M
   return voice_message(g, voice_id, pgc::CT_VOICE_STOP, 0.0f, 0.0, sample_time);
 }
 int pg_graph_remove_voice(pg_graph* g, int voice_id) {  // MixerMessage::RemoveSource (mixed.rs:149-151,400-402)
-  return voice_message(g, voice_id, pgc::CT_VOICE_REMOVE, 0.0f, 0.0, 0);
+  const int rc = voice_message(g, voice_id, pgc::CT_VOICE_REMOVE, 0.0f, 0.0, 0);
+  // the id is dead for every later call from here on (a second remove, a volume change: PG_ERR_NOT_FOUND as the header says), not only once the
+  // next write has drained the message; messages pushed before this one are still delivered (the ring keeps their order)
+  if (rc == PG_OK) g->voice_alive_tab.set((size_t)voice_id, 0);
+  return rc;
 }
 
 static void push_event(pg_graph* g, int mixer, uint64_t sample_time, const PgCmd& cmd) {
@@ -846,6 +867,7 @@ static void drain_control_messages(pg_graph* g) {
           if (hv.mixer == 0 && !hv.transient && g->main_active_voices > 0) g->main_active_voices -= 1;
           g->voices[m.id].mixer = -1;
           g->voice_alive_tab.set((size_t)m.id, 0);
+          g->retired_voices.push_back(m.id);
           g->topo_dirty = true;
           break;
         }
@@ -930,6 +952,12 @@ int pg_graph_set_timing_period(pg_graph* g, int every_n_rounds) {
     g->ev_pool.emplace_back(a, b);
     g->ev_blocks.push_back(1);
   }
+  while (g->timing_period > 0 && g->ev_gen_pool.size() < 512) {   // the generic kernel's launches (pg_graph_dynamic_stats)
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g->ev_gen_pool.emplace_back(a, b);
+  }
   while (g->timing_period > 0 && g->ev_bus_pool.size() < 512) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -981,6 +1009,34 @@ int pg_graph_kernel_stats(pg_graph* g, int reset, double* total_ms, uint64_t* la
   if (launches) *launches = n_ok;
   if (blocks) *blocks = n_blocks;
   if (reset) g->ev_used = 0;
+  return PG_OK;
+}
+// What a workload off the steady state costs (bench.py --workload dyn): out[0] = unit-blocks rendered since the last reset (units x blocks of
+// max_frames, every level), out[1] = unit-blocks that left the time-parallel kernels for the generic kernel (a command inside the block, a
+// smoother still moving, a topology change: the deferral protocol), out[2] = generic launches issued, out[3] = of those, the launches
+// that found work; *generic_ms = GPU time of the generic launches that were hipEvent-timed (pg_graph_set_timing_period), *generic_timed their
+// number. Waits for the graph's stream.
+int pg_graph_dynamic_stats(pg_graph* g, int reset, uint64_t out[4], double* generic_ms, uint64_t* generic_timed) {
+  (void)hipSetDevice(g->device);
+  HIP_TRY(pg_stream_sync(g->stream));
+  if (g->last_stream && g->last_stream != g->stream) HIP_TRY(pg_stream_sync(g->last_stream));
+  unsigned long long dev[3] = {0, 0, 0};
+  if (g->d_error) HIP_TRY(pg_memcpy(dev, (const char*)g->d_error + 8, 16, hipMemcpyDeviceToHost));
+  if (out) { out[0] = g->stat_unit_blocks; out[1] = dev[0]; out[2] = g->stat_generic_launches; out[3] = dev[1]; }
+  double total = 0.0;
+  uint64_t n_ok = 0;
+  for (size_t i = 0; i < g->ev_gen_used; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g->ev_gen_pool[i].second) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, g->ev_gen_pool[i].first, g->ev_gen_pool[i].second) != hipSuccess) continue;
+    total += ms; n_ok += 1;
+  }
+  if (generic_ms) *generic_ms = total;
+  if (generic_timed) *generic_timed = n_ok;
+  if (reset) {
+    g->ev_gen_used = 0; g->stat_unit_blocks = 0; g->stat_generic_launches = 0;
+    if (g->d_error) HIP_TRY(pg_memset((char*)g->d_error + 8, 0, 16));
+  }
   return PG_OK;
 }
 // The same for the launches of the main mixer's bus chain (timed in the rounds whose unit launches are timed).
@@ -1150,13 +1206,19 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
     if (bracket) HIP_TRY(hipEventRecord(e1, stream));
     L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
-    if (!sp.generic_idle) HIP_TRY(pg_launch_units(L, stream, timed_here && time_generic ? e0 : nullptr, timed_here && time_generic ? e1 : nullptr));
+    if (!sp.generic_idle) {
+      hipEvent_t g0 = timed_here && time_generic ? e0 : nullptr, g1 = timed_here && time_generic ? e1 : nullptr;
+      if (timed_here && !time_generic && g->ev_gen_used < g->ev_gen_pool.size()) { g0 = g->ev_gen_pool[g->ev_gen_used].first; g1 = g->ev_gen_pool[g->ev_gen_used].second; g->ev_gen_used++; }   // (rides on the dispatch)
+      HIP_TRY(pg_launch_units(L, stream, g0, g1));
+      g->stat_generic_launches++;
+    }
   } else {
     L.mode = 0;
     if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
     HIP_TRY(pg_launch_units(L, stream, e0, e1));
   }
   if (timed_here) { g->ev_blocks[g->ev_used] = (uint32_t)sp.n_chunks; g->ev_used++; }
+  g->stat_unit_blocks += (uint64_t)lv.cnt * (uint64_t)sp.n_chunks;
   return PG_OK;
 }
 // The level that holds most units carries the timing events of a round
@@ -1208,6 +1270,7 @@ bool graph_is_empty(const pg_graph* g) {
   for (size_t m = 1; m < g->mixers.size(); ++m) no_sub_mixers &= g->mixers[m].removed;
   return g->main_active_voices == 0 && g->mixers[0].fx.empty() && no_sub_mixers && g->mixers[0].events.empty();
 }
+void drain_control_messages_public(pg_graph* g) { drain_control_messages(g); }
 uint64_t graph_next_main_event(const pg_graph* g) { return g->mixers[0].events.empty() ? UINT64_MAX : g->mixers[0].events.front().sample_time; }
 // The number of main-mixer sources still alive -> the graph's mapped status word, behind everything enqueued on `stream` so far;
 // graph_collect_status reads it once the stream has drained.
@@ -1348,6 +1411,11 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   const uint64_t frames = n_samples / 2, mf = g->max_frames, CH = PG_MAX_FRAMES;
   uint64_t done = 0;
   auto fail = [&]() -> size_t { g->failed = true; return 0; };
+  // Deferred bus chain: the call leaves ONE `audible` word per piece it emits, in order (a running cursor — a chunk that an event cut short
+  // has pieces of its own, and max_frames need not divide a chunk), and the offsets at which an event restarted the chunk grid:
+  // process_bus_impl walks the same grid with the same cursor (round-4 advisor finding: the words used to sit at done / max_frames).
+  uint64_t word_cursor = 0;
+  if (g->defer_bus) { g->defer_cuts.clear(); g->defer_pos = pos; g->defer_words = 0; }
   while (done < frames) {
     const uint64_t now = pos + done;
     HostMixer& main = g->mixers[0];
@@ -1375,6 +1443,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     uint64_t span = frames - done;
     if (!main.events.empty()) span = std::min<uint64_t>(span, main.events.front().sample_time - now);
     if (span == 0) continue;
+    const bool span_ends_at_event = span < frames - done;   // the grid restarts behind this span
     uint64_t chunk_n = std::min<uint64_t>(span, CH);
     // StopSource messages: processed by process_messages at the start of write (:294-499)
     if (g->messages_due) {
@@ -1398,6 +1467,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       for (const HostMixer& mx : g->mixers) if (!mx.events.empty()) t_next = std::min(t_next, mx.events.front().sample_time);
       if (t_next != UINT64_MAX && t_next < now + kmax * mf) kmax = t_next > now ? (t_next - now) / mf : 0;
       // the launch must end where a chunk ends: at a multiple of the chunk length or at the end of the span
+      if (g->defer_bus) kmax = std::min<uint64_t>(kmax, g->audible_slots - std::min<uint64_t>(word_cursor, g->audible_slots));   // (one word per block)
       if (CH % mf == 0) k = (kmax * mf >= span && span % mf == 0) ? span / mf : (kmax / (CH / mf)) * (CH / mf);
       else k = (span % mf == 0 && span <= CH && span / mf <= kmax) ? span / mf : 0;
     }
@@ -1432,7 +1502,8 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
         g->rows_free_fresh = false;
       }
       // where the blocks' `audible` words go: with the bus chain deferred to the caller, word c of the call belongs to its c-th block
-      const int slot = g->defer_bus ? (int)std::min<uint64_t>(done / mf, (uint64_t)g->audible_slots - k) : 0;
+      const int slot = g->defer_bus ? (int)word_cursor : 0;
+      if (g->defer_bus) { word_cursor += k; g->defer_words = (int)word_cursor; }
       {
         const Level& top = g->levels.back();
         HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_out + done * 2, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
@@ -1441,6 +1512,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       if (overlap) { HIP_TRY_FAIL(hipEventRecord(g->ev_rows_free, stream)); g->rows_free_fresh = true; }
       if (!g->defer_bus && launch_bus(g, d_out + done * 2, sp, slot, stream)) return fail();
       done += k * mf;
+      if (g->defer_bus && span_ends_at_event && k * mf == span && done < frames) g->defer_cuts.push_back(done);
       continue;
     }
     // ---- one chunk, piece by piece ----
@@ -1457,6 +1529,12 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       if (cuts.size() > (size_t)(PG_MAX_CALLS - 1)) chunk_n = cuts[PG_MAX_CALLS - 1] - now;
     }
     const uint64_t n_pieces = (chunk_n + mf - 1) / mf, n_full = chunk_n / mf;
+    if (g->defer_bus && word_cursor + n_pieces > g->audible_slots) {
+      // the call has used up its `audible` words (audible_slots = max(64, pieces of one chunk): only a call longer than 64 pieces, or one cut by
+      // many events, gets here): what was rendered is returned, the caller goes on with another call — silent aliasing of words is not an option
+      set_error(PG_ERR_PARAMETER, "a deferred-bus write leaves at most %zu `audible` words: %llu frames rendered, call again for the rest", g->audible_slots, (unsigned long long)done);
+      break;
+    }
     if (n_pieces > g->unit_out_blocks) { set_error(PG_ERR_STATE, "per-unit buffers were not reserved for a chunk's pieces"); return fail(); }
     std::vector<LaunchSpan> spans((size_t)n_pieces);
     const uint64_t round0 = g->launch_counter;
@@ -1491,7 +1569,8 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       }
     }
     // the chunk's sum and bus chain: its full pieces in one launch each, a shorter last piece in launches of its own
-    const int slot0 = g->defer_bus ? (int)std::min<uint64_t>(done / mf, (uint64_t)g->audible_slots - n_pieces) : 0;
+    const int slot0 = g->defer_bus ? (int)word_cursor : 0;
+    if (g->defer_bus) { word_cursor += n_pieces; g->defer_words = (int)word_cursor; }
     const size_t chunk_stride = (size_t)g->unit_out_rows * g->stride;
     const Level& top = g->levels.back();
     float* dst = d_out + done * 2;
@@ -1519,6 +1598,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       }
     }
     done += chunk_n;
+    if (g->defer_bus && span_ends_at_event && chunk_n == span && done < frames) g->defer_cuts.push_back(done);
   }
   return (size_t)done * 2;
 }
@@ -1581,6 +1661,13 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
   const uint64_t frames = n_samples / 2, mf = g->max_frames, CH = PG_MAX_FRAMES;
   uint64_t done = 0;
   HostMixer& main = g->mixers[0];
+  // The chunk grid of the write this bus belongs to: it restarts at the bus events (queued below) AND wherever another main-mixer event — a
+  // volume / panning / speed / seek event of a main-mixer source — cut the write; those offsets were recorded by this graph's own deferred write
+  // of the same position (a root that renders no partial of its own, or ranks whose main-mixer sources take events the root does not see: the
+  // caller cuts its calls there, pg_graph_next_main_event). Words are consumed with a running cursor, one per piece, as the write emitted them.
+  const std::vector<uint64_t>* cuts = (g->defer_bus && g->defer_pos == pos_in_frames) ? &g->defer_cuts : nullptr;
+  size_t cut_i = 0;
+  uint64_t word_cursor = 0;
   while (done < frames) {
     const uint64_t now = pos_in_frames + done;
     // effect events of the main mixer (queued by write in defer_bus mode) cut the bus into chunks at their sample times, exactly
@@ -1594,6 +1681,10 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
     }
     uint64_t span = frames - done;
     if (!main.bus_events.empty()) span = std::min<uint64_t>(span, main.bus_events.front().sample_time - now);
+    if (cuts) {
+      while (cut_i < cuts->size() && (*cuts)[cut_i] <= done) ++cut_i;
+      if (cut_i < cuts->size()) span = std::min<uint64_t>(span, (*cuts)[cut_i] - done);
+    }
     if (span == 0) continue;
     // whole blocks of max_frames in one launch (as many chunks as the span holds), a chunk's shorter last piece in a launch of its own
     const PgCmd* d_cmds = nullptr;
@@ -1615,8 +1706,10 @@ int process_bus_impl(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_i
       }
       sp.n_chunks = (int)k;
       if (off == 0 && d_cmds) { sp.d_cmds = d_cmds; sp.n_cmds = (int)cmds.size(); }
-      // word c of the call belongs to its c-th block of max_frames (a chunk's flag sits in the word of its last piece)
-      const uint64_t word = std::min<uint64_t>((done + off) / mf, (uint64_t)g->audible_slots - k);
+      // one word per piece, in the order the write emitted them (a chunk's flag sits in the word of its last piece)
+      if (bus_audible && word_cursor + k > g->audible_slots) return set_error(PG_ERR_PARAMETER, "the bus chain ran out of `audible` words (%zu): cut the call as the write was cut", g->audible_slots);
+      const uint64_t word = word_cursor;
+      word_cursor += k;
       auto one = [&](const LaunchSpan& q, float* dst, int* flags) -> int {
         PgLaunch B;
         fill_launch(g, q, B);
@@ -1664,6 +1757,12 @@ extern "C" {
 int pg_graph_process_bus_device(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream) {
   return process_bus_impl(g, d_bus, n_samples, pos_in_frames, hip_stream ? (hipStream_t)hip_stream : g->stream, nullptr);
 }
+int pg_graph_audible_words(pg_graph* g) { return g->audible_valid ? g->defer_words : 0; }
+uint64_t pg_graph_next_main_event(pg_graph* g, uint64_t pos_in_frames) {
+  drain_control_messages_public(g);
+  for (const Event& e : g->mixers[0].events) if (e.sample_time > pos_in_frames) return e.sample_time;
+  return UINT64_MAX;
+}
 int pg_graph_export_audible(pg_graph* g, float* d_dst, int n_words, void* hip_stream) {
   if (n_words < 0 || (size_t)n_words > g->audible_slots) return set_error(PG_ERR_PARAMETER, "a write leaves at most %zu words", g->audible_slots);
   if (n_words == 0) return PG_OK;
@@ -1676,7 +1775,8 @@ int pg_graph_export_audible(pg_graph* g, float* d_dst, int n_words, void* hip_st
 int pg_graph_process_bus_device_flags(pg_graph* g, float* d_bus, size_t n_samples, uint64_t pos_in_frames, void* hip_stream, const float* d_flags, int n_words) {
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : g->stream;
   if (!d_flags) return process_bus_impl(g, d_bus, n_samples, pos_in_frames, s, nullptr);
-  const size_t need = (n_samples / 2 + g->max_frames - 1) / g->max_frames;
+  const size_t fr = n_samples / 2, per_chunk = (PG_MAX_FRAMES + g->max_frames - 1) / g->max_frames;
+  const size_t need = (fr / PG_MAX_FRAMES) * per_chunk + (fr % PG_MAX_FRAMES + g->max_frames - 1) / g->max_frames;   // pieces of an event-free call (events add pieces: pg_graph_audible_words)
   if (n_words < 0 || (size_t)n_words > g->audible_slots || (size_t)n_words < need) return set_error(PG_ERR_PARAMETER, "the bus chain needs one word per block of max_frames (%zu)", need);
   (void)hipSetDevice(g->device);
   hipLaunchKernelGGL(pg_float_to_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_flags, g->d_audible, n_words);

@@ -245,13 +245,22 @@ struct pg_graph {
   size_t bus_frames = 0;        // frames the staging of pg_graph_write holds (whole chunks: >= PG_MAX_FRAMES)
   size_t audible_slots = 0;     // words of d_audible: one per block of a launch sequence / piece of a chunk
   bool audible_valid = false;   // the last write rendered (its `audible` words are in d_audible)
+  // the last deferred-bus write: its position, the words it left (one per piece, in order) and the offsets at which a main-mixer event
+  // restarted its chunk grid — pg_graph_process_bus_device of the same position walks the same grid
+  uint64_t defer_pos = UINT64_MAX;
+  int defer_words = 0;
+  std::vector<uint64_t> defer_cuts;
   // Graphs with a bus chain, super-block launches: the unit kernels of launch sequence s + 1 run on a stream of their own UNDER the bus chain of
   // sequence s (one workgroup per effect: the machine is all but idle while it walks the blocks). They need the sum of sequence s to have read
   // the per-unit rows (ev_rows_free, recorded behind the mix launch, in front of the bus launch); the sum of s + 1 needs them done (ev_units_done).
   hipStream_t unit_stream = nullptr;
   hipEvent_t ev_units_done = nullptr, ev_rows_free = nullptr;
   hipStream_t overlap_stream = nullptr;  // the write stream ev_rows_free was last recorded on
-  bool rows_free_fresh = false;  // ev_rows_free was recorded behind everything the caller's stream holds that the next unit launch must follow
+  bool rows_free_fresh = false;  // ev_rows_free was recorded behind everything the caller's stream holds that the next unit launch must follow.
+                                 // INVARIANT: whatever the library enqueues on a write's stream that a unit kernel reads — topology uploads, command
+                                 // lists (stage_commands), stream feeds, a change of stream — must clear this flag (all of them do: rebuild_topology,
+                                 // the piece path, flush_stream_feeds, graph_quiesce); the flag persists across calls on purpose, so that a call's
+                                 // unit kernels run under the bus chain of the call before. A caller's own work on that stream never feeds a unit kernel.
   uint64_t bus_group = 16;       // blocks per launch sequence of a small unit level in front of a bus chain (PHONIC_BUS_GROUP)
   bool overlap_bus = true;       // PHONIC_BUS_OVERLAP=0 (read at create): everything on the caller's stream
   bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
@@ -263,6 +272,8 @@ struct pg_graph {
   std::vector<HostMixer> mixers;        // [0] = main
   std::vector<HostVoice> voices;
   std::vector<int> stream_voices;       // ids of the host-fed voices (their feeds are flushed at the top of every write)
+  std::vector<int> retired_voices;      // removed sources whose removal has not reached the device yet (the next topology upload carries it)
+  std::vector<int> retired_ready;       // ... and those it has: their memory is released at the next graph_quiesce
   std::vector<std::unique_ptr<HostFx>> fx;
   std::vector<int> fx_mixer;            // effect id -> mixer id
   std::vector<int> source_unit_of_voice;  // main-mixer voices: unit slot
@@ -315,11 +326,16 @@ struct pg_graph {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_bus_pool;
   std::vector<uint32_t> ev_bus_blocks;
   size_t ev_bus_used = 0;
+  // ... and of the generic kernel's launches, with the counters behind pg_graph_dynamic_stats
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_gen_pool;
+  size_t ev_gen_used = 0;
+  uint64_t stat_unit_blocks = 0, stat_generic_launches = 0;
 };
 
 // ---- graph internals used by the sharded handle (pg_host.hip) -------------------------------------------------
 int graph_quiesce(pg_graph* g);
 void graph_begin_write(pg_graph* g, uint64_t pos);
+void drain_control_messages_public(pg_graph* g);
 bool graph_is_empty(const pg_graph* g);
 uint64_t graph_next_main_event(const pg_graph* g);
 int graph_enqueue_status(pg_graph* g, hipStream_t stream);

@@ -16,6 +16,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <thread>
@@ -24,12 +25,14 @@
 
 // bus[i] = own[i] + sum of the peers' partials in shard order; audible_out[c] = OR over the shards of their flag for chunk c
 __global__ void pg_shard_sum_kernel(float* __restrict__ bus, const float* __restrict__ own, const float* __restrict__ gathered, int n_peers, size_t peer_stride, int n,
-                                    const int* __restrict__ flags, int n_shards, int n_chunks, int* __restrict__ audible_out) {
+                                    const int* __restrict__ flags, int n_shards, int n_chunks, int* __restrict__ audible_out, int flag_stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && (int)threadIdx.x < n_chunks && audible_out) {
-    int a = 0;
-    for (int k = 0; k < n_shards; ++k) a |= flags[k * PG_AUDIBLE_SLOTS + (int)threadIdx.x];
-    audible_out[threadIdx.x] = a;
+  if (blockIdx.x == 0 && audible_out) {
+    for (int c = (int)threadIdx.x; c < n_chunks; c += (int)blockDim.x) {
+      int a = 0;
+      for (int k = 0; k < n_shards; ++k) a |= flags[k * flag_stride + c];
+      audible_out[c] = a;
+    }
   }
   if (i >= n) return;
   float acc = own[i];
@@ -105,9 +108,16 @@ struct ShardWorker {
     { std::lock_guard<std::mutex> lock(m); posted.fetch_add(1, std::memory_order_release); }
     cv.notify_one();
   }
-  int wait() {  // (the caller needs the result before it can go on: it spins)
+  int wait() {  // (the caller needs the result before it can go on: it spins — with a bound: a job that never returns fails the handle)
     const uint64_t want = posted.load(std::memory_order_acquire);
-    while (finished.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+    static const double limit_s = [] { const char* e = getenv("PHONIC_SHARD_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 30.0; }();
+    auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (finished.load(std::memory_order_acquire) != want) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+        return set_error(PG_ERR_DEVICE, "a shard's issuing thread did not report back within %.0f s: the sharded graph is disabled", limit_s);
+    }
     if (rc) set_error(rc, "%s", error.c_str());
     return rc;
   }
@@ -124,6 +134,8 @@ struct pg_sharded_graph {
   std::vector<int> load;                 // sub-mixers + main-mixer sources placed on each shard
   uint32_t sample_rate = 48000;
   size_t max_frames = 0, max_blocks = 1, stride = 0;
+  size_t stage_frames = 0;               // frames the partial / gather / bus staging holds: max(max_blocks x max_frames, one chunk of the reference's grid)
+  size_t flag_stride = PG_AUDIBLE_SLOTS; // words per shard in d_flags (= the shards' audible_slots)
   std::vector<float*> d_partial;         // per shard, on its device: [max_blocks * stride] partial master bus
   float* d_gather = nullptr;             // root device: the peers' partials [(n - 1)][max_blocks * stride]
   int* d_flags = nullptr;                // root device: the shards' `audible` words [n][PG_AUDIBLE_SLOTS] of the segment being summed
@@ -142,7 +154,8 @@ static inline int shard_of(int32_t packed) { return (int)((uint32_t)packed >> 24
 static inline int local_of(int32_t packed) { return (int)((uint32_t)packed & 0xffffffu); }
 
 static int sharded_alloc_buffers(pg_sharded_graph* s) {
-  const size_t words = s->stride * s->max_blocks + 4;
+  s->stage_frames = std::max<size_t>(s->max_frames * s->max_blocks, PG_MAX_FRAMES);
+  const size_t words = 2 * s->stage_frames + 4;
   const size_t n = s->shards.size();
   for (size_t i = 0; i < n; ++i) {
     HIP_TRY(hipSetDevice(s->shards[i]->device));
@@ -187,7 +200,8 @@ pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count
   }
   s->d_partial.assign((size_t)n_devices, nullptr);
   (void)hipSetDevice(devices[0]);
-  const size_t flag_bytes = (size_t)n_devices * PG_AUDIBLE_SLOTS * sizeof(int);
+  s->flag_stride = s->shards[0]->audible_slots;
+  const size_t flag_bytes = (size_t)n_devices * s->flag_stride * sizeof(int);
   if (hipEventCreateWithFlags(&s->summed, hipEventDisableTiming) != hipSuccess || pg_malloc((void**)&s->d_flags, flag_bytes) != hipSuccess || sharded_alloc_buffers(s.get())) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
     pg_sharded_destroy(s.release());   // (shards, events and what was allocated so far)
@@ -407,33 +421,37 @@ int pg_sharded_is_voice_playing(pg_sharded_graph* s, int voice_id) {
 
 }  // extern "C"
 
-// One segment of a write: frames without a main-mixer event of any shard inside. Every shard renders its partial bus (asynchronously, on
-// its own device and stream) and its `audible` words, one per chunk of max_frames; partials and words meet on the root; the bus chain
-// runs behind the sum with the OR-ed words.
-static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_samples, size_t n_samples, uint64_t pos) {
-  const size_t cap = s->stride * s->max_blocks;
+// One span of a write: frames without a main-mixer event of any shard inside, starting on the chunk grid (at the call's start, at an event,
+// or a whole number of chunks behind either). Every shard renders its partial bus (asynchronously, on its own device and stream) into its
+// staging at `stage_off` and leaves one `audible` word per piece; partials and words meet on the root; the bus chain runs behind the sum with
+// the OR-ed words.
+static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stage_off, size_t n_samples, uint64_t pos) {
+  const size_t cap = 2 * s->stage_frames;
   const size_t n = s->shards.size();
   pg_graph* root = s->shards[0];
-  const int n_chunks = (int)std::min<size_t>((n_samples / 2 + s->max_frames - 1) / s->max_frames, PG_AUDIBLE_SLOTS);
+  // words of the span: one per piece (whole chunks of ceil(PG_MAX_FRAMES / max_frames) pieces, then the pieces of the last, shorter chunk)
+  const size_t fr = n_samples / 2, per_chunk = (PG_MAX_FRAMES + s->max_frames - 1) / s->max_frames;
+  const int n_chunks = (int)std::min<size_t>((fr / PG_MAX_FRAMES) * per_chunk + (fr % PG_MAX_FRAMES + s->max_frames - 1) / s->max_frames, s->flag_stride);
   const bool rccl = s->reduce_mode == PG_REDUCE_RCCL;
   // every shard's launch sequence, its `audible` words and (peer-copy mode) the copies that carry both to the root: issued by the shard's own
   // thread when the handle has workers (shard 0 by the caller's), else one after the other here
-  auto issue = [s, off_samples, n_samples, pos, n_chunks, rccl, cap, root](size_t i) -> int {
+  auto issue = [s, stage_off, n_samples, pos, n_chunks, rccl, cap, root](size_t i) -> int {
     pg_graph* g = s->shards[i];
     HIP_TRY(hipSetDevice(g->device));
-    float* part = s->d_partial[i] + off_samples;
+    float* part = s->d_partial[i] + stage_off;
     const size_t w = graph_write_impl(g, part, n_samples, pos, g->stream, false);
     if (g->failed) return PG_ERR_DEVICE;
+    if (w != 0 && w != n_samples) return set_error(PG_ERR_STATE, "shard %d rendered %zu of %zu samples of a span", (int)i, w, n_samples);
     if (w == 0) {  // nothing on this shard: a silent partial and silent flags (not the words an earlier call left there)
       HIP_TRY(hipMemsetAsync(part, 0, n_samples * sizeof(float), g->stream));
-      HIP_TRY(hipMemsetAsync(g->d_audible, 0, PG_AUDIBLE_SLOTS * sizeof(int), g->stream));
+      HIP_TRY(hipMemsetAsync(g->d_audible, 0, g->audible_slots * sizeof(int), g->stream));
     }
     if (rccl) return PG_OK;
     // the root's sum of the previous segment (or call) must have read the gather buffers before this shard overwrites them
     if (s->summed_recorded) HIP_TRY(hipStreamWaitEvent(g->stream, s->summed, 0));
     if (i > 0) {
-      HIP_TRY(hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4) + off_samples, root->device, part, g->device, n_samples * sizeof(float), g->stream));
-      HIP_TRY(hipMemcpyPeerAsync(s->d_flags + i * PG_AUDIBLE_SLOTS, root->device, g->d_audible, g->device, (size_t)n_chunks * sizeof(int), g->stream));
+      HIP_TRY(hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4) + stage_off, root->device, part, g->device, n_samples * sizeof(float), g->stream));
+      HIP_TRY(hipMemcpyPeerAsync(s->d_flags + i * s->flag_stride, root->device, g->d_audible, g->device, (size_t)n_chunks * sizeof(int), g->stream));
       HIP_TRY(hipEventRecord(s->done[i], g->stream));
     } else {
       HIP_TRY(hipMemcpyAsync(s->d_flags, g->d_audible, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, g->stream));
@@ -455,7 +473,7 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_
     ncclResult_t r = g_rccl.GroupStart();
     for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
       pg_graph* g = s->shards[i];
-      r = g_rccl.Reduce(s->d_partial[i] + off_samples, i == 0 ? d_out + off_samples : nullptr, n_samples, ncclFloat32, ncclSum, 0, s->comms[i], g->stream);
+      r = g_rccl.Reduce(s->d_partial[i] + stage_off, i == 0 ? d_dst : nullptr, n_samples, ncclFloat32, ncclSum, 0, s->comms[i], g->stream);
       if (r == ncclSuccess) r = g_rccl.Reduce(g->d_audible, i == 0 ? (void*)s->d_flags : nullptr, (size_t)n_chunks, ncclInt32, ncclMax, 0, s->comms[i], g->stream);
     }
     const ncclResult_t e = g_rccl.GroupEnd();
@@ -465,21 +483,27 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_out, size_t off_
     HIP_TRY(hipMemcpyAsync(root->d_audible, s->d_flags, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, root->stream));
   } else {
     for (size_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root->stream, s->done[i], 0));
-    hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_out + off_samples, s->d_partial[0] + off_samples,
-                       s->d_gather + off_samples, (int)n - 1, cap + 4, (int)n_samples, s->d_flags, (int)n, n_chunks, root->d_audible);
+    hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_dst, s->d_partial[0] + stage_off,
+                       s->d_gather + stage_off, (int)n - 1, cap + 4, (int)n_samples, s->d_flags, (int)n, n_chunks, root->d_audible, (int)s->flag_stride);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->summed, root->stream));
     s->summed_recorded = true;
   }
-  return process_bus_impl(root, d_out + off_samples, n_samples, pos, root->stream, root->d_audible);
+  root->defer_pos = UINT64_MAX;   // (the handle cuts the spans itself: the root's bus chain takes no recorded cuts)
+  return process_bus_impl(root, d_dst, n_samples, pos, root->stream, root->d_audible);
 }
 
-// Source::write of the sharded main mixer, result in d_out (root device) on the root shard's stream. Returns the samples written, 0
-// when the one main mixer would return 0: no playing source, no sub-mixer and no pending event on any shard, and no effect on mixer 0.
-static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos) {
+// Source::write of the sharded main mixer: ONE write call of the one mixer whatever its length (process_messages once on every shard, one
+// call end — src/source/mixed.rs:659-719), walked on the reference's chunk grid: min(remaining, PG_MAX_FRAMES) frames from the call's start
+// and from every main-mixer event of ANY shard. A segment between two events is rendered in spans of whole chunks, as many as the staging
+// holds (stage_frames >= one chunk), so every shard takes its per-chunk decisions on the chunks the one mixer would see — whatever
+// max_blocks x max_frames is (round-4 advisor finding: the host-buffer write used to open a fresh call per max_blocks x max_frames frames).
+// `contiguous`: d_out holds the whole call (device writes); else every span lands at d_out + 0 (the staging bus of host writes) and
+// `span_done(offset, samples)` takes it away. Returns the samples written, 0 when the one main mixer would return 0: no playing source, no
+// sub-mixer and no pending event on any shard, and no effect on mixer 0.
+static size_t sharded_write_walk(pg_sharded_graph* s, float* d_out, bool contiguous, size_t n_samples, uint64_t pos, const std::function<int(size_t, size_t)>& span_done) {
   if (s->failed) return 0;
-  const size_t cap = s->stride * s->max_blocks;
-  if (n_samples > cap || n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "a sharded write holds at most max_blocks x max_frames stereo frames"); return 0; }
+  if (n_samples % 2 != 0) { set_error(PG_ERR_PARAMETER, "n_samples must be a multiple of the channel count"); return 0; }
   // process_messages of the one mixer: every shard takes its messages now, none later in this call
   bool empty = true;
   for (pg_graph* g : s->shards) {
@@ -489,42 +513,50 @@ static size_t sharded_write_impl(pg_sharded_graph* s, float* d_out, size_t n_sam
     empty &= graph_is_empty(g);
   }
   if (empty) return 0;
-  const uint64_t frames = n_samples / 2;
+  const uint64_t frames = n_samples / 2, CH = PG_MAX_FRAMES;
+  // spans hold whole chunks; the words of a span must fit the shards' word tables (flag_stride = max(64, pieces of one chunk))
+  const uint64_t per_chunk = (CH + s->max_frames - 1) / s->max_frames;
+  const uint64_t span_chunks = std::max<uint64_t>(1, std::min<uint64_t>(s->stage_frames / CH, s->flag_stride / per_chunk));
   uint64_t done = 0;
+  size_t stage_off = 0;
   while (done < frames) {
     // the segment ends where the next main-mixer event of any shard comes due (events at or before `now` apply at the segment's head)
     const uint64_t now = pos + done;
-    uint64_t n = frames - done;
+    uint64_t seg = frames - done;
     for (pg_graph* g : s->shards)
-      for (const Event& e : g->mixers[0].events) { if (e.sample_time > now) { n = std::min<uint64_t>(n, e.sample_time - now); break; } }
-    if (sharded_render_segment(s, d_out, (size_t)done * 2, (size_t)n * 2, now)) { s->failed = true; return 0; }
-    done += n;
+      for (const Event& e : g->mixers[0].events) { if (e.sample_time > now) { seg = std::min<uint64_t>(seg, e.sample_time - now); break; } }
+    uint64_t off = 0;
+    while (off < seg) {
+      const uint64_t n = std::min<uint64_t>(seg - off, span_chunks * CH);
+      if (stage_off + n * 2 > 2 * s->stage_frames) stage_off = 0;   // (the staging is a ring of spans: reuse is ordered by the `summed` event and the shards' own streams)
+      float* dst = contiguous ? d_out + (size_t)(done + off) * 2 : d_out;
+      if (sharded_render_segment(s, dst, contiguous ? stage_off : 0, (size_t)n * 2, now + off)) { s->failed = true; return 0; }
+      if (span_done && span_done((size_t)(done + off) * 2, (size_t)n * 2)) { s->failed = true; return 0; }
+      stage_off += (size_t)n * 2;
+      off += n;
+    }
+    done += seg;
   }
   return n_samples;
 }
 
 extern "C" {
 
-size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames) { return sharded_write_impl(s, d_out, n_samples, pos_in_frames); }
+size_t pg_sharded_write_device(pg_sharded_graph* s, float* d_out, size_t n_samples, uint64_t pos_in_frames) { return sharded_write_walk(s, d_out, true, n_samples, pos_in_frames, nullptr); }
 int pg_sharded_synchronize(pg_sharded_graph* s) { return sharded_wait_all(s); }
 size_t pg_sharded_write(pg_sharded_graph* s, float* out, size_t n_samples, uint64_t pos_in_frames) {
-  const size_t cap = s->stride * s->max_blocks;
-  size_t off = 0, total = 0;
-  uint64_t pos = pos_in_frames;
-  while (off < n_samples) {
-    const size_t n = std::min(cap, n_samples - off);
-    const size_t w = sharded_write_impl(s, s->d_bus, n, pos);
-    if (w == 0) { if (s->failed || off == 0) return 0; memset(out + off, 0, n * sizeof(float)); off += n; pos += n / 2; continue; }
+  // every span: the status words of every shard, the span's samples to the pinned staging, one wait, then out of the way for the next span
+  auto span_done = [s, out](size_t off, size_t n) -> int {
     pg_graph* root = s->shards[0];
     // device feedback per shard: how many of its main-mixer sources are still alive (transient sources are dropped when exhausted, mixed.rs:715)
-    for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); if (graph_enqueue_status(g, g->stream) != PG_OK) { s->failed = true; return 0; } }
+    for (pg_graph* g : s->shards) { (void)hipSetDevice(g->device); if (graph_enqueue_status(g, g->stream) != PG_OK) return PG_ERR_DEVICE; }
     (void)hipSetDevice(root->device);
-    if (hipMemcpyAsync(s->h_pinned, s->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, root->stream) != hipSuccess || sharded_wait_all(s) != PG_OK) { s->failed = true; return 0; }
+    if (hipMemcpyAsync(s->h_pinned, s->d_bus, n * sizeof(float), hipMemcpyDeviceToHost, root->stream) != hipSuccess || sharded_wait_all(s) != PG_OK) return PG_ERR_DEVICE;
     for (pg_graph* g : s->shards) graph_collect_status(g);
     memcpy(out + off, s->h_pinned, n * sizeof(float));
-    off += n; pos += n / 2; total += n;
-  }
-  return total;
+    return PG_OK;
+  };
+  return sharded_write_walk(s, s->d_bus, false, n_samples, pos_in_frames, span_done);
 }
 int pg_sharded_device_errors(pg_sharded_graph* s) {
   int e = 0;

@@ -670,15 +670,24 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
       float tv = v->fader_target;
       if (tv != 1.0f) for (int i = tid; i < total; i += nt) out[i] = out[i] * tv;
     } else {
-      if (tid == 0) {
-        float cur = v->fader_current, tgt = v->fader_target, inertia = v->fader_inertia;
-        for (int f = 0; f < wf; ++f) {
-          cur += (tgt - cur) * inertia;
-          for (int c = 0; c < C; ++c) out[f * C + c] *= cur;
+      // a fade in progress (fader.rs:109-117): one lane walks the f32 recurrence and lays the per-frame factors out in the source scratch (free
+      // now: the resampler has written), all lanes multiply — the same products as the reference's loop
+      float* const seq = S.sched_f;
+      constexpr int SEQ_CAP = SRC_OUT_CAP + SRC_WIN_CAP + 2 * (SRC_WIN_CAP + 4);
+      __syncthreads();
+      for (int base = 0; base < wf; base += SEQ_CAP) {
+        const int n = wf - base < SEQ_CAP ? wf - base : SEQ_CAP;
+        if (tid == 0) {
+          float cur = v->fader_current;
+          const float tgt = v->fader_target, inertia = v->fader_inertia;
+          for (int f = 0; f < n; ++f) { cur += (tgt - cur) * inertia; seq[f] = cur; }
+          v->fader_current = cur;
         }
-        v->fader_current = cur;
-        if ((ask_ends || wf < frames) && fabsf(cur - tgt) < 0.0001f) v->fader_state = 2;
+        __syncthreads();
+        for (int i = tid; i < n * C; i += nt) out[base * C + i] *= seq[C == 2 ? (i >> 1) : (C == 1 ? i : i / C)];
+        __syncthreads();
       }
+      if (tid == 0 && (ask_ends || wf < frames) && fabsf(v->fader_current - v->fader_target) < 0.0001f) v->fader_state = 2;
     }
   }
   __syncthreads();
@@ -934,8 +943,21 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   int written = wf * 2;
   __syncthreads();
   // apply_smoothed_gain  smoothing.rs:60-71  (ramp path multiplies per SAMPLE)
+  // While a smoother moves, one lane lays out its value sequence — the serial loop's own sm_next, an f32 recurrence that must be walked — into
+  // the source stage's scratch (free once the source has written: fraction table, position map and input window are contiguous), tile by tile,
+  // and all lanes apply it: the reference's per-sample / per-frame multiplications, same values, same order per sample. (Until round 5 one lane
+  // also did the multiplications, a read-modify-write of LDS per sample with two square roots per frame for the panning: 0.1-0.35 ms per block
+  // for every voice whose volume or panning had been touched in the last 1500 frames — and every unit's block waits for the slowest unit.)
+  float* const seq = S.sched_f;
+  constexpr int SEQ_CAP = SRC_OUT_CAP + SRC_WIN_CAP + 2 * (SRC_WIN_CAP + 4);   // floats from sched_f to the end of the input window
   if (sm_need_ramp(v->volume)) {
-    if (tid == 0) { PgSmooth s = v->volume; for (int i = 0; i < written; ++i) out[i] *= sm_next(s); v->volume = s; }
+    for (int base = 0; base < written; base += SEQ_CAP) {
+      const int n = written - base < SEQ_CAP ? written - base : SEQ_CAP;
+      if (tid == 0) { PgSmooth s = v->volume; sm_sequence(s, seq, n); v->volume = s; }
+      __syncthreads();
+      for (int i = tid; i < n; i += nt) out[base + i] *= seq[i];
+      __syncthreads();
+    }
   } else {
     float gain = v->volume.target;
     if (fabsf(1.0f - gain) > 0.000001f) for (int i = tid; i < written; i += nt) out[i] = out[i] * gain;
@@ -943,10 +965,13 @@ DEVO int voice_write(PgVoice* v, float* out, int frames, int pending_stop, const
   __syncthreads();
   // apply_smoothed_panning  smoothing.rs:74-122
   if (sm_need_ramp(v->panning)) {
-    if (tid == 0) {
-      PgSmooth s = v->panning;
-      for (int f = 0; f + 2 <= written; f += 2) { float l, r; panning_factors(sm_next(s), l, r); out[f] *= l; out[f + 1] *= r; }
-      v->panning = s;
+    const int frames_w = written / 2;
+    for (int base = 0; base < frames_w; base += SEQ_CAP) {
+      const int n = frames_w - base < SEQ_CAP ? frames_w - base : SEQ_CAP;
+      if (tid == 0) { PgSmooth s = v->panning; sm_sequence(s, seq, n); v->panning = s; }
+      __syncthreads();
+      for (int f = tid; f < n; f += nt) { float l, r; panning_factors(seq[f], l, r); out[2 * (base + f)] *= l; out[2 * (base + f) + 1] *= r; }
+      __syncthreads();
     }
   } else {
     float pan = v->panning.target;

@@ -65,6 +65,15 @@ class Graph(GraphHandle):
         """The `audible` words of the last write_device call of a deferred-bus graph as floats (0 / 1): they ride with the partial bus in one reduce."""
         self._check(self._lib.pg_graph_export_audible(self._h, C.c_void_p(d_dst_ptr), n_words, C.c_void_p(stream or 0)))
 
+    def audible_words(self):
+        """Words the last deferred-bus write_device call left: one per piece it was rendered in (events add pieces)."""
+        return int(self._lib.pg_graph_audible_words(self._h))
+
+    def next_main_event(self, pos_in_frames):
+        """Sample time of the first main-mixer event behind pos_in_frames (None: none pending). Writing thread only (drains the control ring)."""
+        t = int(self._lib.pg_graph_next_main_event(self._h, int(pos_in_frames)))
+        return None if t == 0xFFFFFFFFFFFFFFFF else t
+
     def synchronize(self):
         self._check(self._lib.pg_graph_synchronize(self._h))
 
@@ -96,6 +105,15 @@ class Graph(GraphHandle):
         ms, n, b = C.c_double(0.0), C.c_uint64(0), C.c_uint64(0)
         self._check(self._lib.pg_graph_bus_kernel_stats(self._h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(b)))
         return (ms.value / n.value if n.value else 0.0), n.value, b.value
+
+    def dynamic_stats(self, reset=True):
+        """{unit_blocks, deferred_unit_blocks, generic_launches, generic_launches_with_work, generic_ms, generic_timed}: what leaving the
+        steady state cost since the last reset (pg_graph_dynamic_stats; waits for the stream)."""
+        out = (C.c_uint64 * 4)()
+        ms, n = C.c_double(0.0), C.c_uint64(0)
+        self._check(self._lib.pg_graph_dynamic_stats(self._h, 1 if reset else 0, out, C.byref(ms), C.byref(n)))
+        return {"unit_blocks": int(out[0]), "deferred_unit_blocks": int(out[1]), "generic_launches": int(out[2]), "generic_launches_with_work": int(out[3]),
+                "generic_ms": ms.value, "generic_timed": int(n.value)}
 
     def bus_kernel(self):
         return self._lib.pg_graph_bus_kernel(self._h).decode()

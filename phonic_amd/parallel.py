@@ -22,6 +22,21 @@ def reduce_master_bus(bus, root=0, group=None):
     return bus
 
 
+def next_call_frames(g, pos, want_frames, group=None):
+    """Deferred-bus graphs, one process per GPU: a call must end where a main-mixer event of ANY rank comes due (the one main mixer cuts its
+    chunk there for every sub-mixer and for its effect chain, src/source/mixed.rs:679-712). Returns min(want_frames, frames up to the first such
+    event over all ranks) — one MIN all-reduce of a single integer (host side; skip it for graphs that never schedule main-mixer events)."""
+    t = g.next_main_event(pos)
+    n = want_frames if t is None else min(want_frames, t - pos)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        v = torch.tensor([n], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            v = v.cuda()
+        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+        n = int(v.item())
+    return n
+
+
 class MasterBusRing:
     """Master-bus buffers of the sharded render: a ring of `n_buffers` super-blocks of `blocks_per_reduce` blocks each. A rank renders
     block `step` into `slot(step)`; `submit(step)` issues ONE asynchronous sum-reduce to `root` when that block completes its

@@ -75,6 +75,91 @@ def build_headline(g, n_voices, first_voice=0, total_voices=None, seconds=2.0):
                     repeat=_capi.PG_REPEAT_FOREVER)
 
 
+def build_dyn(g, n_voices, audio_seconds, churn_pct_per_s=0.0, silent_pct=0.0, first_frame=0, seed=1234, sample_rate=48000):
+    """The headline layout off its steady state (bench.py --workload dyn): per-voice sub-mixers with a Reverb, where
+    `silent_pct` % of the voices are one-shots that ended long ago (a 0.05 s sample at time 0: once the reverb's tail — 5.6 s at the default
+    room size, reverb.rs:449-467 — and the sub-mixer's 2 s silence gate have passed, EffectProcessor and SubMixerProcessor bypass them,
+    src/source/mixed/effect.rs:56-84, submixer.rs:47-77), and `churn_pct_per_s` % of the voices per second of audio are notes that END and
+    RESTART at random sample times inside [first_frame, first_frame + audio_seconds): the playing source is stopped there (StopSource: its
+    fade-out) and a successor — added up front with that start time, as Player::play_file_source schedules a source (player.rs:519-602) —
+    takes over a random gap later. Returns {"mixers", "reverbs", "voices" (the voice playing at first_frame, per unit), "silent" (set of units),
+    "restarts": [(stop_time, unit, old_voice, new_voice)] sorted by time}."""
+    rng = np.random.default_rng(seed)
+    vol = voice_level(n_voices)
+    n_silent = int(round(n_voices * silent_pct / 100.0))
+    silent = set(int(u) for u in rng.permutation(n_voices)[:n_silent])
+    out = {"mixers": [], "reverbs": [], "voices": [], "silent": silent, "restarts": []}
+    for i in range(n_voices):
+        m = g.add_mixer()
+        out["mixers"].append(m)
+        out["reverbs"].append(g.add_effect(m, _capi.FX_REVERB, reverb_seeds=reverb_seeds(i)))
+        if i in silent:
+            out["voices"].append(g.add_voice(m, tone_buffer(i, 44100, 0.05), 2, 44100, volume=vol, panning=float(np.float32(voice_pan(i)))))
+        else:
+            out["voices"].append(g.add_voice(m, tone_buffer(i, 44100, 2.0), 2, 44100, volume=vol, panning=float(np.float32(voice_pan(i))), has_repeat=1,
+                                             repeat=_capi.PG_REPEAT_FOREVER))
+    live = [u for u in range(n_voices) if u not in silent]
+    n_restarts = int(round(len(live) * churn_pct_per_s / 100.0 * audio_seconds))
+    if n_restarts and live:
+        times = np.sort(rng.integers(first_frame, first_frame + int(audio_seconds * sample_rate), n_restarts))
+        current = {u: out["voices"][u] for u in live}
+        busy_until = {}
+        for t in times:
+            t = int(t)
+            u = int(live[int(rng.integers(0, len(live)))])
+            if busy_until.get(u, -1) >= t:   # (its successor has not started yet: another unit takes this restart)
+                free = [v for v in live if busy_until.get(v, -1) < t]
+                if not free:
+                    continue
+                u = int(free[int(rng.integers(0, len(free)))])
+            gap = int(rng.integers(0, int(0.2 * sample_rate)))
+            nv = g.add_voice(out["mixers"][u], tone_buffer(u + 7, 44100, 2.0), 2, 44100, volume=vol, panning=float(np.float32(voice_pan(u))), has_repeat=1,
+                             repeat=_capi.PG_REPEAT_FOREVER, start_time=t + gap)
+            out["restarts"].append((t, u, current[u], nv))
+            current[u] = nv
+            busy_until[u] = t + gap
+    return out
+
+
+class DynDriver:
+    """Schedules the dynamic workload's commands call by call (bench.py --workload dyn and its parity test drive the product graph and the
+    oracle through the same object): before the call that renders frames [t0, t1) — `events_per_s` x (t1 - t0) / sample_rate commands on average
+    (Poisson), each at a random sample time inside the call on a random audible unit: the reverb's `wet`, the playing source's volume, its
+    panning, equal shares — and the StopSource messages of the planned restarts that fall into the call."""
+
+    def __init__(self, plan, events_per_s, seed, sample_rate=48000, kinds=(0, 1, 2)):
+        self.plan, self.events_per_s, self.sr, self.kinds = plan, float(events_per_s), sample_rate, tuple(kinds)
+        self.rng = np.random.default_rng(seed)
+        self.live = [u for u in range(len(plan["voices"])) if u not in plan["silent"]]
+        self.current = {u: plan["voices"][u] for u in self.live}
+        self.restart_i = 0
+
+    def schedule(self, g, t0, t1):
+        n_cmds = 0
+        rng, plan = self.rng, self.plan
+        n_ev = int(rng.poisson(self.events_per_s * (t1 - t0) / self.sr)) if self.events_per_s > 0 and self.live else 0
+        for _ in range(n_ev):
+            u = int(self.live[int(rng.integers(0, len(self.live)))])
+            t = int(rng.integers(t0, t1))
+            kind = self.kinds[int(rng.integers(0, len(self.kinds)))]
+            if kind == 0:
+                g.schedule_param(plan["reverbs"][u], "wet ", float(np.float32(rng.uniform(0.2, 0.5))), t)
+            elif kind == 1:
+                g.set_voice_volume(self.current[u], float(np.float32(rng.uniform(0.5, 1.0) / 32.0)), t)
+            else:
+                g.set_voice_panning(self.current[u], float(np.float32(rng.uniform(-1.0, 1.0))), t)
+            n_cmds += 1
+        rs = plan["restarts"]
+        while self.restart_i < len(rs) and rs[self.restart_i][0] < t1:
+            t, u, old, new = rs[self.restart_i]
+            if t >= t0:
+                g.stop_voice(old, t)
+                self.current[u] = new
+                n_cmds += 1
+            self.restart_i += 1
+        return n_cmds
+
+
 def build_c2(g, n_voices=64, seconds=2.0):
     """C2: 64 stereo 48 kHz file voices on the main mixer, Eq5 + Reverb on the bus."""
     vol = voice_level(n_voices)

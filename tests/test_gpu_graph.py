@@ -472,6 +472,146 @@ def test_sharded_voices_with_deferred_bus_and_bus_automation():
     assert np.abs(sharded).max() > 1e-3
 
 
+def test_deferred_bus_words_follow_the_pieces_when_events_cut_the_call():
+    """Round-4 advisor finding: the `audible` word of a deferred-bus write sat at done / max_frames — a main-mixer event that cuts a chunk at a
+    frame that is no multiple of max_frames (here: a source's volume event at +500, a bus parameter at +700) put the next chunk's flag into the
+    same word, and the bus chain indexed the words by its own cuts. Now: one word per piece in order (pg_graph_audible_words), and the chain
+    walks the grid the write recorded. (a) ONE graph, deferred: write + export + process_bus_device_flags must equal the same graph rendering
+    its bus chain itself, BIT FOR BIT — one-shots end, the Delay rings out and the chain bypasses itself (exact zeros), so a wrong flag shows.
+    (b) two graphs (two ranks' worth) whose calls end at the main-mixer events of either (pg_graph_next_main_event): equal to the oracle."""
+    import torch
+    from phonic_amd.graph import Graph
+
+    N, blocks = 1024, 110
+
+    def build(g, lo, hi, bus=True):
+        ids = []
+        for i in range(lo, hi):   # main-mixer one-shots, ~1.4 blocks long, starting in block 2
+            ids.append(g.add_voice(0, workloads.tone_buffer(i, 48000, 0.03), 2, 48000, volume=0.5, start_time=2 * N + 37 * i))
+        fx = []
+        if bus:
+            fx.append(g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.8}))
+            fx.append(g.add_effect(0, _capi.FX_DELAY, params={"dlay": 30.0, "fdbk": 0.3, "wet_": 0.6}))
+        return ids, fx
+
+    def automate(g, ids, fx, b, pos, lo=0):
+        if b == 2:
+            if lo == 0:
+                g.set_voice_volume(ids[0], 0.2, pos + 500)
+            if fx:
+                g.schedule_param(fx[1], "fdbk", 0.35, pos + 700)
+        if b == 3 and lo == 0:
+            g.set_voice_panning(ids[1], -0.5, pos + 1000)
+
+    # reference renders: the plain graph and the oracle, block by block
+    outs = []
+    for g in (Graph(SR, 2, N, 0), oracle.OracleGraph(SR, 2, N)):
+        ids, fx = build(g, 0, 4)
+        o = np.zeros((blocks, 2 * N), np.float32)
+        for b in range(blocks):
+            automate(g, ids, fx, b, b * N)
+            w = g.write(o[b], b * N)
+            assert w in (0, 2 * N)
+        outs.append(o.reshape(-1))
+    compare(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-2 and np.abs(outs[0][-2 * N:]).max() == 0.0   # the chain has bypassed itself at the end
+
+    # (a) one graph, bus deferred
+    g = Graph(SR, 2, N, 0)
+    g.set_defer_bus(True)
+    ids, fx = build(g, 0, 4)
+    buf = torch.zeros(2 * N + 64, dtype=torch.float32, device="cuda:0")
+    a = np.zeros((blocks, 2 * N), np.float32)
+    words_seen = set()
+    for b in range(blocks):
+        automate(g, ids, fx, b, b * N)
+        buf.zero_()
+        w = g.write_device(buf.data_ptr(), 2 * N, b * N)
+        g.synchronize()
+        nw = g.audible_words()
+        words_seen.add(nw)
+        if w:
+            assert w == 2 * N
+            g.export_audible(buf.data_ptr() + 4 * 2 * N, nw)
+        g.process_bus_device(buf.data_ptr(), 2 * N, b * N, flags_ptr=buf.data_ptr() + 4 * 2 * N if w else None, n_words=max(nw, 1) if w else 0)
+        g.synchronize()
+        a[b] = buf[: 2 * N].cpu().numpy()
+    assert {1, 3} <= words_seen, words_seen    # block 2 is three pieces: [0, 500) [500, 700) [700, 1024)
+    assert np.array_equal(a.reshape(-1), outs[0])
+    assert g.device_errors() == 0
+
+    # (b) two graphs, calls cut at the main-mixer events of either
+    gs = [Graph(SR, 2, N, 0), Graph(SR, 2, N, 0)]
+    built = [build(gs[0], 0, 2), build(gs[1], 2, 4)]
+    # (the voices are the oracle's 0..3 split over the two graphs; the events of voice 0 / 1 live on graph 0 only)
+    for g in gs:
+        g.set_defer_bus(True)
+    bufs = [torch.zeros(2 * N + 64, dtype=torch.float32, device="cuda:0") for _ in gs]
+    o = np.zeros((blocks, 2 * N), np.float32)
+    for b in range(blocks):
+        for k, g in enumerate(gs):
+            automate(g, built[k][0], built[k][1], b, b * N, lo=2 * k)
+        done = 0
+        while done < N:
+            pos = b * N + done
+            n = N - done
+            for g in gs:
+                t = g.next_main_event(pos)
+                if t is not None:
+                    n = min(n, t - pos)
+            total = None
+            for g, bf in zip(gs, bufs):
+                bf.zero_()
+                w = g.write_device(bf.data_ptr(), 2 * n, pos)
+                g.synchronize()
+                assert w in (0, 2 * n)
+                nw = g.audible_words() if w else 0
+                assert nw in (0, 1)
+                if w:
+                    g.export_audible(bf.data_ptr() + 4 * 2 * n, 1)
+                total = bf.clone() if total is None else total + bf
+            gs[0].process_bus_device(total.data_ptr(), 2 * n, pos, flags_ptr=total.data_ptr() + 4 * 2 * n, n_words=1)
+            gs[0].synchronize()
+            o[b, 2 * done: 2 * (done + n)] = total[: 2 * n].cpu().numpy()
+            done += n
+    compare(o.reshape(-1), outs[1])
+    assert np.abs(o[-1]).max() == 0.0
+
+
+@pytest.mark.parametrize("per_call", [1, 4])
+def test_dynamic_workload_plan_matches_the_oracle(per_call):
+    """bench.py --workload dyn in small: 24 per-voice Reverb sub-mixers, a quarter of the voices short one-shots, voices that are stopped and
+    restarted at random sample times (successors added up front with their start times), reverb `wet` / source volume / source panning commands at
+    random sample times — the SAME plan (phonic_amd.workloads.DynDriver) drives the product graph and the oracle through the same calls (one
+    block per call, and four: super-block launches where the library finds a steady span, pieces where commands fall)."""
+    from phonic_amd.graph import Graph
+
+    N, blocks = 1024, 48
+    outs = []
+    for mode in ("gpu", "oracle"):
+        g = Graph(SR, 2, N, 0) if mode == "gpu" else oracle.OracleGraph(SR, 2, N)
+        if mode == "gpu":
+            g.set_max_blocks_per_launch(per_call)
+        plan = workloads.build_dyn(g, 24, blocks * N / SR, churn_pct_per_s=60.0, silent_pct=25.0, first_frame=4 * N, seed=99, sample_rate=SR)
+        assert len(plan["restarts"]) >= 8 and len(plan["silent"]) == 6
+        drv = workloads.DynDriver(plan, 150.0, 7, sample_rate=SR)
+        o = np.zeros((blocks // per_call, per_call * 2 * N), np.float32)
+        n_cmds = 0
+        for c in range(blocks // per_call):
+            pos = c * per_call * N
+            if c * per_call >= 4:
+                n_cmds += drv.schedule(g, pos, pos + per_call * N)
+            assert g.write(o[c], pos) == o[c].size
+        assert n_cmds > 100
+        outs.append(o.reshape(-1))
+        if mode == "gpu":
+            assert g.device_errors() == 0
+            st = g.dynamic_stats()
+            assert st["unit_blocks"] >= 24 * blocks and 0 < st["deferred_unit_blocks"] < st["unit_blocks"]
+    compare(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-2
+
+
 def test_nested_submixers_tree():
     """Player::add_mixer(parent) (src/player.rs:771-822): main -> group (Eq5, Compressor, own voice) -> {reverb send, filter+chorus
     lane} -> a third level under the lane. The parent sums its sub-mixers in the order they were added, then its sources, then
@@ -1355,6 +1495,64 @@ def test_sharded_superblock_write_takes_the_bus_decisions_per_block(n_shards):
     assert np.abs(audible[2 * per_call + 1]).max() > 1e-2          # the voices play in blocks 8-9 ...
     assert np.abs(audible[2 * per_call + 3]).max() > 1e-4          # ... the delay's repeats ring on in the silent blocks of the same call
     assert np.abs(audible[-1]).max() == 0.0                        # ... and the chain has bypassed itself at the end
+
+
+@pytest.mark.parametrize("mf", [1024, 256])
+def test_sharded_host_write_longer_than_its_staging_is_one_call_on_the_chunk_grid(mf):
+    """pg_sharded_write with a host buffer of MORE than max_blocks x max_frames frames (round-4 advisor finding): it used to be cut into separate
+    write calls of max_blocks x max_frames frames, each with its own process_messages, call end and chunk grid — per-chunk decisions (bypass and
+    tail counters, the chorus' per-call phase bookkeeping under a rate ramp, Eq5's per-call ramp branch, one-shots that end inside the call) then
+    differed from the single graph and the reference for the same call. Calls of 5000 and 9000 frames (max_blocks = 1: the staging holds one
+    chunk), events anywhere inside them; against the single graph (same calls) and the oracle (same calls)."""
+    from phonic_amd.graph import Graph, ShardedGraph
+
+    calls = [5000, 9000, 4096, 700, 8192, 6000]
+
+    def build(g):
+        ids = {}
+        for i in range(5):
+            m = g.add_mixer()
+            if i == 0:
+                ids["ch"] = g.add_effect(m, _capi.FX_CHORUS, params={"rate": 2.0})
+            elif i == 1:
+                ids["eq"] = g.add_effect(m, _capi.FX_EQ5, params={"gan2": 3.0})
+            else:
+                g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.2), 2, 44100, volume=0.3, panning=workloads.voice_pan(i), has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)
+        for i in range(3):   # one-shots on the main mixer: they end inside the second call, the bus Delay rings on and bypasses itself later
+            ids.setdefault("v", []).append(g.add_voice(0, workloads.tone_buffer(10 + i, 48000, 0.05), 2, 48000, volume=0.4, start_time=5000 + 100 * i))
+        g.add_effect(0, _capi.FX_GAIN, params={"gain": 0.8})
+        ids["dl"] = g.add_effect(0, _capi.FX_DELAY, params={"dlay": 30.0, "fdbk": 0.3, "wet_": 0.6})
+        return ids
+
+    def automate(g, ids, c, pos):
+        if c == 0:
+            g.schedule_param(ids["ch"], "rate", 6.0, pos + 1500)     # a rate ramp across a piece and a chunk boundary
+            g.schedule_param(ids["eq"], "gan4", -6.0, pos + 4000)    # a gain ramp that starts just in front of the first chunk's end
+        if c == 1:
+            g.set_voice_volume(ids["v"][1], 0.1, pos + 4500)         # a main-mixer source: cuts every shard's chunk, restarts the grid
+            g.schedule_param(ids["dl"], "fdbk", 0.5, pos + 6000)     # a bus event
+        if c == 4:
+            g.schedule_param(ids["ch"], "rate", 0.5, pos + 8000)
+
+    outs = []
+    for mode in ("sharded", "single", "oracle"):
+        g = ShardedGraph([0, 0, 0], SR, 2, mf) if mode == "sharded" else (Graph(SR, 2, mf, 0) if mode == "single" else oracle.OracleGraph(SR, 2, mf))
+        ids = build(g)
+        chunks, pos = [], 0
+        for c, n in enumerate(calls):
+            automate(g, ids, c, pos)
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        outs.append(np.concatenate(chunks))
+        if mode == "sharded":
+            assert g.device_errors() == 0
+    compare(outs[0], outs[2])
+    compare(outs[1], outs[2])
+    assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5
+    assert np.abs(outs[0]).max() > 1e-2
 
 
 def test_sharded_write_returns_zero_when_the_main_mixer_has_nothing_left():

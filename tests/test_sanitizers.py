@@ -33,7 +33,7 @@ def test_oracle_suites_under_asan_and_ubsan():
 
 
 def _build_host_fuzz(tmp_path, sanitize):
-    """The library's five translation units host-only + the stub HIP runtime + the plan driver, linked into one sanitized executable."""
+    """The library's translation units host-only + the stub HIP runtime + the plan driver, linked into one sanitized executable."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
@@ -42,7 +42,9 @@ def _build_host_fuzz(tmp_path, sanitize):
     flags = ["--cuda-host-only", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-DPG_FAST_WAVES=2", "-Wno-unused", "-Wno-unused-command-line-argument"] + san
     objs = []
     jobs = []
-    for tu in ("pg_host", "pg_fxstate", "pg_effect", "pg_sharded", "pg_kernels"):
+    kernel_tus = sorted(os.path.basename(f)[:-4] for f in __import__("glob").glob(os.path.join(csrc, "pg_k_*.hip")))   # one kernel per translation unit (host side: the stubs)
+    assert len(kernel_tus) >= 7, kernel_tus
+    for tu in ["pg_host", "pg_fxstate", "pg_effect", "pg_sharded", "pg_kernels"] + kernel_tus:
         o = str(tmp_path / (tu + ".o"))
         objs.append(o)
         jobs.append(subprocess.Popen([hipcc] + flags + ["-c", os.path.join(csrc, tu + ".hip"), "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -63,7 +65,7 @@ def _build_host_fuzz(tmp_path, sanitize):
 
 
 def test_host_side_of_the_library_under_asan_and_ubsan(tmp_path):
-    """The five translation units of libphonic_gpu compiled HOST-ONLY (hipcc --cuda-host-only: no device code) with -fsanitize=address,undefined and
+    """The translation units of libphonic_gpu compiled HOST-ONLY (hipcc --cuda-host-only: no device code) with -fsanitize=address,undefined and
     linked against tests/host/hip_stub.cpp instead of the HIP runtime: the library's host logic — topology rebuilds, append-only id maps, the control
     ring's drain, event queues and per-piece command lists, the chunk / piece walk of long writes and its staging spans, host-fed rings, the
     sharded handle's routing and issuing threads, the effect handle — runs random plans through the C ABI (tests/host/host_fuzz.cpp) on the CPU.
