@@ -458,7 +458,7 @@ def measure_dyn(args, local_rank, block, mf, sb):
         "n_gpus": 1, "steps": steps, "warmup": warm_blocks, "ms_per_step": d["offline"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "dyn: the headline's voices off the steady state (events, voices that end and restart, auto-bypassed voices)", "voices_per_gpu": V,
-                   "block_frames": block, "max_frames": mf, "blocks_per_call": sb, "churn_pct_per_s": args.churn, "events_per_s": args.events, "silent_pct": args.silent,
+                   "block_frames": block, "max_frames": mf, "blocks_per_call": sb, "churn_pct_per_s": args.churn, "events_per_s": args.events, "kinds": args.dyn_kinds, "silent_pct": args.silent,
                    "audio_seconds": steps * block / sr, "seed": args.dyn_seed},
         "dyn": {"offline": d["offline"], "realtime": d["realtime"], "steady_offline_ms_per_step": s0["offline"]["ms_per_step"], "steady_realtime_ms_per_step": s0["realtime"]["ms_per_step"],
                 "ratio_offline": d["offline"]["ms_per_step"] / s0["offline"]["ms_per_step"], "ratio_realtime": d["realtime"]["ms_per_step"] / s0["realtime"]["ms_per_step"],

@@ -329,6 +329,9 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
       hipEventCreateWithFlags(&g->ev_rows_free, hipEventDisableTiming) != hipSuccess) {
     g->overlap_bus = false;   // (not fatal: the launches stay on one stream)
   }
+  { const char* e = getenv("PHONIC_CONCURRENT_GENERIC"); if (e && e[0] == '0') g->concurrent_generic = false; }
+  if (!g->unit_stream || hipEventCreateWithFlags(&g->ev_scan_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_generic_done, hipEventDisableTiming) != hipSuccess)
+    g->concurrent_generic = false;
   g->mixers.emplace_back();
   g->mixers[0].depth = 0;
   g->mixers[0].unit_slot = new_unit(g.get(), UNIT_BUS);
@@ -362,9 +365,12 @@ void pg_graph_destroy(pg_graph* g) {
   if (g->h_feedback) (void)pg_host_free(g->h_feedback);
   for (auto& e : g->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : g->ev_bus_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : g->ev_gen_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (g->ev_units_done) (void)hipEventDestroy(g->ev_units_done);
   if (g->ev_rows_free) (void)hipEventDestroy(g->ev_rows_free);
   if (g->unit_stream) { (void)pg_stream_sync(g->unit_stream); (void)hipStreamDestroy(g->unit_stream); }
+  if (g->ev_scan_done) (void)hipEventDestroy(g->ev_scan_done);
+  if (g->ev_generic_done) (void)hipEventDestroy(g->ev_generic_done);
   (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -1197,16 +1203,44 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
     const bool ride = timed_here && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
     const bool bracket = timed_here && !time_generic && n_launches > 1;
-    if (bracket) HIP_TRY(hipEventRecord(e0, stream));
+    // Off the steady state (commands in the block, smoothers still moving): the units the time-parallel kernels cannot take and the units
+    // they can are disjoint, and which is which follows from the unit records as the round begins — a small scan kernel decides it for every
+    // unit up front (the decision the fast kernels used to take themselves, one by one), and the generic kernel then runs BESIDE the fast
+    // kernels instead of behind them: a commanded unit is a lone workgroup's latency chain of 0.15-0.3 ms, and every round used to wait for it
+    // with 250 CUs idle. The generic kernel stays on the write's stream, right behind the scan — it is dispatched first and takes its few CUs
+    // (one workgroup each: its register footprint) — the fast kernels go to the graph's second stream behind an event and fill the rest (they
+    // share a CU with a generic workgroup one or two at a time instead of four); the sum waits for both. (A first version had it the other way
+    // round: the fast kernels, 1024 workgroups that fill every CU, won the race for the machine and the generic kernel ran in their tail:
+    // no gain.) One level, single blocks, single-launch staged mode.
+    const bool concurrent = g->concurrent_generic && !sp.generic_idle && !time_generic && g->levels.size() == 1 && sp.n_chunks == 1 && g->staged_mode != 2 &&
+                            L.defer_list && g->unit_stream && stream != g->unit_stream;
+    hipStream_t fs = stream;   // the stream of the fast kernels
+    if (concurrent) {
+      HIP_TRY(pg_launch_defer_scan(L, stream));
+      HIP_TRY(hipEventRecord(g->ev_scan_done, stream));
+      HIP_TRY(hipStreamWaitEvent(g->unit_stream, g->ev_scan_done, 0));
+      PgLaunch G = L;
+      G.mode = 2; G.pad_chunks = 1;   // (a pre-scanned round: the fast kernels beside it read PgUnit::deferred — it stays as the scan left it)
+      hipEvent_t g0 = nullptr, g1 = nullptr;
+      if (timed_here && g->ev_gen_used < g->ev_gen_pool.size()) { g0 = g->ev_gen_pool[g->ev_gen_used].first; g1 = g->ev_gen_pool[g->ev_gen_used].second; g->ev_gen_used++; }
+      HIP_TRY(pg_launch_units(G, stream, g0, g1));
+      g->stat_generic_launches++;
+      L.defer_list = nullptr; L.defer_count = nullptr; L.pad_chunks = 1;   // the fast kernels read their unit's decision word instead of deciding (and append nothing)
+      fs = g->unit_stream;
+    }
+    if (bracket) HIP_TRY(hipEventRecord(e0, fs));
     L.stage_buf = nullptr; L.staged_on = 0;
     if (staged) {
       L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 2 : 1;
-      HIP_TRY(pg_launch_stages(L, stream, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
+      HIP_TRY(pg_launch_stages(L, fs, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
     }
-    if (fused) HIP_TRY(pg_launch_units(L, stream, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
-    if (bracket) HIP_TRY(hipEventRecord(e1, stream));
+    if (fused) HIP_TRY(pg_launch_units(L, fs, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
+    if (bracket) HIP_TRY(hipEventRecord(e1, fs));
     L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
-    if (!sp.generic_idle) {
+    if (concurrent) {   // (the sum behind this level needs both)
+      HIP_TRY(hipEventRecord(g->ev_generic_done, fs));
+      HIP_TRY(hipStreamWaitEvent(stream, g->ev_generic_done, 0));
+    } else if (!sp.generic_idle) {
       hipEvent_t g0 = timed_here && time_generic ? e0 : nullptr, g1 = timed_here && time_generic ? e1 : nullptr;
       if (timed_here && !time_generic && g->ev_gen_used < g->ev_gen_pool.size()) { g0 = g->ev_gen_pool[g->ev_gen_used].first; g1 = g->ev_gen_pool[g->ev_gen_used].second; g->ev_gen_used++; }   // (rides on the dispatch)
       HIP_TRY(pg_launch_units(L, stream, g0, g1));

@@ -30,6 +30,7 @@ size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide);  // wide: the staged kernel that renders effects in front of the reverb (their state slots)
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
                          size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0);
@@ -263,6 +264,8 @@ struct pg_graph {
                                  // unit kernels run under the bus chain of the call before. A caller's own work on that stream never feeds a unit kernel.
   uint64_t bus_group = 16;       // blocks per launch sequence of a small unit level in front of a bus chain (PHONIC_BUS_GROUP)
   bool overlap_bus = true;       // PHONIC_BUS_OVERLAP=0 (read at create): everything on the caller's stream
+  hipEvent_t ev_scan_done = nullptr, ev_generic_done = nullptr;   // the generic kernel beside the fast kernels (launch_level)
+  bool concurrent_generic = true;   // PHONIC_CONCURRENT_GENERIC=0 (read at create): the generic kernel behind the fast kernels, on one stream
   bool messages_due = false;    // StopSource messages wait for the first launch of the write call that has begun
   int32_t* d_error = nullptr;   // sticky consistency flags of the kernels (PG_DEVERR_*)
   unsigned long long* d_bus_progress = nullptr;  // progress words of the pipelined bus chain (pg_bus_pipeline)

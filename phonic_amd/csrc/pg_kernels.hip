@@ -190,6 +190,25 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
   }
   return hipGetLastError();
 }
+// The deferral decision of a round for every launch slot at once (see launch_level): the same test the fast kernels apply to their own unit
+// — static_defer, maybe_ramping, a command addressed to the unit in this launch — left in the unit record (`deferred`, 0 or 1 for EVERY unit of
+// the level: the fast kernels of the round read it instead of deciding themselves, and the generic kernel of such a round leaves it alone); the
+// deferred slots are appended to the round's list, as a fast kernel would have done, so the generic kernel (mode 2) finds them the usual way.
+__global__ void __launch_bounds__(256) pg_defer_scan_kernel(PgLaunch L) {
+  const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (slot >= L.n_units) return;
+  const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
+  PgUnit& unit = L.units[u];
+  int ok = !(unit.static_defer || unit.maybe_ramping);
+  for (int ci = 0; ok && ci < L.n_cmds; ++ci) if (L.cmds[ci].unit == u) ok = 0;
+  unit.deferred = ok ? 0 : 1;
+  if (!ok) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
+}
+hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream) {
+  if (L.n_units <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pg_defer_scan_kernel, dim3((L.n_units + 255) / 256), dim3(256), 0, stream, L);
+  return hipGetLastError();
+}
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   size_t lds = pg_unit_lds_bytes(L.n_frames, L.mode == 1 ? L.fast_scratch_bytes : 0);  // (the generic kernel renders any chain: full arena)

@@ -100,7 +100,9 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   PG_STAMP(L.diag, 0);
   // deferral decision: identical to the fused fast kernel
   if (tid == 0) {
-    int ok = !(unit.static_defer || unit.maybe_ramping);
+    // (L.pad_chunks: a pre-scanned round — pg_defer_scan_kernel decided for every unit and left the decision in `deferred`; the generic kernel
+    // runs beside this one and may already be rewriting maybe_ramping of the units it renders)
+    int ok = !(unit.static_defer || (L.pad_chunks ? unit.deferred : unit.maybe_ramping));
     for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;
     unit.deferred = ok ? 0 : 1;
     if (!ok && L.n_chunks > 1) pg_raise_super_deferred(L);

@@ -418,7 +418,9 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   else if ((tid & 63) < (int)(sizeof(PgUnit) / 4)) unit_w = ((const uint32_t*)&unit)[tid & 63];
 #define PG_UF(f) ((int)__builtin_amdgcn_readlane((int)unit_w, (int)(offsetof(PgUnit, f) / 4)))
 #define PG_UL(f) (ur[offsetof(PgUnit, f) / 4])
-  const int u_static_defer = PG_UF(static_defer), u_maybe_ramping = PG_UF(maybe_ramping), u_fx0 = PG_UF(fx0), u_staged = PG_UF(staged), u_n_fx0 = PG_UF(n_fx), u_kind0 = PG_UF(kind);
+  // (L.pad_chunks: a pre-scanned round — pg_defer_scan_kernel took the deferral decision for every unit of the level and left it in `deferred`; the
+  // generic kernel runs BESIDE this one and may already be rewriting maybe_ramping of the units it renders: the decision word is what counts)
+  const int u_static_defer = PG_UF(static_defer), u_maybe_ramping = L.pad_chunks ? PG_UF(deferred) : PG_UF(maybe_ramping), u_fx0 = PG_UF(fx0), u_staged = PG_UF(staged), u_n_fx0 = PG_UF(n_fx), u_kind0 = PG_UF(kind);
   uint32_t voice_word = 0;
   unsigned long long fx0_word = 0, fx1_word = 0;
   const int n_fx_words = (int)(sizeof(PgFx) / 4);
@@ -464,7 +466,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
       // end of the block) by the generic kernel: the unit record alone decides, no walk over the effect states.
       int ok = !(u_static_defer || u_maybe_ramping);
       for (int ci0 = 0; ok && ci0 < L.n_cmds; ++ci0) if (L.cmds[ci0].unit == u) ok = 0;  // parameter events: exact path
-      unit.deferred = ok ? 0 : 1;
+      unit.deferred = ok ? 0 : 1;   // (a pre-scanned round: the value the scan kernel left)
       if (!ok && L.n_chunks > 1) pg_raise_super_deferred(L);  // nobody renders the later blocks of this unit
       else if (!ok && L.defer_list) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
       ctl[5] = ok;
@@ -475,7 +477,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     carry.si = si; carry.sf = sf; carry.unit_w = unit_w;
     carry.resident = (tables && L.n_chunks > 1 && (si.w & 0xffffff) <= 1 && u_n_fx0 <= 2) ? 1 : 0;
   } else if (L.mode == 2) {
-    if (tid == 0) { ctl[5] = unit.deferred; unit.deferred = 0; }
+    if (tid == 0) { ctl[5] = unit.deferred; if (!L.pad_chunks) unit.deferred = 0; }   // (pad_chunks: a pre-scanned round — the fast kernels beside this one still read the word)
     __syncthreads();
     if (!ctl[5]) return;
   }
