@@ -821,6 +821,14 @@ def main():
                         "bounded by that workgroup's latency chain, not by HBM (frac = the workload's algorithmic bytes over THIS launch's time, for the record)"})
             for k in ("frac_min", "frac_max", "traffic", "algorithmic_bytes_per_launch"):
                 out["roofline"].pop(k, None)
+        if name == "c3" and out["roofline"]["bound"] == "hbm":
+            # C3 (Filter -> Chorus per voice: 36 B per voice-frame) is ONE workgroup's latency chain per unit and block — ~64 K shader cycles of
+            # dependent trips, barriers and two scans with every workgroup resident (stamps: profiles/r05_c3_stamps.txt) — not a byte stream:
+            # the line says so, like the bus chains of C2 / C4
+            out["roofline"].update({"bound": "latency", "latency_chain_us_per_block": out["roofline"]["kernel_ms_per_block"] * 1e3,
+                                    "shader_cycles_per_block_at_2.4GHz": out["roofline"]["kernel_ms_per_block"] * 1e-3 * 2.4e9,
+                                    "note": "every unit's block is one workgroup's chain of dependent steps (source, Filter scan, chorus phases, SVF scan, two tap / write rounds); all 1024 "
+                                            "workgroups are resident at once, so the block takes one chain; frac = algorithmic bytes over that time, for the record"})
         if rt_legs:
             rt_dt = rt_dts[int(np.argsort(rt_dts)[len(rt_dts) // 2])]
             rt_ach, (rt_ms, rt_bpl, rt_achieved, _), _rt_bt = roofline_of(rt_legs)

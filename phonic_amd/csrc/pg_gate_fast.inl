@@ -22,16 +22,27 @@ DEVO bool gate_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       float env = g.env_current, gain_db = g.gate_gain_db;
       uint32_t hold_counter = g.hold_counter;
       const float att = g.env_attack, rel = g.env_release, ac = g.attack_coeff, rc = g.release_coeff;
-      for (int n = 0; n < N; ++n) {
-        const float envelope = env_run(env, att, rel, db[n]);
+      auto step = [&](float level) -> float {
+        const float envelope = env_run(env, att, rel, level);
         float target_gain_db;
         if (envelope >= threshold) { hold_counter = hold_samples; target_gain_db = 0.0f; }
         else if (hold_counter > 0) { hold_counter -= 1; target_gain_db = 0.0f; }
         else target_gain_db = range_db;
         if (target_gain_db > gain_db) gain_db = ac * gain_db + (1.0f - ac) * target_gain_db;
         else gain_db = rc * gain_db + (1.0f - rc) * target_gain_db;
-        db[n] = gain_db;
+        return gain_db;
+      };
+      // eight frames per trip through LDS (two 16-byte reads, two 16-byte writes): the recurrence itself is ~15 dependent f32 operations per
+      // frame; read and written frame by frame it also paid an LDS round trip per frame (round 5: the Gate was the slowest of the ten effects
+      // alone, 0.12 ms per 1024-unit block — profiles/r05_per_effect.jsonl)
+      int n = 0;
+      for (; n + 8 <= N; n += 8) {
+        float4 a = *(const float4*)(db + n), b = *(const float4*)(db + n + 4);
+        a.x = step(a.x); a.y = step(a.y); a.z = step(a.z); a.w = step(a.w);
+        b.x = step(b.x); b.y = step(b.y); b.z = step(b.z); b.w = step(b.w);
+        *(float4*)(db + n) = a; *(float4*)(db + n + 4) = b;
       }
+      for (; n < N; ++n) db[n] = step(db[n]);
       g.env_current = env; g.gate_gain_db = gain_db; g.hold_counter = hold_counter;
     }
     __syncthreads();

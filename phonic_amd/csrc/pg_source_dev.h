@@ -12,6 +12,9 @@
 namespace pgd {
 
 constexpr int SRC_OUT_CAP = 1024;  // output frames per resampling piece
+#ifndef PG_SCHED_PAR_MIN
+#define PG_SCHED_PAR_MIN 192       // pieces shorter than this take the one-lane walk of the resampler schedule instead of the time-parallel scan (ratio in [0.5, 1))
+#endif
 constexpr int SRC_WIN_CAP = 1040;  // consumed input frames per piece (+4 history)
 
 struct SrcScratch {            // carved from the unit's LDS scratch arena
@@ -332,7 +335,10 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const int j = k * nt + tid; win_x[k] = j < bound ? src[j] : 0ull; }
         }
-        par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+        // Short pieces (small real-time callbacks): the time-parallel schedule is a fixed ~12 K cycles of scan levels and barriers on a workgroup
+        // whose block is a latency chain, the branch-free walk of one lane below ~15 cycles per output frame — the walk wins below a few hundred
+        // frames (stamps per callback size: profiles/r05_headline_stamps_by_callback_size.txt). The window stays requested either way.
+        if (piece >= PG_SCHED_PAR_MIN) par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
       } else {
         const float t23 = sp0 * (ratio < 2.0f ? 8388608.0f : 4194304.0f);
         if (ratio >= 1.0f && ratio < 4.0f && v->initialized[0] && num_in0 > 4ull * (uint64_t)piece + 4ull && sp0 >= 0.0f && sp0 < 1.0f && t23 == floorf(t23) && nt == 256) {
@@ -516,7 +522,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       float* w0 = S.win;
       float* w1 = S.win + (SRC_WIN_CAP + 4);
       if (tid < 4) { w0[tid] = v->input[0][3 - tid]; w1[tid] = v->input[1][3 - tid]; }  // oldest first: input[3] .. input[0]
-      if (par_ok && c_total <= win_pref) {
+      if (win_pref > 0 && c_total <= win_pref) {   // (requested in front of the schedule, from the run's first frame: par_ok or the linear walk)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = k * nt + tid;

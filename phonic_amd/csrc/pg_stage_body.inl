@@ -239,6 +239,10 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
   const StageLds m0 = stage_lds(smem);
   PgFx* lfx = m0.lfx; int* ctl = m0.ctl; float* red = m0.red;
   float* sig = (float*)(m0.arena + (RESIDENT ? STAGE1_UNION : ((STAGE_ARENA_PREFIX + 15) & ~15ull)));  // single launch: where stage 1 left it
+  // the sub-mixer's call record (peak and frames of the chunk's earlier pieces) is needed behind the tail: requested here, it arrives under the
+  // two scans instead of costing the hand-over a trip through the loaded memory system (nothing in this stage writes it before it is used)
+  float call_max0 = 0.0f; uint32_t call_frames0 = 0;
+  if (tid == 0) { call_max0 = unit.call_max; call_frames0 = unit.call_frames; }
   __syncthreads();
   // Per-stage launches: the dry signal (stage 1 left it in the unit's output row) is only needed at the end of the tail. It travels
   // global -> LDS directly (lds_dma_dword: no registers, no wait here) while the two scans run; a dependent load at this point would
@@ -277,7 +281,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
   PG_STAMP(L.diag, 62);
   // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77), one call per chunk ----
   const bool closes = (flags & PG_STAGE_LAST) != 0;
-  if (tid == 0) { ctl[8] = __float_as_int(unit.call_max); ctl[9] = (int)unit.call_frames; }
+  if (tid == 0) { ctl[8] = __float_as_int(call_max0); ctl[9] = (int)call_frames0; }
   __syncthreads();
   const bool aud = submixer_call_piece(unit, ctl + 8, sig, out, 0, N, closes, L.sample_rate, (size_t)L.chunk_stride, (int)(L.out_stride / 2), ctl, red);
   if (tid == 0) {

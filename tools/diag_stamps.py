@@ -5,16 +5,17 @@ from phonic_amd.graph import Graph
 from phonic_amd import _capi
 import workloads
 V=int(sys.argv[1]) if len(sys.argv)>1 and sys.argv[1].isdigit() else 1024
-g=Graph(48000,2,1024,0)
+N=int(sys.argv[sys.argv.index('--frames')+1]) if '--frames' in sys.argv else 1024   # frames per call (= max_frames)
+g=Graph(48000,2,N,0)
 (workloads.build_c5 if 'c5' in sys.argv else workloads.build_headline)(g,V,0,V,2.0)
 lib=_capi.load()
 lib.pg_graph_diag.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.c_int]
 buf=(C.c_uint64*64)()
 lib.pg_graph_diag(g._h,buf,64)
-bus=torch.zeros(2048,device='cuda:0')
+bus=torch.zeros(2*N,device='cuda:0')
 pos=0
 for i in range(20):
-    g.write_device(bus.data_ptr(),2048,pos); pos+=1024
+    g.write_device(bus.data_ptr(),2*N,pos); pos+=N
 g.synchronize()
 lib.pg_graph_diag(g._h,buf,64)
 t=[buf[i] for i in range(64)]

@@ -8,7 +8,7 @@ cp -r $ROOT/phonic_amd/csrc $W/phonic_amd/csrc
 cp $ROOT/include/phonic_gpu.h $W/include/
 cd $W/phonic_amd/csrc
 rm -f *.o libphonic_gpu.so
-make -s -j5 FAST_WAVES="2 $2" 2>&1 | grep -iE " error|spill" | head -5 || true
+make -s -j8 FAST_WAVES="2 $2" 2>&1 | grep -iE " error|spill" | head -5 || true
 mkdir -p $ROOT/tools/ab_libs
 cp libphonic_gpu.so $ROOT/tools/ab_libs/$1.so
 echo "built tools/ab_libs/$1.so"

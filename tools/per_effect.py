@@ -77,7 +77,7 @@ def run(kind, name, params, ramp_param, ramp_vals, ramp):
     ms_block = dt * 1e3 / (calls * PER_CALL)
     b_alg = 8.0 + STATE_B.get(name, 0.0) + 8.0 / V
     gbs = b_alg * V * BLOCK / (ms_block * 1e-3) / 1e9
-    stream_ms = b_alg * V * BLOCK / 5.6e12 * 1e3   # what the bytes alone would take at the access stream's 5.6 TB/s (profiles/r04_ringstream.jsonl)
+    stream_ms = b_alg * V * BLOCK / 5.6e12 * 1e3   # what the bytes alone would take at the access stream's 5.6 TB/s (profiles/r04/r04_ringstream.jsonl)
     print(json.dumps({"effect": name, "case": "ramp" if ramp else "steady", "units": V, "blocks_per_call": PER_CALL, "ms_per_block": round(ms_block, 4),
                       "voice_frames_per_s": round(V * BLOCK / (ms_block * 1e-3)), "b_alg": round(b_alg, 2), "achieved_gbs": round(gbs, 1), "roofline_frac": round(gbs / 8000.0, 4),
                       "bound": "hbm" if stream_ms > 0.5 * ms_block else "latency", "kernel": g.dominant_kernel(),
