@@ -13,5 +13,5 @@ __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage2_kernel(PgLaunch
 __global__ void __launch_bounds__(256, PG_STAGE_WAVES) pg_stage3_kernel(PgLaunch L) {
   if ((int)blockIdx.x >= L.n_units || !stage_unit_staged<1>(L, blockIdx.x)) return;
   bool deferred; const int flags = stage_unit_flags(L, blockIdx.x, deferred);
-  if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags);
+  if (!deferred) stage3_run<1, false>(L, blockIdx.x, flags, pg_smem, 0, make_int4(0, 0, 0, 0));
 }

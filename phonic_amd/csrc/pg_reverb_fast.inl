@@ -489,6 +489,19 @@ DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
   return b.t_mid >= 32 && b.predelay >= 32;
 }
 
+// The same parameters read back from the effect's state block (an LDS copy that rev_block_params has validated in THIS block — the staged
+// single launch, stages 2 and 3): no barrier, no lane-0 work; the values are uniform and go to scalar registers.
+DEVO void rev_block_params_cached(const PgFx& fx, RevBlock& b) {
+  const PgReverb& r = fx.u.reverb;
+  b.blend = uni_f64(r.c_blend); b.regen = uni_f64(r.c_regen); b.wet = uni_f64((double)r.wet.target);
+  b.predelay = uni_u32(r.c_predelay);
+  uint32_t t_mid = 0xffffffffu;
+  for (int i = 0; i < 4; ++i) t_mid = t_mid < r.ap[i].delay ? t_mid : r.ap[i].delay;
+  for (int i = 0; i < 8; ++i) { uint32_t d = r.line[i].delay > 17 ? r.line[i].delay - 17 : 0; t_mid = t_mid < d ? t_mid : d; }
+  if (t_mid > (uint32_t)REV_T_CAP) t_mid = REV_T_CAP;
+  b.t_mid = uni_u32(t_mid);
+}
+
 // ---- front: predelay (DelayLine<2>::process, delay.rs:47-66) in chunks of <= predelay frames, then biquad A ----
 template <bool SCAN_A = true>
 DEVO void rev_front(PgReverb& r, const float* s0, int T, const RevLds& m, const RevBlock& b, unsigned long long* diag) {

@@ -51,6 +51,10 @@ __device__ __forceinline__ PgFx& stage_reverb(const PgLaunch& L, const PgUnit& u
 // unit was deferred to the generic kernel.
 // Returns the unit's stage flags (PG_STAGE_*, also left in the unit record for the per-stage launches), or -1 when the unit was
 // deferred to the generic kernel.
+// Single launch: the later stages of the block take the reverb's block parameters from the effect's LDS copy as this stage left it
+// (rev_block_params_cached) instead of asking rev_block_params again — four barriers and a lane-0 trip through LDS each, on a workgroup
+// whose block is a latency chain. The sub-mixer's call record (peak and frames of the chunk's earlier pieces) is read here with the unit
+// record and waits in ctl[26] / ctl[27] for stage 3: it used to cost that stage a dependent trip through the loaded memory system at its head.
 template <int TAG, bool RESIDENT>
 __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int4 si, const int chunk = 0, char* smem = pg_smem) {
   // `si` = L.slot_info[slot], loaded by the kernel: one load names the unit, its first voice and its reverb (and the unit's staged
@@ -114,6 +118,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
   const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
   const int chunk_audible_input = unit.chunk_audible_input;
+  if (RESIDENT && tid == 0) { ctl[26] = __float_as_int(unit.call_max); ctl[27] = (int)unit.call_frames; }   // (written by stage 3 of the piece before; ctl[24..31]: no stage writes them)
   for (int i = tid; i < 2 * N; i += nt) sig[i] = 0.0f;  // clear_buffer (mixed.rs:673)
   __syncthreads();
   // (staged units are sub-mixers of the main mixer without commands: their chunks are the main mixer's)
@@ -213,9 +218,10 @@ __device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flag
     stage_load_image(m.bufA, L.stage_buf + (size_t)slot * PG_STAGE_BUF_DOUBLES, N);
   }
   __syncthreads();
-  rev_load_vtab(lfx->u.reverb, m);
+  rev_load_vtab(lfx->u.reverb, m);   // (visible behind the first barrier of rev_mid's chunk set-up)
   RevBlock b;
-  (void)rev_block_params(*lfx, m, m0.ctl, b);
+  if (RESIDENT) rev_block_params_cached(*lfx, b);
+  else (void)rev_block_params(*lfx, m, m0.ctl, b);
   rev_mid(lfx->u.reverb, N, m, b, m0.ctl, L.diag);
   __syncthreads();
   if (!RESIDENT) {
@@ -226,10 +232,11 @@ __device__ __forceinline__ void stage2_run(const PgLaunch& L, int slot, int flag
 }
 
 template <int TAG, bool RESIDENT>
-__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags, char* smem = pg_smem, const int chunk = 0) {
-  // one load names the unit and its reverb (as in stage 1); it is issued ahead of the dry-signal transfer below so that waiting
-  // for it does not wait for the transfer (loads return in order)
-  const int4 si = L.slot_info[slot];
+__device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flags, char* smem, const int chunk, const int4 si_in) {
+  // single launch: the slot's table entry, the block parameters and the sub-mixer's call record come from stage 1 (registers / ctl[26..27]).
+  // Per-stage launches: one load names the unit and its reverb (as in stage 1); it is issued ahead of the dry-signal transfer below so that
+  // waiting for it does not wait for the transfer (loads return in order)
+  const int4 si = RESIDENT ? si_in : L.slot_info[slot];
   PgUnit& unit = L.units[si.x];
   PgFx& gfx = L.fx[si.z];
   const int tid = pg_tid(), nt = blockDim.x;
@@ -242,8 +249,8 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
   // the sub-mixer's call record (peak and frames of the chunk's earlier pieces) is needed behind the tail: requested here, it arrives under the
   // two scans instead of costing the hand-over a trip through the loaded memory system (nothing in this stage writes it before it is used)
   float call_max0 = 0.0f; uint32_t call_frames0 = 0;
-  if (tid == 0) { call_max0 = unit.call_max; call_frames0 = unit.call_frames; }
-  __syncthreads();
+  if (!RESIDENT && tid == 0) { call_max0 = unit.call_max; call_frames0 = unit.call_frames; }
+  if (!RESIDENT) __syncthreads();
   // Per-stage launches: the dry signal (stage 1 left it in the unit's output row) is only needed at the end of the tail. It travels
   // global -> LDS directly (lds_dma_dword: no registers, no wait here) while the two scans run; a dependent load at this point would
   // cost a full trip through the loaded memory system. Lane l of wave w, trip k: sample k * 256 + w * 64 + l.
@@ -264,7 +271,8 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
       }
       __syncthreads();
       RevBlock b;
-      (void)rev_block_params(*lfx, m, ctl, b);
+      if (RESIDENT) rev_block_params_cached(*lfx, b);
+      else (void)rev_block_params(*lfx, m, ctl, b);
       rev_tail_impl<!RESIDENT>(lfx->u.reverb, sig, N, m, b, L.diag);
       PG_STAMP(L.diag, 60);
       if (!lfx->standalone) fx_processor_post(*lfx, sig, N * 2, (flags & PG_STAGE_INPUT_BYPASSED) != 0, (flags & PG_STAGE_LAST) != 0, L.sample_rate, ctl, red);
@@ -281,7 +289,7 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
   PG_STAMP(L.diag, 62);
   // ---- hand the block to the parent mixer: staged units are sub-mixers (SubMixerProcessor::process, submixer.rs:47-77), one call per chunk ----
   const bool closes = (flags & PG_STAGE_LAST) != 0;
-  if (tid == 0) { ctl[8] = __float_as_int(call_max0); ctl[9] = (int)call_frames0; }
+  if (tid == 0) { ctl[8] = RESIDENT ? ctl[26] : __float_as_int(call_max0); ctl[9] = RESIDENT ? ctl[27] : (int)call_frames0; }
   __syncthreads();
   const bool aud = submixer_call_piece(unit, ctl + 8, sig, out, 0, N, closes, L.sample_rate, (size_t)L.chunk_stride, (int)(L.out_stride / 2), ctl, red);
   if (tid == 0) {
@@ -328,9 +336,9 @@ __device__ __forceinline__ int stage_unit_flags(const PgLaunch& L, int slot, boo
 #endif
 typedef __attribute__((address_space(3))) char* PgLdsPtr;
 #if PG_STAGE_OUTLINE & 4
-static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk); }
+static __device__ __noinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk, int4 si) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk, si); }
 #else
-__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk); }
+__device__ __forceinline__ void stage3_call(const PgLaunch* L, int slot, int flags, PgLdsPtr smem, int chunk, int4 si) { stage3_run<2, true>(*L, slot, flags, (char*)smem, chunk, si); }
 #endif
 // The kernel's dynamic LDS as an opaque value: handed to the out-of-line stage as is, constant propagation would put the name
 // pg_smem (and with it the offset-table lookup) back into the callee.
@@ -374,7 +382,7 @@ __device__ __forceinline__ void stage_fused_body(const PgLaunch& L) {
     stage2_run<TAG, true>(L, slot, flags);
     __syncthreads();
     PG_SLOT_STAMP(2);
-    stage3_call(&sL, slot, flags, stage_smem_arg(), chunk);
+    stage3_call(&sL, slot, flags, stage_smem_arg(), chunk, si);
     PG_SLOT_STAMP(3);
     __syncthreads();
   }
