@@ -115,10 +115,9 @@ DEVO bool chorus_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     // 0. the sequences of the piece
     if (tid < 4) {
       PgSmooth& g = tid == 0 ? c.delay : (tid == 1 ? c.depth : (tid == 2 ? c.feedback : c.wet));
-      PgSmooth sm = g;
       float* dst = seq + tid * cap;
-      for (int k = 0; k < P; ++k) { const float v = sm_next(sm); dst[k] = tid == 2 ? clampf(v, -0.999f, 0.999f) : v; }
-      g = sm;
+      sm_sequence(g, dst, P);
+      if (tid == 2) for (int k = 0; k < P; ++k) dst[k] = clampf(dst[k], -0.999f, 0.999f);
     } else if (tid == 64) {  // update_lfos while rate / phase ramp, then lfo.run() of both oscillators (chorus.rs:327-329,353-354)
       PgSmooth rate = c.rate, phase = c.phase;
       PgLfo o0 = c.osc[0], o1 = c.osc[1];

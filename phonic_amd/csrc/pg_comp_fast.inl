@@ -138,7 +138,7 @@ DEVO bool comp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
       const float cur = carry;
       if (tid == 0) {
         c.env_current = cur;
-        if (makeup_ramps) { PgSmooth m = c.makeup; for (int n = 0; n < N; ++n) a0[n] = sm_next(m); c.makeup = m; }  // makeup_gain.next_value() per frame (a0 is free by now)
+        if (makeup_ramps) sm_sequence(c.makeup, a0, N);  // makeup_gain.next_value() per frame (a0 is free by now)
         c.peak_value = (double)__uint_as_float((uint32_t)red[0]);
         c.peak_pos = (wp0 + (uint32_t)red[1]) & mask;
         c.write_pos = (wp0 + (uint32_t)N) & mask;

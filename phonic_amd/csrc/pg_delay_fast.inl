@@ -212,10 +212,8 @@ DEVO bool delay_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     __syncthreads();
     // 0. the ten sequences of the piece
     if (tid < DELAY_RAMP_SEQS - 1) {
-      PgSmooth sm = delay_ramp_smoother(d, tid);
       float* dst = seq + tid * cap;
-      for (int k = 0; k < P; ++k) dst[k] = sm_next(sm);
-      delay_ramp_smoother(d, tid) = sm;
+      sm_sequence(delay_ramp_smoother(d, tid), dst, P);
     } else if (tid == 64) {  // lfo.run(), then the rate update while it ramps (delay.rs:343-347)
       PgLfo l = d.lfo;
       PgSmooth rate = d.lfo_rate;

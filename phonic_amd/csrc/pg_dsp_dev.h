@@ -91,12 +91,15 @@ DEV float sm_next(PgSmooth& s) {  // :21-28
   if (sm_need_ramp(s)) { sm_ramp(s); return s.current; }
   return s.target;
 }
-// n successive values of sm_next into dst (one lane; the callers hand the sequence to all lanes). The exponential smoother — the one every
-// source volume / panning uses — as a tight loop: the ramp test and the ramp step share their one expression (smoothing.rs:198-214).
+// n successive values of sm_next into dst (one lane; the callers hand the sequence to all lanes): the smoother's state in registers for the
+// whole walk — the ramp test and the ramp step of each kind share their expressions (smoothing.rs:198-214, 360-382, 499-518), same operations in
+// the same order as sm_next. (A loop of sm_next calls on a PgSmooth costs ~500 cycles per frame: the record is re-read and re-written through
+// memory on every call. One commanded reverb's wet ramp was 0.2 ms per 1024-frame block that way, tools/diag_cmd.py.)
 DEV void sm_sequence(PgSmooth& s, float* dst, int n) {
+  const float t = s.target;
   if (s.kind == SM_EXP) {
     float c = s.current;
-    const float t = s.target, a = s.a, comp = s.comp;
+    const float a = s.a, comp = s.comp;
     for (int i = 0; i < n; ++i) {
       const float add = (t - c) * a * comp;
       const bool ramp = fabsf(add) > F32_EPS100;
@@ -104,9 +107,27 @@ DEV void sm_sequence(PgSmooth& s, float* dst, int n) {
       dst[i] = ramp ? c : t;
     }
     s.current = c;
-    return;
+  } else if (s.kind == SM_LIN) {
+    float c = s.current;
+    const float step = s.b;
+    uint32_t pending = s.pending;
+    for (int i = 0; i < n; ++i) {
+      const bool ramp = pending > 0;
+      if (ramp) { c += step; pending -= 1; if (pending == 0) c = t; }
+      dst[i] = ramp ? c : t;
+    }
+    s.current = c; s.pending = pending;
+  } else {
+    float c = s.current, vel = s.b;
+    const float omega = s.a * s.comp;
+    const float k = omega * omega, d = 2.0f * omega;
+    for (int i = 0; i < n; ++i) {
+      const bool ramp = fabsf(vel) > F32_EPS100 || fabsf(t - c) > F32_EPS100;
+      if (ramp) { vel += (t - c) * k - vel * d; c += vel; }
+      dst[i] = ramp ? c : t;
+    }
+    s.current = c; s.b = vel;
   }
-  for (int i = 0; i < n; ++i) dst[i] = sm_next(s);
 }
 DEV void sm_init(PgSmooth& s, float v) {
   s.target = v; s.current = v;

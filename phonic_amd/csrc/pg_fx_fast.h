@@ -79,11 +79,9 @@ DEVO void filter_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     const int T = frames - done < piece ? frames - done : piece;
     float* qv = cut + T;
     __syncthreads();
-    if (tid == 0) {
-      PgSmooth sc = f.cutoff, sq = f.q;
-      for (int k = 0; k < T; ++k) { cut[k] = clampf(sm_next(sc), 20.0f, nyq); qv[k] = sm_next(sq); }
-      f.cutoff = sc; f.q = sq;
-    }
+    // (the two smoothers do not interact: one lane each, in different waves; the clamp of the cutoff follows on the same lane)
+    if (tid == 0) { sm_sequence(f.cutoff, cut, T); for (int k = 0; k < T; ++k) cut[k] = clampf(cut[k], 20.0f, nyq); }
+    else if (tid == 64) sm_sequence(f.q, qv, T);
     for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
     __syncthreads();
     auto coef = [&](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {
@@ -123,9 +121,9 @@ DEVO void eq5_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc) {
     for (int s = tid; s < 2 * T; s += nt) buf[REV_IDX(s >> 1, s & 1)] = (double)sig[2 * done + s];
     for (int i = 0; i < 5; ++i) {
       __syncthreads();
-      if (tid == 0) { PgSmooth s = e.bws[i]; for (int k = 0; k < T; ++k) { const float b = sm_next(s); qv[k] = (i == 0 || i == 4) ? b : 1.0f / fmaxf(b, 0.001f); } e.bws[i] = s; }
-      else if (tid == 64) { PgSmooth s = e.freqs[i]; for (int k = 0; k < T; ++k) cut[k] = clampf(sm_next(s), 20.0f, nyq); e.freqs[i] = s; }
-      else if (tid == 128) { PgSmooth s = e.gains[i]; for (int k = 0; k < T; ++k) gn[k] = sm_next(s); e.gains[i] = s; }
+      if (tid == 0) { sm_sequence(e.bws[i], qv, T); if (!(i == 0 || i == 4)) for (int k = 0; k < T; ++k) qv[k] = 1.0f / fmaxf(qv[k], 0.001f); }
+      else if (tid == 64) { sm_sequence(e.freqs[i], cut, T); for (int k = 0; k < T; ++k) cut[k] = clampf(cut[k], 20.0f, nyq); }
+      else if (tid == 128) sm_sequence(e.gains[i], gn, T);
       if (tid < 2) lst[tid] = e.st[tid][i];
       __syncthreads();
       const int btype = eq5_band_type(i);
@@ -195,7 +193,7 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
       float* gseq = fc.tmp;
       const int gcap = fc.tmp_floats < 1024 ? fc.tmp_floats : 1024;
       auto lay_out = [&](int T) {  // the gains of the next T frames -> gseq (caller syncs)
-        if (tid == 0) { PgSmooth sg = g.gain; for (int k = 0; k < T; ++k) gseq[k] = sm_next(sg); g.gain = sg; }
+        if (tid == 0) sm_sequence(g.gain, gseq, T);
       };
       float v = g.gain.target;
       if (g.dc_mode != 0) {
@@ -253,8 +251,8 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
           for (int done = 0; done < frames; done += cap) {
             const int T = frames - done < cap ? frames - done : cap;
             __syncthreads();
-            if (tid == 0) { PgSmooth sp = p.pan; for (int k = 0; k < T; ++k) pseq[k] = pan_ramping ? sm_next(sp) : sp.target; p.pan = sp; }
-            else if (tid == 64) { PgSmooth sw = p.width; for (int k = 0; k < T; ++k) wseq[k] = width_ramping ? sm_next(sw) : sw.target; p.width = sw; }
+            if (tid == 0) { if (pan_ramping) sm_sequence(p.pan, pseq, T); else { const float v = p.pan.target; for (int k = 0; k < T; ++k) pseq[k] = v; } }
+            else if (tid == 64) { if (width_ramping) sm_sequence(p.width, wseq, T); else { const float v = p.width.target; for (int k = 0; k < T; ++k) wseq[k] = v; } }
             __syncthreads();
             for (int k = tid; k < T; k += nt) {
               const int f = 2 * (done + k);
@@ -342,8 +340,8 @@ DEVO bool fx_fast_process(PgFx& fx, float* sig, int n, FastCtx& fc) {
           for (int done = 0; done < frames; done += cap) {
             const int T = frames - done < cap ? frames - done : cap;
             __syncthreads();
-            if (tid == 0) { PgSmooth sd = d.drive; for (int k = 0; k < T; ++k) dseq[k] = sm_next(sd); d.drive = sd; }
-            else if (tid == 64 && !full_wet) { PgSmooth sx = d.mix; for (int k = 0; k < T; ++k) mseq[k] = sm_next(sx); d.mix = sx; }
+            if (tid == 0) sm_sequence(d.drive, dseq, T);
+            else if (tid == 64 && !full_wet) sm_sequence(d.mix, mseq, T);
             __syncthreads();
             for (int s = tid; s < 2 * T; s += nt) {
               const float drive = dseq[s >> 1];

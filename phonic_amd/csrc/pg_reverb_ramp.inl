@@ -25,15 +25,12 @@ DEVO bool reverb_wet_ramp_fast(PgFx& fx, float* sig, int n_samples, FastCtx& fc)
     float* wv = fc.tmp;       // [T] wet per frame
     float* cut = fc.tmp + T;  // [T] low-pass cutoff per frame (reverb.rs:413, clamped as update_filter_coefs does)
     __syncthreads();
-    if (tid == 0) {
-      PgSmooth s = r.wet;
-      for (int k = 0; k < T; ++k) {
-        const float w = sm_next(s);
-        wv[k] = w;
-        cut[k] = clampf((float)(10000.0 - (rs * (double)w * 3000.0)), 20.0f, nyq);
-      }
-      r.wet = s;
-    }
+    // the smoother's value sequence on one lane (sm_sequence: the exponential smoother as a tight register loop — the generic sm_next loop
+    // through a local PgSmooth cost ~500 cycles per frame here, 0.2 ms per 1024-frame block of ONE commanded unit: tools/diag_cmd.py), the
+    // cutoff that follows from it on all lanes
+    if (tid == 0) sm_sequence(r.wet, wv, T);
+    __syncthreads();
+    for (int k = tid; k < T; k += nt) cut[k] = clampf((float)(10000.0 - (rs * (double)wv[k] * 3000.0)), 20.0f, nyq);
     __syncthreads();
     auto coef_q = [&](float q) {
       return [=](int n, double& a1, double& a2, double& a3, double& m0, double& m1, double& m2) {

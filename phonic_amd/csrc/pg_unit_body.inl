@@ -523,6 +523,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   float* const out = external ? nullptr : L.unit_out + (size_t)chunk * L.chunk_stride + (size_t)slot * L.out_stride;
   int call_start = 0;
   bool cmd_at_0 = false;
+  int chain_ramping = -1;   // generic kernel, lane 0: does an effect of the chain still ramp? — from the LDS copies the last segment's chain left (-1: that segment did not run it)
   while (frame0 < N) {
     // apply all commands due at frame0 (process_events, event.rs:41-50)
     while (!FAST_ONLY && ci < L.n_cmds && L.cmds[ci].unit == u && (int)L.cmds[ci].frame <= frame0) {  // (the fast kernel defers units with commands)
@@ -618,10 +619,12 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     }
     PG_STAMP(L.diag, 1);
     // process_effects (mixed.rs:627-655)
+    if (!FAST_ONLY) chain_ramping = -1;
     if (PG_UL(n_fx) > 0) {
       bool input_bypassed = !audible_input;
       if (!(PG_UL(effects_bypassed) && input_bypassed)) {
         bool all_bypassed = true;
+        if (!FAST_ONLY) chain_ramping = 0;
         for (int fi = 0; fi < PG_UL(n_fx); ++fi) {
           // stage the effect's state block in LDS: the per-block bookkeeping of lane 0 (smoother checks, coefficient and
           // delay-length updates, ring positions) then costs LDS instead of HBM round trips; written back afterwards
@@ -647,6 +650,9 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
           else is_active = fx_processor_process<FAST_ONLY, KMASK>(fx, sseg, seg * 2, input_bypassed, seg_first, seg_last, L.sample_rate, fc, L.fast, ctl, red);
           if (is_active) { input_bypassed = false; all_bypassed = false; }
           __syncthreads();
+          // (the steady-state test below, on the state as it goes back to global memory: read here it costs LDS trips — twelve ring positions of a
+          // reverb from global memory were ~15 K cycles at the end of a commanded unit's block, tools/diag_cmd.py)
+          if (!FAST_ONLY && tid == 0) chain_ramping |= fx_fast_eligible(fx, PG_UL(staged) != 0 || L.wide == 0) ? 0 : 1;
           for (int i = tid; i < (int)(sizeof(PgFx) / 4); i += nt) ((uint32_t*)&gfx)[i] = ((const uint32_t*)lfx)[i];
         }
         carry.fx_valid = 1;
@@ -661,7 +667,8 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
 
   if (!FAST_ONLY && tid == 0) {  // back in steady state? (decides whether the fast kernel may take the unit next block)
     int ramping = 0;
-    for (int fi = 0; fi < PG_UL(n_fx); ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[PG_UL(fx_off) + fi]], PG_UL(staged) != 0 || L.wide == 0) ? 0 : 1;  // (staged and lean kernels carry no ramp paths)
+    if (chain_ramping >= 0) ramping = chain_ramping;   // the block's last segment ran the chain: decided there, on the LDS copies
+    else for (int fi = 0; fi < PG_UL(n_fx); ++fi) ramping |= fx_fast_eligible(L.fx[L.fx_index[PG_UL(fx_off) + fi]], PG_UL(staged) != 0 || L.wide == 0) ? 0 : 1;  // (staged and lean kernels carry no ramp paths)
     for (int vi = 0; vi < PG_UL(n_voices); ++vi) {  // a pitch glide in progress is rendered here as well
       const PgVoice& vv = L.voices[L.voice_index[PG_UL(voice_off) + vi]];
       ramping |= (vv.current_speed != vv.target_speed) ? 1 : 0;
