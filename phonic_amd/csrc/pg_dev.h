@@ -259,7 +259,7 @@ struct PgUnit {
                                 // kernel once every effect of the unit is back in steady state)
   int32_t voice0;               // host: device index of the unit's first voice (skips one dependent load at kernel start)
   int32_t fx0;                  // host: device index of the unit's first effect (prefetched during the source stage)
-  int32_t staged;               // host: the chain is [Gain|Panning]* -> Reverb: eligible for the staged pipeline (pg_stage*_kernel)
+  int32_t staged;               // host: reverb-terminated chain, eligible for the staged pipeline: 1 lean, 2 wide leading effects, 3 wide + source adapters (pg_stage_body.inl)
   int32_t stage_flags;          // device: hand-over between the stage kernels of one block (PG_STAGE_*)
   int32_t child_off, n_children;  // host: nested sub-mixers of this mixer, entries of PgLaunch::child_rows (summed before the sources)
   int32_t seg_idx;              // device: semantic chunks this mixer has begun in the main mixer's current chunk, minus one (indexes its sub-mixers' call_audible)
@@ -334,7 +334,7 @@ struct PgLaunch {
   int32_t* defer_reset;   // the other round's counter, zeroed by the generic kernel for the next round
   unsigned long long* host_feedback;  // pinned host word: the generic kernel reports (round << 32 | units it found deferred)
   uint32_t round;         // launch counter of this round
-  int32_t staged_on;      // 1: units flagged `staged` are rendered by the stage kernels of this round, the fused fast kernel skips them
+  int32_t staged_on;      // units whose `staged` level is 1 .. staged_on are rendered by the stage kernels of this round, the fused fast kernel skips them
   uint64_t call_end;      // position at which the MixedSource::write call this launch belongs to ends (see PgVoice::zombie_end)
   const float* rows_base; // nested sub-mixers: row 0 of the per-unit output table (unit_out points at this launch's level) ...
   const int2* child_rows; // ... and {row, unit slot} of every nested sub-mixer, indexed by PgUnit::child_off

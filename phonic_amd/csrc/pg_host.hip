@@ -128,7 +128,7 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     if (m == 0) { u.n_voices = 0; u.voice_off = 0; continue; }
     if (!mx.children.empty()) u.staged = 0;  // sums its sub-mixers' rows first (previous level): not a staged unit; the fast kernels take it in steady state
     for (int v : mx.voices) {
-      if (g->voices[v].outer || g->voices[v].stream) u.staged = 0;  // ResampledSource staging / host-fed ring: the fast kernels render them, the staged ones do not carry the code
+      if ((g->voices[v].outer || g->voices[v].stream) && u.staged) u.staged = 3;  // ResampledSource staging / host-fed ring: the staged kernel whose source stage carries the adapters (round 5: pg_stage_fused_adapt_kernel)
       if (g->voices[v].outer) g->any_outer = true;
     }
     u.voice_off = (int)vidx.size(); u.n_voices = (int)mx.voices.size();
@@ -193,14 +193,14 @@ static int rebuild_topology(pg_graph* g, hipStream_t stream) {
     }
     if ((rc = g->d_slot_lead.upload_async(lead, stream))) return rc;
   }
-  g->n_staged = 0; g->n_staged_wide = 0; g->n_static_defer = 0;
+  g->n_staged = 0; g->n_staged_wide = 0; g->n_staged_adapt = 0; g->n_static_defer = 0;
   for (Level& lv : g->levels) {
-    lv.n_staged = lv.n_staged_wide = lv.n_static_defer = 0;
+    lv.n_staged = lv.n_staged_wide = lv.n_staged_adapt = lv.n_static_defer = 0;
     for (int i = lv.off; i < lv.off + lv.cnt; ++i) {
       const PgUnit& u = topo[g->order[i]];
-      lv.n_staged += u.staged ? 1 : 0; lv.n_staged_wide += u.staged == 2 ? 1 : 0; lv.n_static_defer += u.static_defer ? 1 : 0;
+      lv.n_staged += u.staged ? 1 : 0; lv.n_staged_wide += u.staged == 2 ? 1 : 0; lv.n_staged_adapt += u.staged == 3 ? 1 : 0; lv.n_static_defer += u.static_defer ? 1 : 0;
     }
-    g->n_staged += lv.n_staged; g->n_staged_wide += lv.n_staged_wide; g->n_static_defer += lv.n_static_defer;
+    g->n_staged += lv.n_staged; g->n_staged_wide += lv.n_staged_wide; g->n_staged_adapt += lv.n_staged_adapt; g->n_static_defer += lv.n_static_defer;
   }
   g->h_units = topo;
   g->fast_kind_mask = kind_mask;
@@ -938,13 +938,14 @@ int pg_graph_set_fast_math(pg_graph* g, int level) { g->fast = level != 0; g->la
 const char* pg_graph_dominant_kernel(pg_graph* g) {
   if (g->topo_dirty) { (void)graph_quiesce(g); (void)rebuild_topology(g, g->stream); (void)pg_stream_sync(g->stream); }
   if (!g->fast || g->n_static_defer * 2 > g->n_graph_units) return "pg_unit_kernel";
-  const int n_lean = g->n_staged - g->n_staged_wide;
+  const int n_lean = g->n_staged - g->n_staged_wide - g->n_staged_adapt;
   const int n_handled = g->staged_mode == 1 ? g->n_staged : n_lean;
   if (g->staged_mode && n_handled > 0) {
     if (g->staged_mode == 2) return n_handled < g->n_graph_units ? "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel + pg_unit_kernel_fast" : "pg_stage1_kernel + pg_stage2_kernel + pg_stage3_kernel";
     if (n_handled < g->n_graph_units) return "pg_stage_fused_kernel + pg_unit_kernel_fast";
-    if (n_lean > 0 && g->n_staged_wide > 0) return "pg_stage_fused_kernel + pg_stage_fused_wide_kernel";
-    return g->n_staged_wide > 0 ? "pg_stage_fused_wide_kernel" : "pg_stage_fused_kernel";
+    const int kinds = (n_lean > 0) + (g->n_staged_wide > 0) + (g->n_staged_adapt > 0);
+    if (kinds > 1) return n_lean > 0 ? (g->n_staged_wide > 0 ? (g->n_staged_adapt > 0 ? "pg_stage_fused_kernel + pg_stage_fused_wide_kernel + pg_stage_fused_adapt_kernel" : "pg_stage_fused_kernel + pg_stage_fused_wide_kernel") : "pg_stage_fused_kernel + pg_stage_fused_adapt_kernel") : "pg_stage_fused_wide_kernel + pg_stage_fused_adapt_kernel";
+    return g->n_staged_adapt > 0 ? "pg_stage_fused_adapt_kernel" : (g->n_staged_wide > 0 ? "pg_stage_fused_wide_kernel" : "pg_stage_fused_kernel");
   }
   return g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || g->levels.size() > 1 || g->any_outer) ? "pg_unit_kernel_fast_wide" : "pg_unit_kernel_fast_mid") : "pg_unit_kernel_fast";
 }
@@ -1195,12 +1196,12 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     // fast kernel; units it cannot run (ramping parameters, effects without a fast path) are deferred ...
     L.mode = 1; L.wide = g->wide ? (((g->fast_kind_mask & ((1u << PG_FX_REVERB) | (1u << PG_FX_COMPRESSOR))) || nested || g->any_outer) ? 1 : 2) : 0;  // (2: the four-per-CU kernel; it neither sums nested mixers nor stages a ResampledSource)
     // reverb-terminated sub-mixers go through the staged kernels; level 2 (wide leading effects) only in the single-launch mode
-    const int n_lean = lv.n_staged - lv.n_staged_wide;
+    const int n_lean = lv.n_staged - lv.n_staged_wide - lv.n_staged_adapt;
     const int n_handled = g->staged_mode == 1 ? lv.n_staged : n_lean;
     const bool staged = g->staged_mode && n_handled > 0 && g->d_stage && n <= 1024;
-    const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && lv.n_staged_wide > 0;
+    const bool lean = staged && n_lean > 0, wide = staged && g->staged_mode == 1 && lv.n_staged_wide > 0, adapt = staged && g->staged_mode == 1 && lv.n_staged_adapt > 0;
     const bool fused = !staged || n_handled < lv.cnt;
-    const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide : 3) : 0) + (int)fused;
+    const int n_launches = (staged ? (g->staged_mode == 1 ? (int)lean + (int)wide + (int)adapt : 3) : 0) + (int)fused;
     const bool ride = timed_here && !time_generic && n_launches == 1;       // one dominant launch: timestamps from its dispatch
     const bool bracket = timed_here && !time_generic && n_launches > 1;
     // Off the steady state (commands in the block, smoothers still moving): the units the time-parallel kernels cannot take and the units
@@ -1231,8 +1232,8 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     if (bracket) HIP_TRY(hipEventRecord(e0, fs));
     L.stage_buf = nullptr; L.staged_on = 0;
     if (staged) {
-      L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 2 : 1;
-      HIP_TRY(pg_launch_stages(L, fs, g->staged_mode == 1 ? 1 : 0, lean, wide, ride ? e0 : nullptr, ride ? e1 : nullptr));
+      L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 3 : 1;
+      HIP_TRY(pg_launch_stages(L, fs, g->staged_mode == 1 ? 1 : 0, lean, wide, adapt, ride ? e0 : nullptr, ride ? e1 : nullptr));
     }
     if (fused) HIP_TRY(pg_launch_units(L, fs, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
     if (bracket) HIP_TRY(hipEventRecord(e1, fs));

@@ -31,7 +31,7 @@ size_t pg_stage_lds_bytes(int stage, uint32_t n_frames);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide);  // wide: the staged kernel that renders effects in front of the reverb (their state slots)
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream);
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
                          size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0);
 
@@ -211,7 +211,7 @@ struct HostMixer {
 };
 // Launch level: the units of one depth of the mixer tree. A mixer reads its sub-mixers' output rows, so the levels are launched
 // deepest first, in stream order; the sub-mixers of the main mixer and its sources form the last level (summed by the mix kernels).
-struct Level { int off = 0, cnt = 0, n_staged = 0, n_staged_wide = 0, n_static_defer = 0; };
+struct Level { int off = 0, cnt = 0, n_staged = 0, n_staged_wide = 0, n_staged_adapt = 0, n_static_defer = 0; };
 
 struct pg_graph {
   int device = 0;
@@ -228,6 +228,7 @@ struct pg_graph {
   int staged_mode = 1;     // [Gain|Panning]* -> Reverb units: 1 = staged single launch (pg_stage_fused_kernel), 2 = one launch per stage, 0 = fused fast kernel
   int n_staged = 0;        // graph units eligible for the staged pipeline (levels 1 and 2)
   int n_staged_wide = 0;   // ... of level 2 (leading effects beyond Gain / Panning)
+  int n_staged_adapt = 0;  // ... of level 3 (a voice behind a ResampledSource or a host-fed one)
   int n_static_defer = 0;  // graph units that always run on the generic kernel
   double* d_stage = nullptr;  // [stage_rows][PG_STAGE_BUF_DOUBLES]
   DeviceTable<int4> d_slot_info;  // per launch slot: {unit slot, first voice, last effect, voices}

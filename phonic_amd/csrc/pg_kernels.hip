@@ -22,6 +22,7 @@ __global__ void pg_stage2_kernel(PgLaunch L);
 __global__ void pg_stage3_kernel(PgLaunch L);
 __global__ void pg_stage_fused_kernel(PgLaunch L);
 __global__ void pg_stage_fused_wide_kernel(PgLaunch L);
+__global__ void pg_stage_fused_adapt_kernel(PgLaunch L);
 
 
 // ---- mixer-graph sum -------------------------------------------------------------------------------------
@@ -172,10 +173,11 @@ static hipError_t pg_ensure_func_attributes() {
   for (const void* f : fns) if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)pg_stage_fused_adapt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) != hipSuccess) return e;
   if (dev >= 0 && dev < 64) done[dev] = true;
   return hipSuccess;
 }
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0, hipEvent_t ev1) {
   if (L.n_units <= 0) return hipSuccess;
   { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
   if (single_launch) {
@@ -183,6 +185,7 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
     // no marker packets in the stream, which cost ~7 us per round with hipEventRecord
     if (lean) hipExtLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, ev0, ev1, 0, L);
     if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, lean ? nullptr : ev0, lean ? nullptr : ev1, 0, L);
+    if (adapt) hipExtLaunchKernelGGL(pg_stage_fused_adapt_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, (lean || wide) ? nullptr : ev0, (lean || wide) ? nullptr : ev1, 0, L);
   } else {
     hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
     hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);

@@ -315,6 +315,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
     }
     // steady playback with ratio in [0.5, 1): every lane takes part in the exact time-parallel schedule
     bool par_ok = false;
+    bool par_short = false;   // eligible for the time-parallel schedule, but the piece is short: the one-lane walk below is the cheaper way
     int par_c = 0;
     float par_sp = 0.0f;
     unsigned long long win_x[4] = {0ull, 0ull, 0ull, 0ull};  // prefetched stereo frames of the input window
@@ -339,6 +340,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         // whose block is a latency chain, the branch-free walk of one lane below ~15 cycles per output frame — the walk wins below a few hundred
         // frames (stamps per callback size: profiles/r05_headline_stamps_by_callback_size.txt). The window stays requested either way.
         if (piece >= PG_SCHED_PAR_MIN) par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+        else par_short = true;
       } else {
         const float t23 = sp0 * (ratio < 2.0f ? 8388608.0f : 4194304.0f);
         if (ratio >= 1.0f && ratio < 4.0f && v->initialized[0] && num_in0 > 4ull * (uint64_t)piece + 4ull && sp0 >= 0.0f && sp0 < 1.0f && t23 == floorf(t23) && nt == 256) {
@@ -503,7 +505,10 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
       v->sub_pos[0] = sub_pos; v->sub_pos[1] = sub_pos;
       v->initialized[0] = initialized; v->initialized[1] = initialized;
       v->playback_pos = pp; v->repeat_count = repeat_count; v->pos_eof = eof;
-      v->sched_hit = par_ok ? 2 : (linear == 2 ? 1 : 0);
+      // 2 = the voice needs no published schedule: it took the time-parallel one, or walked a short piece by choice (a class representative
+      // that published for such voices replayed the NEXT piece into global memory from one lane — 22 K cycles at the end of ITS workgroup's
+      // 128-frame block, a quarter of the launch, for a schedule every voice of the class walks in 2 K: profiles/r05_headline_stamps_by_callback_size.txt)
+      v->sched_hit = (par_ok || (par_short && linear == 1)) ? 2 : (linear == 2 ? 1 : 0);
       S.ctl[0] = produced; S.ctl[1] = c;
     }
     __syncthreads();

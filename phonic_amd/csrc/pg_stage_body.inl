@@ -82,7 +82,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   // directly (no registers, nothing waits here) while the source stage runs, into slots behind the voice record (pg_stage_lds_bytes).
   PgFx* const lead = (PgFx*)((char*)lv + ((sizeof(PgVoice) + 15) & ~15ull));
   int lead0 = -1, lead1 = -1, lead2 = -1;
-  if (TAG == 3) {
+  if (TAG >= 3) {
     const int4 sl = L.slot_lead[slot];
     lead0 = __builtin_amdgcn_readfirstlane(sl.x); lead1 = __builtin_amdgcn_readfirstlane(sl.y); lead2 = __builtin_amdgcn_readfirstlane(sl.z);
 #pragma unroll
@@ -114,7 +114,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     ctl[5] = ok;
   }
   __syncthreads();
-  if (!ctl[5]) { if (TAG == 3) lds_dma_wait(); return -1; }   // (nothing may still be on its way into LDS when the workgroup moves on)
+  if (!ctl[5]) { if (TAG >= 3) lds_dma_wait(); return -1; }   // (nothing may still be on its way into LDS when the workgroup moves on)
   // the unit record is read once: every later `unit.x` would be another dependent trip to L2 on this workgroup's critical path
   const int n_voices = unit.n_voices, voice_off = unit.voice_off, n_fx = unit.n_fx, fx_off = unit.fx_off, effects_bypassed = unit.effects_bypassed;
   const int chunk_audible_input = unit.chunk_audible_input;
@@ -127,7 +127,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   int later = 0;
   for (int vi = 0; vi < n_voices; ++vi) {
     PgVoice* gv = &L.voices[vi == 0 ? si.y : L.voice_index[voice_off + vi]];
-    const int r = voice_process<false, 0>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word, pc.chunk_end, pc.first, pc.chunk_end);
+    const int r = voice_process<false, TAG == 4 ? 2 : 0>(gv, lv, sig, tmp, N, pos0, S, L.sched, L.sched_bank, vi == 0, voice_word, pc.chunk_end, pc.first, pc.chunk_end);   // (TAG 4, pg_stage_fused_adapt_kernel: also voices behind a ResampledSource and host-fed ones — the host sends their units there, level 3)
     audible_input |= (r & 1) != 0;
     later |= r & 2;
   }
@@ -135,7 +135,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
   if (pc.first) { audible_input = audible_input || later != 0; if (tid == 0) unit.chunk_audible_input = audible_input ? 1 : 0; }
   else audible_input = chunk_audible_input != 0;
   PG_STAMP(L.diag, 1);
-  if (TAG == 3) lds_dma_wait();   // the leading effects' state blocks (requested in front of the source stage: long there); the loop's first barrier publishes them
+  if (TAG >= 3) lds_dma_wait();   // the leading effects' state blocks (requested in front of the source stage: long there); the loop's first barrier publishes them
   int flags = audible_input ? PG_STAGE_AUDIBLE : 0;
   if (pc.first) flags |= PG_STAGE_FIRST;
   if (pc.last) flags |= PG_STAGE_LAST;
@@ -145,7 +145,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
     bool all_bypassed = true;
     for (int fi = 0; fi + 1 < n_fx; ++fi) {  // leading effects
       const int li = fi == 0 ? lead0 : fi == 1 ? lead1 : fi == 2 ? lead2 : -1;
-      const bool pre = TAG == 3 && li >= 0;
+      const bool pre = TAG >= 3 && li >= 0;
       PgFx& g1 = L.fx[pre ? li : L.fx_index[fx_off + fi]];
       PgFx* const cfx = pre ? lead + fi : lfx;
       __syncthreads();
@@ -153,7 +153,7 @@ __device__ __forceinline__ int stage1_run(const PgLaunch& L, int slot, const int
       __syncthreads();
       if (fi == 0) PG_STAMP(L.diag, 46);
       bool is_active;
-      constexpr int KM = TAG == 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
+      constexpr int KM = TAG >= 3 ? PG_KMASK_LEADING : PG_KMASK_GAINPAN;
       if (cfx->standalone) {
         __syncthreads();
         if (tid == 0) fx_call_begin(*cfx);
@@ -302,7 +302,8 @@ __device__ __forceinline__ void stage3_run(const PgLaunch& L, int slot, int flag
 #ifndef PG_STAGE_WAVES
 #define PG_STAGE_WAVES 4
 #endif
-// unit.staged: 0 no, 1 = leading effects are Gain / Panning only, 2 = any kind of PG_KMASK_LEADING. A launch renders the levels
+// unit.staged: 0 no, 1 = leading effects are Gain / Panning only, 2 = any kind of PG_KMASK_LEADING, 3 = as 2 with a voice behind a ResampledSource or a
+// host-fed one (the source stage with the adapters: a kernel of its own so that the other two keep their register allocation). A launch renders the levels
 // up to L.staged_on; LEVEL selects which of them this kernel takes.
 template <int LEVEL>
 __device__ __forceinline__ bool stage_unit_staged(const PgLaunch& L, int slot) {

@@ -61,7 +61,7 @@ def dynamic_lds():
     lib = _capi.load()
     lib.pg_debug_lds_bytes.restype = C.c_size_t
     lib.pg_debug_lds_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
-    return {"pg_stage_fused_kernel": lib.pg_debug_lds_bytes(0, 1024, 0), "pg_stage_fused_wide_kernel": lib.pg_debug_lds_bytes(2, 1024, 0), "pg_unit_kernel_fast_mid": lib.pg_debug_lds_bytes(1, 1024, (1 << 2) | (1 << 6)),
+    return {"pg_stage_fused_kernel": lib.pg_debug_lds_bytes(0, 1024, 0), "pg_stage_fused_wide_kernel": lib.pg_debug_lds_bytes(2, 1024, 0), "pg_stage_fused_adapt_kernel": lib.pg_debug_lds_bytes(2, 1024, 0), "pg_unit_kernel_fast_mid": lib.pg_debug_lds_bytes(1, 1024, (1 << 2) | (1 << 6)),
             # the lean fast kernel with Gain / Panning only, and the wide one with C-like chains that hold no Reverb / Compressor (Filter, Eq5,
             # Delay, Distortion): the arenas that let three workgroups share a CU
             "pg_unit_kernel_fast": lib.pg_debug_lds_bytes(1, 1024, (1 << 0) | (1 << 1)),
