@@ -6,17 +6,18 @@ from phonic_amd.graph import Graph
 from phonic_amd import _capi
 import workloads
 V=1024
-g=Graph(48000,2,1024,0)
+F=int(sys.argv[sys.argv.index('--frames')+1]) if '--frames' in sys.argv else 1024   # frames per call (= max_frames): a host's callback size
+g=Graph(48000,2,F,0)
 workloads.build_headline(g,V,0,V,2.0)
 lib=_capi.load()
 lib.pg_graph_diag.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.c_int]
 N=64+4*4096
 buf=(C.c_uint64*N)()
 lib.pg_graph_diag(g._h,buf,N)
-bus=torch.zeros(2048,device='cuda:0')
+bus=torch.zeros(2*F,device='cuda:0')
 pos=0
 for i in range(12):
-    g.write_device(bus.data_ptr(),2048,pos); pos+=1024
+    g.write_device(bus.data_ptr(),2*F,pos); pos+=F
 g.synchronize()
 lib.pg_graph_diag(g._h,buf,N)
 a=np.array(buf[64:64+4*V],dtype=np.int64).reshape(V,4)
@@ -39,5 +40,5 @@ print("end    p50 by XCD (slot % 8):", [round(float(np.median(us[slots%8==x,3]))
 print("stage2 p50 by dispatch quarter (slot // 256):", [round(float(np.median(d2[slots//256==q])),1) for q in range(4)])
 print("end    p50 by dispatch quarter:", [round(float(np.median(us[slots//256==q,3])),1) for q in range(4)])
 print("end    max by dispatch quarter:", [round(float(np.max(us[slots//256==q,3])),1) for q in range(4)])
-h,_=np.histogram(us[:,3],bins=np.arange(80,140,5)); print("ends histogram 80..135 step 5 us:", h.tolist())
+hi=float(us[:,3].max()); h,e=np.histogram(us[:,3],bins=12,range=(0.5*hi,hi)); print("ends histogram from %.0f us in steps of %.1f us:" % (0.5*hi,(hi-0.5*hi)/12), h.tolist())
 print("stage-1 end p50/p90/max: %.1f %.1f %.1f ; stage-2 end p50/p90/max: %.1f %.1f %.1f" % (tuple(np.percentile(us[:,1],[50,90,100]))+tuple(np.percentile(us[:,2],[50,90,100]))))
