@@ -1450,6 +1450,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   // has pieces of its own, and max_frames need not divide a chunk), and the offsets at which an event restarted the chunk grid:
   // process_bus_impl walks the same grid with the same cursor (round-4 advisor finding: the words used to sit at done / max_frames).
   uint64_t word_cursor = 0;
+  int* const aud_words = (g->defer_bus && g->d_audible_out) ? g->d_audible_out : g->d_audible;   // where the mixer sum leaves the `audible` words
   if (g->defer_bus) { g->defer_cuts.clear(); g->defer_pos = pos; g->defer_words = 0; }
   while (done < frames) {
     const uint64_t now = pos + done;
@@ -1542,7 +1543,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       {
         const Level& top = g->levels.back();
         HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_out + done * 2, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
-                                   g->d_audible + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride));
+                                   aud_words + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride));
       }
       if (overlap) { HIP_TRY_FAIL(hipEventRecord(g->ev_rows_free, stream)); g->rows_free_fresh = true; }
       if (!g->defer_bus && launch_bus(g, d_out + done * 2, sp, slot, stream)) return fail();
@@ -1610,11 +1611,11 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     const Level& top = g->levels.back();
     float* dst = d_out + done * 2;
     if (n_full > 0) HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
-                                               g->d_audible + slot0, stream, (int)n_full, chunk_stride));
+                                               aud_words + slot0, stream, (int)n_full, chunk_stride));
     if (n_pieces > n_full) {
       const LaunchSpan& r = spans[(size_t)n_full];
       HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)n_full * chunk_stride + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst + n_full * mf * 2, r.n * 2,
-                                 g->d_audible_tab + (size_t)n_full * g->unit_out_rows + top.off, g->unit_out_rows, g->d_audible + slot0 + (int)n_full, stream, 1, chunk_stride));
+                                 g->d_audible_tab + (size_t)n_full * g->unit_out_rows + top.off, g->unit_out_rows, aud_words + slot0 + (int)n_full, stream, 1, chunk_stride));
     }
     if (!g->defer_bus && !g->mixers[0].fx.empty()) {
       // the bus unit's commands of the chunk's first piece (main-mixer effect events) ride on its bus launch

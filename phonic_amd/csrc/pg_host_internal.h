@@ -313,6 +313,7 @@ struct pg_graph {
   float* d_partial = nullptr; size_t partial_rows = 0;
   float* d_bus = nullptr;               // [2*max_frames + 4]
   int* d_audible = nullptr;             // [audible_slots] audible_input of the bus chain, one word per block of a round / of a deferred-bus call
+  int* d_audible_out = nullptr;         // deferred-bus writes only (pg_sharded, direct delivery): the mixer sum leaves the call's words HERE instead of d_audible — the root's table, on the root's device
   int32_t* d_audible_tab = nullptr;     // [max_blocks][unit_out_rows] per-unit `audible` results, block by block (PgLaunch::audible_tab)
   bool status_pending = false;          // graph_enqueue_status ran, graph_collect_status has not
   float* h_pinned = nullptr;

@@ -128,6 +128,7 @@ struct ShardWorker {
   }
 };
 
+constexpr size_t PG_FLAG_BANKS = 4;
 struct pg_sharded_graph {
   std::vector<std::unique_ptr<ShardWorker>> workers;   // [shard - 1]; empty: the caller's thread issues every shard
   std::vector<pg_graph*> shards;
@@ -138,7 +139,16 @@ struct pg_sharded_graph {
   size_t flag_stride = PG_AUDIBLE_SLOTS; // words per shard in d_flags (= the shards' audible_slots)
   std::vector<float*> d_partial;         // per shard, on its device: [max_blocks * stride] partial master bus
   float* d_gather = nullptr;             // root device: the peers' partials [(n - 1)][max_blocks * stride]
-  int* d_flags = nullptr;                // root device: the shards' `audible` words [n][PG_AUDIBLE_SLOTS] of the segment being summed
+  int* d_flags = nullptr;                // root device: the shards' `audible` words [PG_FLAG_BANKS][n][PG_AUDIBLE_SLOTS]: one bank per segment in flight
+  // Direct delivery (peer-copy mode, round 5): a shard's mixer sum writes its partial bus and its words straight into the root's gather buffer
+  // and word table (peer access across devices) — no copy launches behind the render; the segments of consecutive calls land in a ring of
+  // regions / banks, and the shards' streams wait for the root's last sum only when a region comes round again.
+  bool direct = true;
+  uint64_t seg_counter = 0;
+  std::vector<hipEvent_t> summed_bank;   // [PG_FLAG_BANKS] root: the sum of the last segment that used bank b has read its region and its words
+  std::vector<char> bank_recorded;
+  hipEvent_t last_sum = nullptr;         // the sum event recorded last (behind every earlier one on the root's stream)
+  bool last_banked = false;
   float* d_bus = nullptr;                // root device: the summed bus of a write with a host buffer
   float* h_pinned = nullptr;
   std::vector<hipEvent_t> done;          // per shard: partial (and flags) arrived on the root
@@ -201,14 +211,32 @@ pg_sharded_graph* pg_sharded_create(uint32_t sample_rate, uint32_t channel_count
   s->d_partial.assign((size_t)n_devices, nullptr);
   (void)hipSetDevice(devices[0]);
   s->flag_stride = s->shards[0]->audible_slots;
-  const size_t flag_bytes = (size_t)n_devices * s->flag_stride * sizeof(int);
+  const size_t flag_bytes = PG_FLAG_BANKS * (size_t)n_devices * s->flag_stride * sizeof(int);
   if (hipEventCreateWithFlags(&s->summed, hipEventDisableTiming) != hipSuccess || pg_malloc((void**)&s->d_flags, flag_bytes) != hipSuccess || sharded_alloc_buffers(s.get())) {
     set_error(PG_ERR_DEVICE, "device allocation failed");
     pg_sharded_destroy(s.release());   // (shards, events and what was allocated so far)
     return nullptr;
   }
   (void)pg_memset(s->d_flags, 0, flag_bytes);
+  s->bank_recorded.assign(PG_FLAG_BANKS, 0);
+  for (size_t b = 0; b < PG_FLAG_BANKS; ++b) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error(PG_ERR_DEVICE, "hipEventCreate failed"); pg_sharded_destroy(s.release()); return nullptr; }
+    s->summed_bank.push_back(e);
+  }
   s->mixer_map.append(0);  // global mixer 0 = the main mixer (its chain lives on the root shard)
+  // direct delivery needs the root's memory mapped on every shard's device (same device: it is); PHONIC_SHARD_DIRECT=0 keeps the copies
+  { const char* d = getenv("PHONIC_SHARD_DIRECT"); if (d && d[0] == '0') s->direct = false; }
+  for (int i = 1; i < n_devices && s->direct; ++i) {
+    if (devices[i] == devices[0]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) != hipSuccess || !can) { s->direct = false; break; }
+    (void)hipSetDevice(devices[i]);
+    const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) s->direct = false;
+    (void)hipGetLastError();
+  }
+  (void)hipSetDevice(devices[0]);
   const char* e = getenv("PHONIC_SHARD_THREADS");
   if (n_devices > 1 && !(e && e[0] == '0')) {
     for (int i = 1; i < n_devices; ++i) {
@@ -232,6 +260,7 @@ void pg_sharded_destroy(pg_sharded_graph* s) {
   }
   (void)hipSetDevice(s->shards[0]->device);
   if (s->summed) (void)hipEventDestroy(s->summed);
+  for (hipEvent_t e : s->summed_bank) (void)hipEventDestroy(e);
   if (s->d_gather) (void)pg_free(s->d_gather);
   if (s->d_bus) (void)pg_free(s->d_bus);
   if (s->d_flags) (void)pg_free(s->d_flags);
@@ -433,28 +462,48 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stag
   const size_t fr = n_samples / 2, per_chunk = (PG_MAX_FRAMES + s->max_frames - 1) / s->max_frames;
   const int n_chunks = (int)std::min<size_t>((fr / PG_MAX_FRAMES) * per_chunk + (fr % PG_MAX_FRAMES + s->max_frames - 1) / s->max_frames, s->flag_stride);
   const bool rccl = s->reduce_mode == PG_REDUCE_RCCL;
+  const bool direct = s->direct && !rccl;
+  // Direct delivery in BANKS: a segment of at most stage_frames / PG_FLAG_BANKS frames (a real-time call) takes region b of the partial /
+  // gather buffers and bank b of the word table, b = its number mod PG_FLAG_BANKS, and the shards' streams wait — in front of their render:
+  // its sum kernel is what writes there — for the sum of the segment that used bank b LAST, PG_FLAG_BANKS segments ago: long done, so shards
+  // on different devices do not meet once per call. Longer segments (and the copy / RCCL modes) use the caller's region and bank 0 and wait
+  // for the last recorded sum, which is behind every earlier one.
+  const bool banked = direct && fr * PG_FLAG_BANKS <= s->stage_frames;
+  const size_t bank = banked ? (size_t)(s->seg_counter % PG_FLAG_BANKS) : 0;
+  if (banked) stage_off = bank * 2 * (s->stage_frames / PG_FLAG_BANKS);
+  int* const flags = s->d_flags + bank * n * s->flag_stride;
+  hipEvent_t wait_ev = nullptr;
+  if (banked && s->last_banked) wait_ev = s->bank_recorded[bank] ? s->summed_bank[bank] : nullptr;
+  else wait_ev = s->last_sum;
+  s->seg_counter += 1;
+  const bool wait_sum = wait_ev != nullptr;
   // every shard's launch sequence, its `audible` words and (peer-copy mode) the copies that carry both to the root: issued by the shard's own
   // thread when the handle has workers (shard 0 by the caller's), else one after the other here
-  auto issue = [s, stage_off, n_samples, pos, n_chunks, rccl, cap, root](size_t i) -> int {
+  auto issue = [s, stage_off, n_samples, pos, n_chunks, rccl, direct, wait_sum, wait_ev, flags, cap, root](size_t i) -> int {
     pg_graph* g = s->shards[i];
     HIP_TRY(hipSetDevice(g->device));
-    float* part = s->d_partial[i] + stage_off;
+    // direct delivery: a peer's partial bus goes straight to its slot of the root's gather ring, every shard's words to its row of the bank
+    float* part = (direct && i > 0) ? s->d_gather + (i - 1) * (cap + 4) + stage_off : s->d_partial[i] + stage_off;
+    g->d_audible_out = direct ? flags + i * s->flag_stride : nullptr;
+    int* const words = direct ? g->d_audible_out : g->d_audible;
+    if (direct && wait_sum) HIP_TRY(hipStreamWaitEvent(g->stream, wait_ev, 0));   // (in front of the render: its sum kernel is what writes there)
     const size_t w = graph_write_impl(g, part, n_samples, pos, g->stream, false);
     if (g->failed) return PG_ERR_DEVICE;
     if (w != 0 && w != n_samples) return set_error(PG_ERR_STATE, "shard %d rendered %zu of %zu samples of a span", (int)i, w, n_samples);
     if (w == 0) {  // nothing on this shard: a silent partial and silent flags (not the words an earlier call left there)
       HIP_TRY(hipMemsetAsync(part, 0, n_samples * sizeof(float), g->stream));
-      HIP_TRY(hipMemsetAsync(g->d_audible, 0, g->audible_slots * sizeof(int), g->stream));
+      HIP_TRY(hipMemsetAsync(words, 0, (direct ? (size_t)n_chunks : g->audible_slots) * sizeof(int), g->stream));
     }
     if (rccl) return PG_OK;
+    if (direct) { if (i > 0) HIP_TRY(hipEventRecord(s->done[i], g->stream)); return PG_OK; }
     // the root's sum of the previous segment (or call) must have read the gather buffers before this shard overwrites them
-    if (s->summed_recorded) HIP_TRY(hipStreamWaitEvent(g->stream, s->summed, 0));
+    if (wait_sum) HIP_TRY(hipStreamWaitEvent(g->stream, wait_ev, 0));
     if (i > 0) {
       HIP_TRY(hipMemcpyPeerAsync(s->d_gather + (i - 1) * (cap + 4) + stage_off, root->device, part, g->device, n_samples * sizeof(float), g->stream));
-      HIP_TRY(hipMemcpyPeerAsync(s->d_flags + i * s->flag_stride, root->device, g->d_audible, g->device, (size_t)n_chunks * sizeof(int), g->stream));
+      HIP_TRY(hipMemcpyPeerAsync(flags + i * s->flag_stride, root->device, g->d_audible, g->device, (size_t)n_chunks * sizeof(int), g->stream));
       HIP_TRY(hipEventRecord(s->done[i], g->stream));
     } else {
-      HIP_TRY(hipMemcpyAsync(s->d_flags, g->d_audible, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, g->stream));
+      HIP_TRY(hipMemcpyAsync(flags, g->d_audible, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, g->stream));
     }
     return PG_OK;
   };
@@ -484,9 +533,12 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stag
   } else {
     for (size_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root->stream, s->done[i], 0));
     hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_dst, s->d_partial[0] + stage_off,
-                       s->d_gather + stage_off, (int)n - 1, cap + 4, (int)n_samples, s->d_flags, (int)n, n_chunks, root->d_audible, (int)s->flag_stride);
+                       s->d_gather + stage_off, (int)n - 1, cap + 4, (int)n_samples, flags, (int)n, n_chunks, root->d_audible, (int)s->flag_stride);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->summed, root->stream));
+    hipEvent_t ev = banked ? s->summed_bank[bank] : s->summed;
+    HIP_TRY(hipEventRecord(ev, root->stream));
+    if (banked) s->bank_recorded[bank] = 1;
+    s->last_sum = ev; s->last_banked = banked;
     s->summed_recorded = true;
   }
   root->defer_pos = UINT64_MAX;   // (the handle cuts the spans itself: the root's bus chain takes no recorded cuts)
