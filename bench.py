@@ -692,6 +692,20 @@ def main():
         # the real-time call pattern — ONE write call per block, as the reference's WavOutput and cpal callbacks pull (src/output/wav.rs:210-250,
         # src/output/cpal.rs:700-723) — timed in the same run on the same graph: no super-block launches, every block its own launch sequence
         rt_legs, rt_dts = (legs_for(min_seconds / 2, 1) if (sb > 1 and world == 1 and with_realtime) else (None, None))
+        # ... and what a host that WAITS for every callback's samples sees (cpal's data callback, src/output/cpal.rs:700-723: the samples are handed
+        # over when the callback returns): one call, one stream synchronisation, per call — the call's latency, launch and wait included
+        rt_sync = None
+        if rt_legs is not None:
+            lat = []
+            for _ in range(max(50, min(400, args.steps * 4))):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                render(1, 1)
+                render_stream.synchronize()
+                lat.append(time.perf_counter() - t0)
+            ring.drain()
+            lat.sort()
+            rt_sync = {"calls": len(lat), "ms_per_call_p50": lat[len(lat) // 2] * 1e3, "ms_per_call_p10": lat[len(lat) // 10] * 1e3, "ms_per_call_p90": lat[(9 * len(lat)) // 10] * 1e3}
         if sampler:
             sampler.stop()
         last = ring.last_block()
@@ -700,7 +714,7 @@ def main():
         dev_err = g.device_errors()
         if dev_err:
             raise RuntimeError(f"kernel consistency flags raised: {dev_err}")
-        res = dict(name=name, scaling=scaling, v_per_gpu=v_per_gpu, total_voices=total_voices, M=M, dts=dts, legs=legs, rt_dts=rt_dts, rt_legs=rt_legs, peak=peak,
+        res = dict(name=name, scaling=scaling, v_per_gpu=v_per_gpu, total_voices=total_voices, M=M, dts=dts, legs=legs, rt_dts=rt_dts, rt_legs=rt_legs, rt_sync=rt_sync, peak=peak,
                    offline_calls=offline_calls, kernel=g.dominant_kernel(), bus_kernel=g.bus_kernel(), roofline_of=roofline_of)
         torch.cuda.set_stream(torch.cuda.default_stream(local_rank))
         del ring
@@ -845,6 +859,10 @@ def main():
                 "repeats": len(rt_dts),
                 "timed_seconds": sum(rt_dts),
             }
+            if R.get("rt_sync"):
+                # (the figures above come from calls issued back to back without a host wait; this one is the latency of ONE call for a host that
+                # waits for its samples: kernel + mixer sum + launch + the wait itself)
+                out["config"]["realtime"]["synchronous"] = dict(R["rt_sync"], what="one call + one stream synchronisation per callback: the call's latency as a waiting host sees it")
         if S5:
             d5 = S5["dts"][int(np.argsort(S5["dts"])[len(S5["dts"]) // 2])]
             _, (ms5, bpl5, ach5, _l5), _bt5 = S5["roofline_of"](S5["legs"])

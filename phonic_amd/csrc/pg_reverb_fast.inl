@@ -460,6 +460,9 @@ DEVO void rev_load_vtab(const PgReverb& r, const RevLds& m) {
   for (int k = 0; k < TRIPS; ++k) { const int i = tid + k * 256; if (i < 8 * REV_VTAB_N) { m.vtab[2 * i] = t0[k]; m.vtab[2 * i + 1] = t1[k]; } }
 }
 
+// (Measured and not kept, round 5: the table requested by LDS-DMA from stage 1 of the staged single launch, under the predelay — workgroup 0's
+// stage-2 set-up got 1.5 K cycles shorter, the launch 1.5-3 % LONGER at every callback size: 2080 dword-granular transfers per block and a
+// second spilled register. profiles/r05_ab_vtab_prefetch.txt)
 // block parameters (reverb.rs:429-440): delay lengths, blend/regen, the three low-pass coefficient sets; cached in the effect
 // state while room size and wet stay put. All lanes call; returns false for a degenerate geometry (serial path).
 DEVO bool rev_block_params(PgFx& fx, const RevLds& m, int* ctl, RevBlock& b) {
@@ -578,7 +581,9 @@ DEVO void rev_mid(PgReverb& r, int frames, const RevLds& m, const RevBlock& b, i
     PG_STAMP(diag, 12);
     PG_STAMP_VAL(diag, 20 + (done > 0 ? 1 : 0), done);
     PG_STAMP_VAL(diag, 22, b.t_mid);
+#ifndef PG_DIAG_SCHED   // (tools/diag_stamps.py: the schedule's own stamps use slots 30-35)
     for (int i = 0; i < 16; ++i) PG_STAMP_VAL(diag, 24 + i, ctl[8 + i]);
+#endif
     int T = frames - done;
     if ((uint32_t)T > b.t_mid) T = (int)b.t_mid;
     for (int i = 0; i < 16; ++i) T = T < ctl[8 + i] ? T : ctl[8 + i];

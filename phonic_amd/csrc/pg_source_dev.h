@@ -88,7 +88,7 @@ DEVO SchedTab schedtab_step(int u0) {
 }
 
 // All lanes of the workgroup (256). `scr`: >= 32 ints of LDS. Returns false when it gave up (caller replays serially).
-DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out) {
+DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float* of, int* scr, int& c_total, float& sp_out, unsigned long long* diag = nullptr) {
   const int tid = pg_tid(), lane = tid & 63, wave = tid >> 6;
   const int TWO24 = 1 << 24;
   const int R = (int)(ratio * 16777216.0f);  // exact: ratio in [0.5, 1)
@@ -97,10 +97,12 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
   int* s_res = scr + 4;       // c_total, sp_out bits
   SchedTab* s_wave = (SchedTab*)(scr + 8);  // [4 waves] wave totals
   if (tid == 0) { s_start[0] = 0; s_start[1] = (int)(sp0 * 16777216.0f); s_start[2] = 0; }
+  PG_STAMP(diag, 30);
   for (int iter = 0; iter < 16; ++iter) {
     __syncthreads();
     const int k0 = s_start[0], S = s_start[1], cc0 = s_start[2];
     if (tid == 0) *s_viol = 0x7fffffff;
+    if (iter == 0) PG_STAMP(diag, 31);
     // closed form of this lane's four elements: U0 = ((S + (j-1) R) mod 2^24) + R — the low 24 bits of a 32-bit product suffice
     int U0[4]; int side[4];
     SchedTab T[4];
@@ -114,6 +116,7 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
       T[e] = (j >= 1 && k < piece && side[e]) ? schedtab_step(u0) : 0ull;
     }
     SchedTab incl = schedtab_compose(schedtab_compose(T[0], T[1]), schedtab_compose(T[2], T[3]));
+    if (iter == 0) PG_STAMP(diag, 32);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const SchedTab b = __shfl_up(incl, off, 64);
@@ -122,6 +125,7 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
     if (lane == 63) s_wave[wave] = incl;
     SchedTab excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 0ull;
+    if (iter == 0) PG_STAMP(diag, 33);
     __syncthreads();
     int d = 0;  // d at the start element is 0; tables in front of it are identities
     for (int w = 0; w < wave; ++w) d += schedtab_at(s_wave[w], d);
@@ -146,10 +150,11 @@ DEVO bool sched_parallel(float ratio, float sp0, int piece, uint16_t* oc, float*
         if (k == piece - 1) { const int A1 = P + R; s_res[0] = cc; s_res[1] = (int)__float_as_uint((float)(A1 + sched_rho(A1)) * 5.9604644775390625e-08f); }
       }
     }
+    if (iter == 0) PG_STAMP(diag, 34);
     if (viol != 0x7fffffff) atomicMin(s_viol, viol);
     __syncthreads();
     const int kv = *s_viol;
-    if (kv == 0x7fffffff) { c_total = s_res[0]; sp_out = __uint_as_float((uint32_t)s_res[1]); return true; }
+    if (kv == 0x7fffffff) { PG_STAMP(diag, 35); c_total = s_res[0]; sp_out = __uint_as_float((uint32_t)s_res[1]); return true; }
     // restart from the exact state of the element in front of the first differing decision
     const int kr = kv - 1;
     __syncthreads();
@@ -270,6 +275,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
   uint64_t lr_start = 0, lr_end = v->n_samples;
   if (v->repeat > 0 && v->has_loop) { lr_start = v->loop_start * C; lr_end = v->loop_end * C; }
   int written = 0;  // frames
+  PG_STAMP(S.diag, 37);
   const bool bypass = fabsf(v->ratio - 1.0f) < 0.000001f;  // cubic.rs:53-58
   while (written < out_frames) {
     __syncthreads();
@@ -339,7 +345,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         // Short pieces (small real-time callbacks): the time-parallel schedule is a fixed ~12 K cycles of scan levels and barriers on a workgroup
         // whose block is a latency chain, the branch-free walk of one lane below ~15 cycles per output frame — the walk wins below a few hundred
         // frames (stamps per callback size: profiles/r05_headline_stamps_by_callback_size.txt). The window stays requested either way.
-        if (piece >= PG_SCHED_PAR_MIN) par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp);
+        if (piece >= PG_SCHED_PAR_MIN) par_ok = sched_parallel(ratio, sp0, piece, S.sched_c, S.sched_f, (int*)S.posmap, par_c, par_sp, S.diag);
         else par_short = true;
       } else {
         const float t23 = sp0 * (ratio < 2.0f ? 8388608.0f : 4194304.0f);
@@ -627,6 +633,7 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
   *post_on = 0;
   const int tid = pg_tid(), nt = blockDim.x;
   const int C = (int)v->channels;
+  PG_STAMP(S.diag, 36);
   // process_messages: Stop (preloaded.rs:195-208)
   if (tid == 0 && pending_stop && !v->finished) {
     if (v->fade_out_seconds > 0.0f) {  // VolumeFader::start_fade_out  fader.rs:67-91

@@ -31,6 +31,10 @@ for k in ([0,16,17,18,19,1,46,43,44,45,47,40,41,42,8,11,3,14,13,12,2,4,5,6,7,15]
     prev=t[k]
 
 laps=[buf[50+i] for i in range(5)]
+t30=[buf[i] for i in (16,36,37,30,31,32,33,34,35,17)]
+n30=['voice staged','file_source_write entered','src_write_buffer entered','sched_parallel entered','first barrier passed','closed forms + 3 composes','wave scan (6 shuffle + compose steps)','cross-wave prefix + walk + stores','last barrier passed','schedule done (lane-0 bookkeeping + barrier)']
+if t30[1]:
+    for i in range(1,len(t30)): print(f"schedule: {n30[i]:44s} +{t30[i]-t30[i-1]:8d} cyc")
 print('phase-3 laps of wave 0, summed over 20 blocks (cycles/block):', {n: laps[i]//20 for i,n in enumerate(['line taps issued','ap loads+sin+chain','interp+householder','barrier wait','stores'])})
 
 if '--staged' in sys.argv:
