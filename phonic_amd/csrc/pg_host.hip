@@ -1440,6 +1440,7 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
   if (g->topo_dirty) { g->rows_free_fresh = false; if (rebuild_topology(g, stream)) { g->failed = true; return 0; } }
   if (!g->stream_voices.empty()) { g->rows_free_fresh = false; if (flush_stream_feeds(g, stream)) { g->failed = true; return 0; } }
   if (g->overlap_stream != stream) { g->rows_free_fresh = false; g->overlap_stream = stream; }
+  g->write_done_attached = false;
   g->audible_valid = false;   // (a write that finds nothing to do launches nothing: the words an earlier call left are not this call's)
   if (graph_is_empty(g)) return 0;
   g->audible_valid = true;
@@ -1543,7 +1544,8 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       {
         const Level& top = g->levels.back();
         HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, d_out + done * 2, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
-                                   aud_words + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride));
+                                   aud_words + slot, stream, (int)k, (size_t)g->unit_out_rows * g->stride, (g->write_done_event && done + k * mf == frames) ? g->write_done_event : nullptr));
+        if (g->write_done_event && done + k * mf == frames) g->write_done_attached = true;
       }
       if (overlap) { HIP_TRY_FAIL(hipEventRecord(g->ev_rows_free, stream)); g->rows_free_fresh = true; }
       if (!g->defer_bus && launch_bus(g, d_out + done * 2, sp, slot, stream)) return fail();
@@ -1610,12 +1612,14 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
     const size_t chunk_stride = (size_t)g->unit_out_rows * g->stride;
     const Level& top = g->levels.back();
     float* dst = d_out + done * 2;
+    const bool last_chunk_of_call = g->write_done_event != nullptr && done + chunk_n == frames;   // (the event rides on the call's last sum launch)
+    if (last_chunk_of_call) g->write_done_attached = true;
     if (n_full > 0) HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst, (uint32_t)mf * 2, g->d_audible_tab + top.off, g->unit_out_rows,
-                                               aud_words + slot0, stream, (int)n_full, chunk_stride));
+                                               aud_words + slot0, stream, (int)n_full, chunk_stride, (last_chunk_of_call && n_pieces == n_full) ? g->write_done_event : nullptr));
     if (n_pieces > n_full) {
       const LaunchSpan& r = spans[(size_t)n_full];
       HIP_TRY_FAIL(pg_launch_mix(g->d_unit_out + (size_t)n_full * chunk_stride + (size_t)top.off * g->stride, g->stride, top.cnt, g->d_partial, dst + n_full * mf * 2, r.n * 2,
-                                 g->d_audible_tab + (size_t)n_full * g->unit_out_rows + top.off, g->unit_out_rows, aud_words + slot0 + (int)n_full, stream, 1, chunk_stride));
+                                 g->d_audible_tab + (size_t)n_full * g->unit_out_rows + top.off, g->unit_out_rows, aud_words + slot0 + (int)n_full, stream, 1, chunk_stride, last_chunk_of_call ? g->write_done_event : nullptr));
     }
     if (!g->defer_bus && !g->mixers[0].fx.empty()) {
       // the bus unit's commands of the chunk's first piece (main-mixer effect events) ride on its bus launch

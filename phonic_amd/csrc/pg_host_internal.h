@@ -3,6 +3,7 @@
 // multi-GPU handle). Nothing here is part of the ABI (include/phonic_gpu.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -33,7 +34,7 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0
 hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream);
 hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
-                         size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0);
+                         size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0, hipEvent_t done = nullptr);
 
 // ---- errors ---------------------------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);  // records the thread's last error message (pg_last_error_message) and returns `code`
@@ -313,6 +314,8 @@ struct pg_graph {
   float* d_partial = nullptr; size_t partial_rows = 0;
   float* d_bus = nullptr;               // [2*max_frames + 4]
   int* d_audible = nullptr;             // [audible_slots] audible_input of the bus chain, one word per block of a round / of a deferred-bus call
+  hipEvent_t write_done_event = nullptr; // set by the sharded handle around a write: rides on the call's LAST mixer-sum launch as its stop event (write_done_attached says it did)
+  bool write_done_attached = false;
   int* d_audible_out = nullptr;         // deferred-bus writes only (pg_sharded, direct delivery): the mixer sum leaves the call's words HERE instead of d_audible — the root's table, on the root's device
   int32_t* d_audible_tab = nullptr;     // [max_blocks][unit_out_rows] per-unit `audible` results, block by block (PgLaunch::audible_tab)
   bool status_pending = false;          // graph_enqueue_status ran, graph_collect_status has not

@@ -223,16 +223,20 @@ hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0
   else hipExtLaunchKernelGGL(pg_unit_kernel, dim3(L.n_units < 256 ? L.n_units : 256), dim3(256), (uint32_t)lds, stream, ev0, ev1, 0, L);  // (mode 3: n_units = stages of the bus pipeline)
   return hipGetLastError();
 }
+// `done`: an event that rides on the (last) launch as its stop event — the sharded handle's "this shard's partial bus has arrived" without a
+// separate hipEventRecord call per shard and write (three HIP calls per shard and call are what the handle's host time is made of).
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
-                         size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks, size_t chunk_stride) {
+                         size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks, size_t chunk_stride, hipEvent_t done) {
   int n_vec4 = (int)((n_samples + 3) / 4);
   int group = 16;
   int n_groups = (n_units + group - 1) / group;
   if (n_groups < 1) n_groups = 1;
   if (n_chunks < 1) n_chunks = 1;
   if (n_groups <= PG_MIX_MAX_GROUPS) {
-    hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, audible_tab,
-                       audible_stride, audible_out, chunk_stride);
+    if (done) hipExtLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, nullptr, done, 0, unit_out, stride, n_units, n_groups, bus,
+                                    (int)n_samples, audible_tab, audible_stride, audible_out, chunk_stride);
+    else hipLaunchKernelGGL(pg_mix_kernel, dim3((n_vec4 + PG_MIX_COLS - 1) / PG_MIX_COLS + 1, n_chunks), dim3(256), 0, stream, unit_out, stride, n_units, n_groups, bus, (int)n_samples, audible_tab,
+                            audible_stride, audible_out, chunk_stride);
     return hipGetLastError();
   }
   dim3 b(64), g1((n_vec4 + 63) / 64, n_groups), g2((n_vec4 + 63) / 64 + 1);  // +1: the flag-reduction block
@@ -240,6 +244,7 @@ hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, fl
     hipLaunchKernelGGL(pg_mix_kernel_1, g1, b, 0, stream, unit_out + (size_t)c * chunk_stride, stride, n_units, group, partial, n_vec4);
     hipLaunchKernelGGL(pg_mix_kernel_2, g2, b, 0, stream, partial, stride, n_groups, bus + (size_t)c * n_samples, (int)n_samples, audible_tab + (size_t)c * audible_stride, n_units, audible_out ? audible_out + c : nullptr);
   }
+  if (done) { hipError_t e = hipEventRecord(done, stream); if (e != hipSuccess) return e; }
   return hipGetLastError();
 }
 

@@ -487,7 +487,10 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stag
     g->d_audible_out = direct ? flags + i * s->flag_stride : nullptr;
     int* const words = direct ? g->d_audible_out : g->d_audible;
     if (direct && wait_sum) HIP_TRY(hipStreamWaitEvent(g->stream, wait_ev, 0));   // (in front of the render: its sum kernel is what writes there)
+    g->write_done_event = (direct && i > 0) ? s->done[i] : nullptr;   // "this shard's partial has arrived" rides on its last sum launch
     const size_t w = graph_write_impl(g, part, n_samples, pos, g->stream, false);
+    const bool done_rode = g->write_done_event != nullptr && g->write_done_attached;
+    g->write_done_event = nullptr;
     if (g->failed) return PG_ERR_DEVICE;
     if (w != 0 && w != n_samples) return set_error(PG_ERR_STATE, "shard %d rendered %zu of %zu samples of a span", (int)i, w, n_samples);
     if (w == 0) {  // nothing on this shard: a silent partial and silent flags (not the words an earlier call left there)
@@ -495,7 +498,7 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stag
       HIP_TRY(hipMemsetAsync(words, 0, (direct ? (size_t)n_chunks : g->audible_slots) * sizeof(int), g->stream));
     }
     if (rccl) return PG_OK;
-    if (direct) { if (i > 0) HIP_TRY(hipEventRecord(s->done[i], g->stream)); return PG_OK; }
+    if (direct) { if (i > 0 && (!done_rode || w == 0)) HIP_TRY(hipEventRecord(s->done[i], g->stream)); return PG_OK; }
     // the root's sum of the previous segment (or call) must have read the gather buffers before this shard overwrites them
     if (wait_sum) HIP_TRY(hipStreamWaitEvent(g->stream, wait_ev, 0));
     if (i > 0) {
@@ -532,11 +535,10 @@ static int sharded_render_segment(pg_sharded_graph* s, float* d_dst, size_t stag
     HIP_TRY(hipMemcpyAsync(root->d_audible, s->d_flags, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToDevice, root->stream));
   } else {
     for (size_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root->stream, s->done[i], 0));
-    hipLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, d_dst, s->d_partial[0] + stage_off,
-                       s->d_gather + stage_off, (int)n - 1, cap + 4, (int)n_samples, flags, (int)n, n_chunks, root->d_audible, (int)s->flag_stride);
+    hipEvent_t ev = banked ? s->summed_bank[bank] : s->summed;   // rides on the sum's launch as its stop event
+    hipExtLaunchKernelGGL(pg_shard_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, root->stream, nullptr, ev, 0, d_dst, s->d_partial[0] + stage_off,
+                          s->d_gather + stage_off, (int)n - 1, cap + 4, (int)n_samples, flags, (int)n, n_chunks, root->d_audible, (int)s->flag_stride);
     HIP_TRY(hipGetLastError());
-    hipEvent_t ev = banked ? s->summed_bank[bank] : s->summed;
-    HIP_TRY(hipEventRecord(ev, root->stream));
     if (banked) s->bank_recorded[bank] = 1;
     s->last_sum = ev; s->last_banked = banked;
     s->summed_recorded = true;

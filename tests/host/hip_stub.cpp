@@ -30,6 +30,8 @@ hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned int) { *d = h; re
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned int) { static unsigned n = 0; return (++n & 1) ? hipSuccess : hipErrorPeerAccessAlreadyEnabled; }   // (both answers the handle accepts)
 hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
   for (size_t r = 0; r < height; ++r) memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
   return hipSuccess;

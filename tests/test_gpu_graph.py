@@ -2078,3 +2078,98 @@ def test_device_failure_makes_the_graph_silent_for_good():
     lib.pg_debug_fail_launch_round(2)                         # the second shard's round of the next write
     assert s.write(out, N) == 0 and s.write(out, 2 * N) == 0
     lib.pg_debug_fail_launch_round(0)
+
+@pytest.mark.parametrize("feed", ["resampled", "host_fed"])
+def test_adapter_backed_reverb_units_render_on_their_staged_kernel(feed):
+    """Round 5: a reverb-terminated sub-mixer whose voice sits behind a ResampledSource
+    (src/source/resampled.rs:27-152) or is fed by the host (pg_graph_add_stream_voice) is a staged unit of level 3 — pg_stage_fused_adapt_kernel,
+    the wide staged kernel with the source adapters in its source stage — instead of a unit of the fused fast kernel at two workgroups per CU.
+    Ragged call sizes walk the 512-frame staging ranges through every alignment; single launches and super-block launches; a one-shot voice runs
+    out inside a call (the ResampledSource is asked again and plays its stale input range: PgVoice::zombie_end). Against the oracle, and the
+    staged render against the same graph with the staged kernels off."""
+    from phonic_amd.graph import Graph
+
+    sizes = [1024, 1024, 700, 1024, 324, 1024, 1024, 512, 2048, 1024, 3072, 1024]
+
+    def build(g):
+        fed = []
+        for i in range(6):
+            m = g.add_mixer()
+            if i % 2:
+                g.add_effect(m, _capi.FX_FILTER, params={"cuto": 2500.0 + 300.0 * i})
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            if feed == "resampled":
+                g.add_voice(m, workloads.tone_buffer(i, 44100, 0.25 if i == 4 else 0.12), 2, 44100, volume=0.25, panning=workloads.voice_pan(i), source_rate=32000,
+                            **({} if i == 4 else dict(has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER)))
+            else:
+                fed.append(g.add_stream_voice(m, 2, SR, 65536, volume=0.25, panning=workloads.voice_pan(i)))   # (the whole render fits: the host feeds ahead of every call)
+        return fed
+
+    def render(g, fed):
+        rng = np.random.default_rng(7)
+        chunks, pos = [], 0
+        for n in sizes:
+            for k, v in enumerate(fed):
+                g.feed_voice(v, (0.3 * rng.standard_normal((n, 2))).astype(np.float32))
+            o = np.zeros(2 * n, np.float32)
+            assert g.write(o, pos) == 2 * n
+            chunks.append(o)
+            pos += n
+        return np.concatenate(chunks)
+
+    gg = Graph(SR, 2, 1024, 0)
+    gg.set_max_blocks_per_launch(4)
+    a = render(gg, build(gg))
+    assert "pg_stage_fused_adapt_kernel" in gg.dominant_kernel(), gg.dominant_kernel()
+    assert np.abs(a).max() > 1e-3 and gg.device_errors() == 0
+    if feed == "resampled":   # (the oracle has no host-fed sources: those are held against the preloaded voice, tests/test_gpu_stream_voices.py)
+        go = oracle.OracleGraph(SR, 2, 1024)
+        b = render(go, build(go))
+        compare(a, b, 1e-5, 1e-4)
+    g0 = Graph(SR, 2, 1024, 0)
+    g0.set_staged(0)
+    f0 = build(g0)
+    c = render(g0, f0)
+    assert "pg_stage" not in g0.dominant_kernel()
+    compare(a, c, 1e-6, 1e-5)
+
+
+def test_sharded_direct_delivery_equals_the_copies(monkeypatch):
+    """Round 5: in the peer-copy mode a shard's mixer sum writes its partial bus and its `audible` words straight into the root's gather ring /
+    word banks (pg_sharded.hip: direct delivery; regions and banks rotate over four segments). Bit-identical to the copies (PHONIC_SHARD_DIRECT=0)
+    over one-block calls issued back to back without a host wait (the ring comes round many times), a long call (one region, the last sum awaited)
+    and voices that end under a bus Delay (silent shards: their words must be this call's)."""
+    import torch
+    from phonic_amd.graph import ShardedGraph
+
+    N = 1024
+
+    def build(g):
+        for i in range(7):
+            m = g.add_mixer()
+            g.add_effect(m, _capi.FX_REVERB, reverb_seeds=workloads.reverb_seeds(i))
+            g.add_voice(m, workloads.tone_buffer(i, 44100, 0.1 if i < 5 else 0.35), 2, 44100, volume=0.3, panning=workloads.voice_pan(i),
+                        **(dict(has_repeat=1, repeat=_capi.PG_REPEAT_FOREVER) if i < 5 else {}))
+        g.add_effect(0, _capi.FX_DELAY)
+
+    def run(direct):
+        monkeypatch.setenv("PHONIC_SHARD_DIRECT", "1" if direct else "0")
+        g = ShardedGraph([0, 0, 0], SR, 2, N)
+        g.set_max_blocks_per_launch(4)
+        build(g)
+        calls = 30
+        d = torch.zeros((calls + 1, 8 * N), dtype=torch.float32, device="cuda:0")
+        pos = 0
+        for c in range(calls):   # one-block calls in flight
+            assert g.write_device(d[c].data_ptr(), 2 * N, pos) == 2 * N
+            pos += N
+        assert g.write_device(d[calls].data_ptr(), 8 * N, pos) == 8 * N   # a four-block call behind them
+        g.synchronize()
+        assert g.device_errors() == 0
+        out = d.cpu().numpy().copy()
+        g.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 1e-2
