@@ -332,6 +332,8 @@ struct PgLaunch {
   int32_t* defer_count;   // fast kernels append the launch slots they defer: count of this round ...
   int32_t* defer_list;    // ... and the slots; the generic kernel (mode 2) walks the list
   int32_t* defer_reset;   // the other round's counter, zeroed by the generic kernel for the next round
+  int32_t* defer_state;   // pre-scanned rounds: how many of the deferred units were deferred for their STATE (static_defer / maybe_ramping) rather than for a command
+  int32_t* defer_state_reset;   // ... in this round (the scan kernel counts, the generic kernel reports it: host_feedback[3]); the other round's word, zeroed like defer_reset
   unsigned long long* host_feedback;  // pinned host word: the generic kernel reports (round << 32 | units it found deferred)
   uint32_t round;         // launch counter of this round
   int32_t staged_on;      // units whose `staged` level is 1 .. staged_on are rendered by the stage kernels of this round, the fused fast kernel skips them

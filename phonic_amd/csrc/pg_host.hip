@@ -257,8 +257,8 @@ static int graph_reserve(pg_graph* g) {
     if (g->d_defer) (void)pg_free(g->d_defer);
     g->d_defer = nullptr;
     const size_t nr = std::max(rows, g->defer_rows * 2);
-    HIP_TRY(pg_malloc((void**)&g->d_defer, (2 + nr) * sizeof(int32_t)));
-    HIP_TRY(pg_memset(g->d_defer, 0, (2 + nr) * sizeof(int32_t)));
+    HIP_TRY(pg_malloc((void**)&g->d_defer, (4 + nr) * sizeof(int32_t)));
+    HIP_TRY(pg_memset(g->d_defer, 0, (4 + nr) * sizeof(int32_t)));
     g->defer_rows = nr;
   }
   bool any_reverb = false;
@@ -319,6 +319,7 @@ pg_graph* pg_graph_create(uint32_t sample_rate, uint32_t channel_count, size_t m
   if (pg_malloc((void**)&g->d_error, 32) == hipSuccess) (void)pg_memset(g->d_error, 0, 32); else g->d_error = nullptr;   // [0] flags, [2..3] u64 deferred unit-blocks, [4..5] u64 generic launches with work
   if (pg_host_malloc((void**)&g->h_feedback, 64, hipHostMallocMapped) == hipSuccess) {
     g->h_feedback[0] = ~0ull;  // nothing reported yet
+    g->h_feedback[3] = ~0ull;
     g->h_feedback[1] = 0; g->h_feedback[2] = 0;  // [1] status word (graph_enqueue_status), [2] consistency flags the kernels mirror here
     if (hipHostGetDevicePointer((void**)&g->d_feedback, g->h_feedback, 0) != hipSuccess) g->d_feedback = nullptr;
   }
@@ -1083,7 +1084,8 @@ double pg_graph_kernel_ms(pg_graph* g, int reset, uint64_t* launches) {
 // nothing deferred, and units leave the steady state only through those host-visible events.
 static bool graph_steady(const pg_graph* g) {
   if (!(g->fast && g->levels.size() == 1 && g->n_static_defer == 0 && g->d_feedback)) return false;
-  const unsigned long long fb = *(volatile unsigned long long*)g->h_feedback;
+  // word 3: (round << 32 | units that round deferred for their STATE); units deferred for a command alone do not count — see cmd_may_ramp
+  const unsigned long long fb = *(volatile unsigned long long*)(g->h_feedback + 3);
   return fb != ~0ull && (uint32_t)fb == 0u && (int32_t)((uint32_t)(fb >> 32) - (uint32_t)g->last_change_round) >= 0;
 }
 // A super-block launch sequence renders several blocks of max_frames per workgroup: only in steady state (nobody would render the
@@ -1184,7 +1186,14 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
   L.unit_out = g->d_unit_out + (size_t)sp.row_block * (size_t)L.chunk_stride + (size_t)lv.off * g->stride;
   L.audible_tab = g->d_audible_tab + (size_t)sp.row_block * g->unit_out_rows + lv.off; L.audible_stride = g->unit_out_rows;
   L.slot_info = g->d_slot_info.d + lv.off; L.slot_fx = g->d_slot_fx.d + lv.off; L.slot_lead = g->d_slot_lead.d + lv.off;
-  if (g->d_defer) { L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 2; }
+  if (g->d_defer) {
+    L.defer_count = g->d_defer + (g->defer_phase & 1); L.defer_reset = g->d_defer + ((g->defer_phase & 1) ^ 1); L.defer_list = g->d_defer + 4;
+    L.defer_state = g->d_defer + 2 + (g->defer_phase & 1); L.defer_state_reset = g->d_defer + 2 + ((g->defer_phase & 1) ^ 1);
+    // (a round that skips the generic launch right behind one that had it: that round's counts would still be in its words when their phase
+    // comes round again — a command round may be followed by a steady one at once since voice commands no longer end the steady state)
+    if (sp.generic_idle && g->defer_dirty) { HIP_TRY(hipMemsetAsync(g->d_defer, 0, 4 * sizeof(int32_t), stream)); g->defer_dirty = false; }
+    if (!sp.generic_idle) g->defer_dirty = true;
+  }
   g->defer_phase++;
   // The event pair times the launch(es) that do the bulk of this graph's work: the fast / staged kernels, or — when most units
   // hold an effect without a time-parallel path — the generic kernel. When that is a single launch the events ride on the
@@ -1249,7 +1258,7 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     }
   } else {
     L.mode = 0;
-    if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 2 * sizeof(int32_t), stream));  // no deferral protocol this round: keep both counters clean
+    if (g->d_defer) HIP_TRY(hipMemsetAsync(g->d_defer, 0, 4 * sizeof(int32_t), stream));  // no deferral protocol this round: keep the counters clean
     HIP_TRY(pg_launch_units(L, stream, e0, e1));
   }
   if (timed_here) { g->ev_blocks[g->ev_used] = (uint32_t)sp.n_chunks; g->ev_used++; }
@@ -1590,7 +1599,16 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       if (!cmds.empty()) {
         if (stage_commands(g, cmds, stream, &sp.d_cmds)) return fail();
         sp.n_cmds = (int)cmds.size();
-        g->last_change_round = sp.round;
+        // Which commands can leave the steady state behind them? A parameter command may start a smoother of an effect (the device knows how
+        // long: the next rounds' scans tell), a speed command a glide, markers belong to split chunks. Source volume / panning / stop / seek
+        // change nothing the time-parallel kernels do not render (AmplifiedSource / PannedSource smoothers, the fader, a new position): a unit
+        // deferred for those alone is back on its kernel in the next block, so the host need not wait for the device to say so — offline
+        // calls keep their super-block launches between such commands (notes that stop and start: bench.py --workload dyn --churn).
+        bool may_ramp = false;
+        for (const PgCmd& c : cmds) may_ramp |= !(c.type == CMD_VOICE_VOLUME || c.type == CMD_VOICE_PAN || c.type == CMD_VOICE_STOP || c.type == CMD_VOICE_SEEK);
+        // (the round AFTER this one is the first whose scan sees what the commands left behind: this round's own count of state-deferred units
+        // was taken in front of them)
+        if (may_ramp) g->last_change_round = sp.round + 1;
       }
       // Steady state: the generic kernel of an earlier round (not older than the last topology change / command / mode switch) found
       // nothing deferred, and units leave the steady state only through those host-visible events -> the generic launch is skipped.

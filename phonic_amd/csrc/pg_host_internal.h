@@ -239,7 +239,8 @@ struct pg_graph {
   DeviceTable<PgUnit> d_topo;     // topology fields of every unit, patched into d_units by pg_patch_units_kernel
   std::vector<Level> levels;    // deepest first
   uint64_t defer_phase = 0;     // one deferral hand-shake per level launch (two counters, alternating)
-  int32_t* d_defer = nullptr;  // [2 counters][defer_rows slots]: compact list of the units the fast kernels deferred
+  int32_t* d_defer = nullptr;  // [2 counters][2 state counters][defer_rows slots]: compact list of the units the fast kernels deferred
+  bool defer_dirty = false;    // a round with a generic launch left a count in its counter: the first round that skips the launch clears all four words
   size_t defer_rows = 0;
   size_t stage_rows = 0;
   bool defer_bus = false;

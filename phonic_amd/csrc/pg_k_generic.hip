@@ -127,8 +127,16 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
     const int n = *L.defer_count;
     if (blockIdx.x == 0 && pg_tid() == 0) {
       *L.defer_reset = 0;
-      // tell the host how many units this round deferred: after a round with none (and no change since) it skips this launch
-      if (L.host_feedback) { *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n; __threadfence_system(); }
+      // tell the host how many units this round deferred: after a round with none (and no change since) it skips this launch. Word 3: how many
+      // of them were deferred for their STATE (a pre-scanned round counts those apart; else all of them): a round whose units were deferred
+      // for commands alone — source volume / panning / stop / seek, which leave no smoother of an effect moving — leaves the graph in steady state
+      const int n_state = (L.pad_chunks && L.defer_state) ? *L.defer_state : n;
+      if (L.defer_state_reset) *L.defer_state_reset = 0;
+      if (L.host_feedback) {
+        *(volatile unsigned long long*)(L.host_feedback + 3) = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n_state;
+        *(volatile unsigned long long*)L.host_feedback = ((unsigned long long)L.round << 32) | (unsigned long long)(uint32_t)n;
+        __threadfence_system();
+      }
       // statistics (pg_graph_dynamic_stats): unit-blocks that left the fast kernels, and the generic launches that found any
       if (L.error_word && n > 0) { atomicAdd((unsigned long long*)(L.error_word + 2), (unsigned long long)n); atomicAdd((unsigned long long*)(L.error_word + 4), 1ull); }
     }

@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(256) pg_defer_scan_kernel(PgLaunch L) {
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   PgUnit& unit = L.units[u];
   int ok = !(unit.static_defer || unit.maybe_ramping);
+  if (!ok && L.defer_state) atomicAdd(L.defer_state, 1);   // deferred for its state: what decides whether the graph is back in steady state (graph_steady)
   for (int ci = 0; ok && ci < L.n_cmds; ++ci) if (L.cmds[ci].unit == u) ok = 0;
   unit.deferred = ok ? 0 : 1;
   if (!ok) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
