@@ -2173,3 +2173,67 @@ def test_sharded_direct_delivery_equals_the_copies(monkeypatch):
     a, b = run(True), run(False)
     assert np.array_equal(a, b)
     assert np.abs(a).max() > 1e-2
+
+
+def test_voice_commands_do_not_end_the_steady_state_of_offline_calls():
+    """Round 5 (pg_host.hip: cmd may_ramp / feedback word 3): source volume / panning / stop commands leave no smoother of an EFFECT moving, so a
+    unit deferred for those alone is back on its time-parallel kernel in the next block and the host keeps rendering super-block launches between
+    such commands WITHOUT waiting for the device to report the steady state — here: eight-block calls enqueued back to back on a caller's stream
+    (no host wait: the feedback of a commanded round has not arrived when the next span is planned), notes that stop and restart at random sample
+    times plus volume / panning commands. Bit for bit the render of the same calls piece by piece (max_blocks 1), within tolerance of the oracle,
+    no consistency flag, and most blocks in launches of several blocks; a reverb `wet` command in the middle (it CAN start a ramp) must take the
+    graph off the super-block path until the device says the ramp has ended."""
+    import torch
+    from phonic_amd.graph import Graph
+
+    N, per_call, calls = 1024, 8, 12
+    stream = torch.cuda.Stream()
+
+    def run(g, async_calls):
+        plan = workloads.build_dyn(g, 24, calls * per_call * N / SR, churn_pct_per_s=12.0, silent_pct=0.0, first_frame=2 * per_call * N, seed=5, sample_rate=SR)
+        drv = workloads.DynDriver(plan, 5.0, 11, sample_rate=SR, kinds=(1, 2))
+        d = torch.zeros((calls, per_call * 2 * N), dtype=torch.float32, device="cuda:0") if async_calls else None
+        o = np.zeros((calls, per_call * 2 * N), np.float32)
+        n_cmds = 0
+        for c in range(calls):
+            pos = c * per_call * N
+            if c >= 2:
+                n_cmds += drv.schedule(g, pos, pos + per_call * N)
+            if c == calls - 2:
+                g.schedule_param(plan["reverbs"][3], "wet ", 0.45, pos + 3 * N + 17)
+            if async_calls:
+                if c == calls - 2:   # what the calls with voice commands alone took: most of their blocks rode in launches of several blocks
+                    torch.cuda.synchronize()
+                    _, launches, blocks = g.kernel_stats(reset=True)
+                    stats.append((launches, blocks))
+                assert g.write_device(d[c].data_ptr(), per_call * 2 * N, pos, stream.cuda_stream) == per_call * 2 * N
+                if c < 2:
+                    torch.cuda.synchronize()   # (the graph has played for a while: the device has reported its steady state once)
+                    g.kernel_stats(reset=True)
+            else:
+                assert g.write(o[c], pos) == o[c].size
+        if async_calls:
+            torch.cuda.synchronize()
+            o = d.cpu().numpy()
+        assert n_cmds >= 8 and len(plan["restarts"]) >= 3
+        return o.reshape(-1)
+
+    stats = []
+    ga = Graph(SR, 2, N, 0)
+    ga.set_max_blocks_per_launch(per_call)
+    ga.set_timing_period(1)
+    a = run(ga, True)
+    assert ga.device_errors() == 0
+    launches, blocks = stats[0]
+    # (a launch of several blocks covers whole chunks of four blocks or runs to the call's end, and a block with a command goes piece by piece with
+    # the rest of its chunk: ~1.6 blocks per launch at one command every few blocks; it was 1.0 from the first command on while any command ended
+    # the steady state — the host plans these calls before the device has rendered the first of them)
+    assert blocks == (calls - 4) * per_call and blocks / max(1, launches) > 1.3, (launches, blocks)
+    _, launches, blocks = ga.kernel_stats()
+    assert blocks == 2 * per_call and launches >= per_call + 4, (launches, blocks)   # behind the `wet` command: block by block (the host has no word from the device yet)
+    g1 = Graph(SR, 2, N, 0)
+    b = run(g1, False)
+    assert np.array_equal(a, b), f"{int(np.count_nonzero(a != b))} samples differ from the piece-by-piece render"
+    c = run(oracle.OracleGraph(SR, 2, N), False)
+    compare(a, c)
+    assert np.abs(a).max() > 1e-2
