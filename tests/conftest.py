@@ -43,6 +43,15 @@ def pytest_collection_modifyitems(session, config, items):
             _FUZZ["by_family"].setdefault(_fam(it.nodeid), {"requested": 0, "passed": 0, "failed": 0, "skipped_by_classifier": 0, "skipped_other": 0})["requested"] += 1
 
 
+def pytest_deselected(items):   # (-k / -m deselect behind the collection hook above: those cases were never requested)
+    for it in items:
+        if "test_gpu_fuzz.py" in it.nodeid:
+            f = _FUZZ["by_family"].get(_fam(it.nodeid))
+            if f and f["requested"] > 0:
+                f["requested"] -= 1
+                _FUZZ["collected"] -= 1
+
+
 def pytest_sessionstart(session):
     import signal
     import time
