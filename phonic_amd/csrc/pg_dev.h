@@ -301,6 +301,11 @@ struct PgCmd {
   uint64_t value64;
 };
 
+// A round's command list as a kernel argument of the decision-scan kernel (rounds of at most PG_CMD_PACK commands: nearly all of them): the scan
+// reads its commands from here and leaves them in the device ring for the kernels behind it — no copy kernel in front of the round (5-6 us on
+// the stream in a kernel trace of the dynamic rounds).
+#define PG_CMD_PACK 16
+struct PgCmdPack { PgCmd c[PG_CMD_PACK]; int32_t n; int32_t pad[3]; };
 #define PG_BUS_PIPELINE_MAX 16  // effects of a bus chain the pipelined launch takes (one workgroup each); longer chains stay one workgroup
 struct PgLaunch {
   PgUnit* units;

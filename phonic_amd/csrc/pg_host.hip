@@ -1098,7 +1098,9 @@ static bool graph_super_ok(const pg_graph* g) {
 }
 
 // The command list of one round -> a fresh region of the device ring (asynchronous copy from the pinned ring on the round's stream).
-static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream_t stream, const PgCmd** d_out) {
+// `h_out` (optional): the caller takes the list to the device itself — as an argument of the round's decision-scan kernel, which leaves it in the
+// region reserved here (launch_level) — and gets the pinned copy; no copy is enqueued then.
+static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream_t stream, const PgCmd** d_out, const PgCmd** h_out = nullptr) {
   const size_t n = cmds.size();
   if (n > PG_CMD_RING) {
     // More commands in ONE launch round than the ring holds (tens of thousands of events between two samples): the degenerate case
@@ -1118,7 +1120,8 @@ static int stage_commands(pg_graph* g, const std::vector<PgCmd>& cmds, hipStream
     g->cmds_since_sync = 0; skipped = 0;
   }
   memcpy(g->h_cmd_ring + g->cmd_head, cmds.data(), n * sizeof(PgCmd));
-  HIP_TRY(hipMemcpyAsync(g->d_cmd_ring + g->cmd_head, g->h_cmd_ring + g->cmd_head, n * sizeof(PgCmd), hipMemcpyHostToDevice, stream));
+  if (h_out) *h_out = g->h_cmd_ring + g->cmd_head;
+  else HIP_TRY(hipMemcpyAsync(g->d_cmd_ring + g->cmd_head, g->h_cmd_ring + g->cmd_head, n * sizeof(PgCmd), hipMemcpyHostToDevice, stream));
   *d_out = g->d_cmd_ring + g->cmd_head;
   g->cmd_head += n;
   g->cmds_since_sync += skipped + n;
@@ -1152,6 +1155,7 @@ struct LaunchSpan {
   uint64_t round = 0;
   bool timed = false;        // a hipEvent pair is reserved for this span (g->ev_used names it)
   bool generic_idle = false;
+  const PgCmd* h_cmds = nullptr;   // the round's commands travel as an argument of its decision-scan kernel (no copy was enqueued): the pinned list
 };
 static void fill_launch(pg_graph* g, const LaunchSpan& sp, PgLaunch& L) {
   memset(&L, 0, sizeof L);
@@ -1171,6 +1175,13 @@ static void fill_launch(pg_graph* g, const LaunchSpan& sp, PgLaunch& L) {
   // (a super-block runs without the resampler schedule cache: its banks alternate per launch, not per block; voices of a cached
   // class replay their schedule serially, and the cache re-validates itself by key when single-block rounds resume)
   L.sched = sp.n_chunks > 1 ? nullptr : g->d_sched.d; L.sched_bank = (int)(sp.round & 1);
+}
+// Does this round of level li run the generic kernel BESIDE the fast kernels behind a decision-scan kernel (launch_level)?
+static bool level_concurrent(const pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_t stream) {
+  const Level& lv = g->levels[li];
+  const bool time_generic = g->fast && lv.n_static_defer * 2 > lv.cnt;
+  return g->fast && lv.cnt > 0 && g->concurrent_generic && !sp.generic_idle && !time_generic && g->levels.size() == 1 && sp.n_chunks == 1 && g->staged_mode != 2 &&
+         g->d_defer && g->unit_stream && stream != g->unit_stream;
 }
 static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_t stream) {
   if (li == 0 && g_fail_round_countdown.load(std::memory_order_relaxed) > 0 && g_fail_round_countdown.fetch_sub(1) == 1)   // (once per launch round)
@@ -1222,12 +1233,10 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     // share a CU with a generic workgroup one or two at a time instead of four); the sum waits for both. (A first version had it the other way
     // round: the fast kernels, 1024 workgroups that fill every CU, won the race for the machine and the generic kernel ran in their tail:
     // no gain.) One level, single blocks, single-launch staged mode.
-    const bool concurrent = g->concurrent_generic && !sp.generic_idle && !time_generic && g->levels.size() == 1 && sp.n_chunks == 1 && g->staged_mode != 2 &&
-                            L.defer_list && g->unit_stream && stream != g->unit_stream;
+    const bool concurrent = level_concurrent(g, li, sp, stream);
     hipStream_t fs = stream;   // the stream of the fast kernels
     if (concurrent) {
-      HIP_TRY(pg_launch_defer_scan(L, stream));
-      HIP_TRY(hipEventRecord(g->ev_scan_done, stream));
+      HIP_TRY(pg_launch_defer_scan(L, stream, g->ev_scan_done, sp.h_cmds));   // (the event rides on the scan's dispatch: no marker packet in front of the generic kernel; h_cmds: the round's commands as its argument)
       HIP_TRY(hipStreamWaitEvent(g->unit_stream, g->ev_scan_done, 0));
       PgLaunch G = L;
       G.mode = 2; G.pad_chunks = 1;   // (a pre-scanned round: the fast kernels beside it read PgUnit::deferred — it stays as the scan left it)
@@ -1242,14 +1251,21 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
     L.stage_buf = nullptr; L.staged_on = 0;
     if (staged) {
       L.stage_buf = g->d_stage + (size_t)lv.off * PG_STAGE_BUF_DOUBLES; L.staged_on = g->staged_mode == 1 ? 3 : 1;
-      HIP_TRY(pg_launch_stages(L, fs, g->staged_mode == 1 ? 1 : 0, lean, wide, adapt, ride ? e0 : nullptr, ride ? e1 : nullptr));
+      // (concurrent: "the fast kernels are done" rides on their last launch as its stop event when no timing event does)
+      HIP_TRY(pg_launch_stages(L, fs, g->staged_mode == 1 ? 1 : 0, lean, wide, adapt, ride ? e0 : nullptr, ride ? e1 : nullptr,
+                               (concurrent && !fused && !ride && !bracket && g->staged_mode == 1) ? g->ev_generic_done : nullptr));
     }
-    if (fused) HIP_TRY(pg_launch_units(L, fs, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : nullptr));
+    const bool tail_on_fused = concurrent && fused && !bracket && !(ride && !staged);
+    if (fused) HIP_TRY(pg_launch_units(L, fs, ride && !staged ? e0 : nullptr, ride && !staged ? e1 : (tail_on_fused ? g->ev_generic_done : nullptr)));
     if (bracket) HIP_TRY(hipEventRecord(e1, fs));
     L.mode = 2;  // ... to the generic kernel, which walks the list of deferred units (skipped while the host knows the list is empty)
     if (concurrent) {   // (the sum behind this level needs both)
-      HIP_TRY(hipEventRecord(g->ev_generic_done, fs));
-      HIP_TRY(hipStreamWaitEvent(stream, g->ev_generic_done, 0));
+      // what the write's stream waits for: the timing stop event when one was taken (it sits behind the fast kernels), else the event that rode
+      // on their last launch; a marker packet only where neither exists (the per-stage launch mode never gets here)
+      hipEvent_t fast_done = (ride || bracket) ? e1 : g->ev_generic_done;
+      const bool rode = ride || bracket || tail_on_fused || (staged && !fused && g->staged_mode == 1);
+      if (!rode) HIP_TRY(hipEventRecord(g->ev_generic_done, fs));
+      HIP_TRY(hipStreamWaitEvent(stream, fast_done, 0));
     } else if (!sp.generic_idle) {
       hipEvent_t g0 = timed_here && time_generic ? e0 : nullptr, g1 = timed_here && time_generic ? e1 : nullptr;
       if (timed_here && !time_generic && g->ev_gen_used < g->ev_gen_pool.size()) { g0 = g->ev_gen_pool[g->ev_gen_used].first; g1 = g->ev_gen_pool[g->ev_gen_used].second; g->ev_gen_used++; }   // (rides on the dispatch)
@@ -1597,8 +1613,10 @@ size_t graph_write_impl(pg_graph* g, float* d_out, size_t n_samples, uint64_t po
       if (p == 0) cmds = head;
       collect_piece_commands(g, cmds, sp.t0, sp.n, now, now + chunk_n);
       if (!cmds.empty()) {
-        if (stage_commands(g, cmds, stream, &sp.d_cmds)) return fail();
+        // (a round that will run its decision-scan kernel takes a short list there as the kernel's argument: no copy kernel on the stream)
         sp.n_cmds = (int)cmds.size();
+        const bool by_scan = cmds.size() <= PG_CMD_PACK && level_concurrent(g, 0, sp, stream);
+        if (stage_commands(g, cmds, stream, &sp.d_cmds, by_scan ? &sp.h_cmds : nullptr)) return fail();
         // Which commands can leave the steady state behind them? A parameter command may start a smoother of an effect (the device knows how
         // long: the next rounds' scans tell), a speed command a glide, markers belong to split chunks. Source volume / panning / stop / seek
         // change nothing the time-parallel kernels do not render (AmplifiedSource / PannedSource smoothers, the fader, a new position): a unit

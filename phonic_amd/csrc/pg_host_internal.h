@@ -31,8 +31,8 @@ size_t pg_unit_lds_bytes(uint32_t n_frames, size_t scratch_bytes = 0);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames);
 size_t pg_stage_lds_bytes(int stage, uint32_t n_frames, bool wide);  // wide: the staged kernel that renders effects in front of the reverb (their state slots)
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream);
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream, hipEvent_t done = nullptr, const PgCmd* h_cmds = nullptr);
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, hipEvent_t tail_done = nullptr);
 hipError_t pg_launch_mix(const float* unit_out, uint32_t stride, int n_units, float* partial, float* bus, uint32_t n_samples, const int32_t* audible_tab,
                          size_t audible_stride, int* audible_out, hipStream_t stream, int n_chunks = 1, size_t chunk_stride = 0, hipEvent_t done = nullptr);
 

@@ -177,15 +177,19 @@ static hipError_t pg_ensure_func_attributes() {
   if (dev >= 0 && dev < 64) done[dev] = true;
   return hipSuccess;
 }
-hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0, hipEvent_t ev1) {
+// `tail_done`: an event that rides on the LAST launch as its stop event when that launch carries none of its own (the concurrent path's "fast
+// kernels done" without a marker packet behind them; single_launch only).
+hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_launch, int lean, int wide, int adapt, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t tail_done) {
   if (L.n_units <= 0) return hipSuccess;
   { hipError_t e = pg_ensure_func_attributes(); if (e != hipSuccess) return e; }
   if (single_launch) {
     // ev0/ev1 (only passed when exactly one of the two launches happens): start / stop timestamps taken from the dispatch itself —
     // no marker packets in the stream, which cost ~7 us per round with hipEventRecord
-    if (lean) hipExtLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, ev0, ev1, 0, L);
-    if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, lean ? nullptr : ev0, lean ? nullptr : ev1, 0, L);
-    if (adapt) hipExtLaunchKernelGGL(pg_stage_fused_adapt_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, (lean || wide) ? nullptr : ev0, (lean || wide) ? nullptr : ev1, 0, L);
+    const int last = adapt ? 2 : wide ? 1 : 0;   // which of the launches below comes last
+    auto stop = [&](int which, hipEvent_t own) { return own ? own : (which == last ? tail_done : nullptr); };
+    if (lean) hipExtLaunchKernelGGL(pg_stage_fused_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames), stream, ev0, stop(0, ev1), 0, L);
+    if (wide) hipExtLaunchKernelGGL(pg_stage_fused_wide_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, lean ? nullptr : ev0, stop(1, lean ? nullptr : ev1), 0, L);
+    if (adapt) hipExtLaunchKernelGGL(pg_stage_fused_adapt_kernel, dim3(L.n_units), dim3(256), (uint32_t)pg_stage_lds_bytes(0, L.n_frames, true), stream, (lean || wide) ? nullptr : ev0, stop(2, (lean || wide) ? nullptr : ev1), 0, L);
   } else {
     hipLaunchKernelGGL(pg_stage1_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(1, L.n_frames), stream, L);
     hipLaunchKernelGGL(pg_stage2_kernel, dim3(L.n_units), dim3(256), pg_stage_lds_bytes(2, L.n_frames), stream, L);
@@ -197,20 +201,31 @@ hipError_t pg_launch_stages(const PgLaunch& L, hipStream_t stream, int single_la
 // — static_defer, maybe_ramping, a command addressed to the unit in this launch — left in the unit record (`deferred`, 0 or 1 for EVERY unit of
 // the level: the fast kernels of the round read it instead of deciding themselves, and the generic kernel of such a round leaves it alone); the
 // deferred slots are appended to the round's list, as a fast kernel would have done, so the generic kernel (mode 2) finds them the usual way.
-__global__ void __launch_bounds__(256) pg_defer_scan_kernel(PgLaunch L) {
+__global__ void __launch_bounds__(256) pg_defer_scan_kernel(PgLaunch L, PgCmdPack pack) {
+  // pack.n > 0: the round's commands arrive as this kernel's argument; block 0 leaves them where L.cmds points (the device ring) for the kernels
+  // of the round, which start behind this one
+  if (pack.n > 0 && blockIdx.x == 0 && (int)threadIdx.x < pack.n * (int)(sizeof(PgCmd) / 4))
+    ((uint32_t*)const_cast<PgCmd*>(L.cmds))[threadIdx.x] = ((const uint32_t*)pack.c)[threadIdx.x];
   const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
   if (slot >= L.n_units) return;
   const int u = L.unit_order ? L.unit_order[slot] : L.unit_base + slot;
   PgUnit& unit = L.units[u];
   int ok = !(unit.static_defer || unit.maybe_ramping);
   if (!ok && L.defer_state) atomicAdd(L.defer_state, 1);   // deferred for its state: what decides whether the graph is back in steady state (graph_steady)
-  for (int ci = 0; ok && ci < L.n_cmds; ++ci) if (L.cmds[ci].unit == u) ok = 0;
+  if (pack.n > 0) { for (int ci = 0; ok && ci < pack.n; ++ci) if (pack.c[ci].unit == u) ok = 0; }
+  else for (int ci = 0; ok && ci < L.n_cmds; ++ci) if (L.cmds[ci].unit == u) ok = 0;
   unit.deferred = ok ? 0 : 1;
   if (!ok) L.defer_list[atomicAdd(L.defer_count, 1)] = slot;
 }
-hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream) {
-  if (L.n_units <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pg_defer_scan_kernel, dim3((L.n_units + 255) / 256), dim3(256), 0, stream, L);
+// `done` rides on the launch as its stop event: what the fast kernels' stream waits for, without a marker packet between the scan and the
+// generic kernel behind it on the write's stream (a kernel trace of the dynamic rounds showed 14 us between the two).
+hipError_t pg_launch_defer_scan(const PgLaunch& L, hipStream_t stream, hipEvent_t done, const PgCmd* h_cmds) {
+  if (L.n_units <= 0) { return done ? hipEventRecord(done, stream) : hipSuccess; }
+  static_assert(PG_CMD_PACK * (sizeof(PgCmd) / 4) <= 256, "block 0 copies the pack with one dword per lane");
+  PgCmdPack pack = {};
+  pack.n = 0;
+  if (h_cmds && L.n_cmds > 0 && L.n_cmds <= PG_CMD_PACK) { for (int i = 0; i < L.n_cmds; ++i) pack.c[i] = h_cmds[i]; pack.n = L.n_cmds; }
+  hipExtLaunchKernelGGL(pg_defer_scan_kernel, dim3((L.n_units + 255) / 256), dim3(256), 0, stream, nullptr, done, 0, L, pack);
   return hipGetLastError();
 }
 hipError_t pg_launch_units(const PgLaunch& L, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
