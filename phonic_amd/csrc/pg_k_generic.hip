@@ -125,6 +125,9 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   if (L.mode == 3) { pg_bus_pipeline<PG_KMASK_GENERIC>(L); return; }
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
     const int n = *L.defer_count;
+    // the round waits for this kernel's longest unit while the time-parallel kernel beside it has slack: its waves go first on their SIMDs
+    // (- 1 % per dynamic round, profiles/r05_ab_dyn_round_overhead.txt)
+    __builtin_amdgcn_s_setprio(3);
     if (blockIdx.x == 0 && pg_tid() == 0) {
       *L.defer_reset = 0;
       // tell the host how many units this round deferred: after a round with none (and no change since) it skips this launch. Word 3: how many
