@@ -1245,6 +1245,8 @@ static int launch_level(pg_graph* g, size_t li, const LaunchSpan& sp, hipStream_
       HIP_TRY(pg_launch_units(G, stream, g0, g1));
       g->stat_generic_launches++;
       L.defer_list = nullptr; L.defer_count = nullptr; L.pad_chunks = 1;   // the fast kernels read their unit's decision word instead of deciding (and append nothing)
+      static const bool diag_generic_only = getenv("PHONIC_DIAG_GENERIC") != nullptr;   // (diagnostic builds: both kernels' first workgroups stamp the same words)
+      if (diag_generic_only) L.diag = nullptr;
       fs = g->unit_stream;
     }
     if (bracket) HIP_TRY(hipEventRecord(e0, fs));

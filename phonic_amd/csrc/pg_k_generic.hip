@@ -124,6 +124,7 @@ __device__ __forceinline__ void pg_bus_pipeline(const PgLaunch& L) {
 __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
   if (L.mode == 3) { pg_bus_pipeline<PG_KMASK_GENERIC>(L); return; }
   if (L.mode == 2 && L.defer_list) {  // deferred units only: the compact list the fast kernels of this round appended to
+    PG_STAMP(L.diag, 56);
     const int n = *L.defer_count;
     // the round waits for this kernel's longest unit while the time-parallel kernel beside it has slack: its waves go first on their SIMDs
     // (- 1 % per dynamic round, profiles/r05_ab_dyn_round_overhead.txt)
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(256) pg_unit_kernel(PgLaunch L) {
       carry.resident = 0; carry.fx_valid = 0;
       pg_unit_body<false, PG_KMASK_GENERIC>(L, L.defer_list[i], 0, carry);
       __syncthreads();
+      PG_STAMP(L.diag, 59);
     }
     return;
   }

@@ -480,6 +480,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
     if (tid == 0) { ctl[5] = unit.deferred; if (!L.pad_chunks) unit.deferred = 0; }   // (pad_chunks: a pre-scanned round — the fast kernels beside this one still read the word)
     __syncthreads();
     if (!ctl[5]) return;
+    PG_STAMP(L.diag, 57);
   }
   // The first effects' state blocks (one qword per lane, ~1 KB each) are in flight since the head of the kernel (or requested here when the
   // launch carries no slot tables): the HBM round trips complete under the source stage; the words wait in registers until the chain stages
@@ -517,6 +518,7 @@ __device__ __forceinline__ void pg_unit_body(const PgLaunch& L, const int slot, 
   __syncthreads();
 
   // ---- event-split loop of MixedSource::write (mixed.rs:679-712) for this unit ----
+  if (L.mode == 2) PG_STAMP(L.diag, 58);
   int frame0 = 0;
   // nested sub-mixers: an ancestor that splits its chunk at events calls this unit once per segment (CMD_CALL_SPLIT marks the
   // boundaries); the silence gate and the `audible` result are per call. Only the generic kernel sees more than one call per piece.

@@ -27,7 +27,7 @@ lib.pg_graph_diag.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 stream_t = torch.cuda.Stream(device=0)
 torch.cuda.set_stream(stream_t)
 out = torch.zeros(2 * N, device="cuda:0")
-NAMES = {16: "voice staged", 17: "schedule done", 18: "window filled", 19: "interp done", 1: "after source", 8: "fx staged", 9: "processor logic", 11: "block params",
+NAMES = {56: "kernel entry", 57: "unit taken", 58: "before segments", 59: "unit left", 16: "voice staged", 17: "schedule done", 18: "window filled", 19: "interp done", 1: "after source", 8: "fx staged", 9: "processor logic", 11: "block params",
          3: "predelay done", 12: "rec setup", 2: "chunk setup", 4: "anchors", 5: "phase 3 done", 6: "epilogue", 7: "tail done", 14: "effects done", 15: "end"}
 
 
@@ -70,7 +70,7 @@ def case(kind, off, per_block=1):
             "deferred_unit_blocks": st["deferred_unit_blocks"], "device_errors": g.device_errors()}
     print(json.dumps(line))
     if any(t) and kind is not None:
-        order = [16, 17, 18, 19, 1, 8, 9, 11, 3, 12, 2, 4, 5, 6, 7, 14, 15]
+        order = [56, 57, 58, 16, 17, 18, 19, 1, 8, 9, 11, 3, 12, 2, 4, 5, 6, 7, 14, 15, 59]
         have = [(k, t[k]) for k in order if t[k]]
         base = min(v for _, v in have)
         print("   stamps of the generic kernel's first unit, last block (cycles from its first stamp; a split block's second segment overwrites the first's):")
