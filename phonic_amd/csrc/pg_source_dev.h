@@ -698,7 +698,16 @@ DEVO int file_source_write(PgVoice* v, float* out, int frames, int pending_stop,
         if (tid == 0) {
           float cur = v->fader_current;
           const float tgt = v->fader_target, inertia = v->fader_inertia;
-          for (int f = 0; f < n; ++f) { cur += (tgt - cur) * inertia; seq[f] = cur; }
+          // (eight values per trip, written out: inside the render kernels the compiler leaves such a walk rolled — see sm_sequence, pg_dsp_dev.h)
+          int f = 0;
+          for (; f + 8 <= n; f += 8) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { cur += (tgt - cur) * inertia; o[k] = cur; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) seq[f + k] = o[k];
+          }
+          for (; f < n; ++f) { cur += (tgt - cur) * inertia; seq[f] = cur; }
           v->fader_current = cur;
         }
         __syncthreads();
