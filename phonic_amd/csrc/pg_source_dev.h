@@ -382,6 +382,11 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
         uint64_t num_in = div_channels(remaining_in, C);
         const PgSchedEntry* se = S.sched_rd;
         if (se && !(se->valid && se->piece == piece && se->ratio_bits == __float_as_uint(ratio) && se->subpos_in_bits == __float_as_uint(sub_pos))) se = nullptr;
+        // A voice's first process call pushes three input frames before anything else (cubic.rs:61-69): they are the first three of the run the
+        // walks below consume, so the walks start their count at three. (Such a piece used to fall through to the general loop at the end — two
+        // branches and two LDS stores per frame on this lane, ~100 K cycles for a block, and every note that starts makes its launch wait for it:
+        // tools/exp_extra_voices.py.)
+        const int c_pre = (!initialized && num_in >= 3) ? 3 : 0;
         if (par_ok) {
           S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
           c = par_c;
@@ -397,11 +402,12 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           pp += (uint64_t)c * C;
           produced = piece;
           linear = 2;
-        } else if (ratio < 1.0f && initialized && num_in > (uint64_t)piece) {
+        } else if (ratio < 1.0f && (initialized || c_pre) && num_in > (uint64_t)piece + (uint64_t)c_pre) {
           // Keep the recurrence entirely in the vector ALU (the values are wave-uniform, and the compiler would otherwise
           // bounce the compare result through the scalar unit every step): 3 dependent VALU ops per output frame.
+          initialized = 1;
           float sp = sub_pos;
-          int cc = c;
+          int cc = c + c_pre;
           asm volatile("" : "+v"(sp), "+v"(cc));
           int k = 0;
           for (; k + 4 <= piece; k += 4) {
@@ -429,16 +435,16 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
           pp += (uint64_t)c * C;  // num_in > piece >= c: the loop end cannot be reached
           produced = piece;
           linear = 1;
-        } else if (ratio >= 1.0f && ratio <= 4.0f && initialized && sub_pos >= 0.0f) {
+        } else if (ratio >= 1.0f && ratio <= 4.0f && (initialized || c_pre) && sub_pos >= 0.0f) {
           // The same for ratio >= 1 (cubic.rs:92-111; a sampler's notes above the file's pitch): an output frame pushes input frames while
           // sub_pos < ratio — at most K = ceil(ratio) of them, since sub_pos >= 0 — then steps back by ratio. With more than piece * K input
           // frames in front of the loop end the `consumed >= num_in` exit is dead and the K conditional pushes are straight-line code: the
           // same comparisons, additions of 1.0f and the subtraction in the same order (the general loop below pays two branches and an LDS
           // store per pushed frame).
           const int K = (int)ceilf(ratio);
-          if (num_in > (uint64_t)piece * (uint64_t)K + (uint64_t)K) {
+          if (num_in > (uint64_t)piece * (uint64_t)K + (uint64_t)K + (uint64_t)c_pre) {
             float sp = sub_pos;
-            int cc = c;
+            int cc = c + c_pre;
             asm volatile("" : "+v"(sp), "+v"(cc));
             bool short_of = false;
             for (int k = 0; k < piece; ++k) {
@@ -449,6 +455,7 @@ DEVO int src_write_buffer(PgVoice* v, float* out, int out_frames, const SrcScrat
               S.sched_f[k] = 1.0f - sp;
             }
             if (!short_of) {  // (always: K pushes reach ratio from any sub_pos >= 0; the general loop takes over otherwise)
+              initialized = 1;
               sub_pos = sp;
               c = cc;
               S.ctl[3] = (int)(uint32_t)div_channels(pp, C);
