@@ -341,6 +341,16 @@ size_t po_index_log_end(int32_t* out, size_t cap) {
   return n;
 }
 
+// knee-edge log (test hook, po_utils.hpp): arm, render on this thread, collect the sample times
+static thread_local std::vector<uint64_t> g_knee_log_storage;
+void po_knee_log_begin(void) { g_knee_log_storage.clear(); knee_log() = &g_knee_log_storage; }
+size_t po_knee_log_end(uint64_t* out, size_t cap) {
+  knee_log() = nullptr;
+  size_t n = g_knee_log_storage.size();
+  for (size_t i = 0; i < n && i < cap; ++i) out[i] = g_knee_log_storage[i];
+  return n;
+}
+
 #ifndef PO_BUILD_FLAGS
 #define PO_BUILD_FLAGS "unknown"
 #endif

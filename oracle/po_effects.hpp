@@ -883,6 +883,7 @@ struct CompressorEffect : Effect {
       float t = threshold.value();
       float w = knee_width.value();
       float slope = (ratio.value() >= 20.0f) ? 1.0f : 1.0f - 1.0f / ratio.value();
+      if (w > 0.0f) log_knee_edge(envelope, t + w / 2.0f, chunk_time_now() + (uint64_t)(f / 2));   // (test hook, po_utils.hpp)
       float gr_db;
       if (w > 0.0f && envelope > (t - w / 2.0f) && envelope < (t + w / 2.0f)) {
         float knee_lower = t - w / 2.0f;

@@ -563,6 +563,7 @@ struct MixedSource : Source {
         size_t chunk_len = frames_to_process * channel_count_;
         bool audible_input = process_sub_mixers(chunk_output, chunk_len, chunk_time);
         audible_input |= process_sources(chunk_output, chunk_len, chunk_time);
+        chunk_time_now() = chunk_time;   // (test hook: po_utils.hpp log_knee_edge)
         process_effects(chunk_output, chunk_len, !audible_input);
         total_frames_written += frames_to_process;
       }

@@ -99,6 +99,19 @@ inline void remap_buffer_channels(const float* in, size_t in_ch, float* out, siz
 // (po_index_log_begin / po_index_log_end): ReverbDelayLine::get logs read_1 per channel, InterpolatedDelayLine::process logs read_idx1.
 inline std::vector<int32_t>*& index_log() { static thread_local std::vector<int32_t>* log = nullptr; return log; }
 inline void log_index(size_t v) { if (index_log()) index_log()->push_back((int32_t)v); }
+// Test hook: where the reference's output is discontinuous in its input. CompressorEffect's gain computer has no branch for an envelope exactly on
+// the knee's upper edge (compressor.rs:258-270; tests/test_oracle_graph.py): a one-frame click that an implementation whose upstream arithmetic
+// differs in the last place reproduces a frame earlier, later or not at all. While a log is armed (po_knee_log_begin / po_knee_log_end) every
+// frame whose envelope comes within 64 ulps of that edge is logged with its sample time — the mixers publish their chunk's time in front of
+// process_effects — so a parity test can tell such a click from a real difference.
+inline uint64_t& chunk_time_now() { static thread_local uint64_t t = 0; return t; }
+inline std::vector<uint64_t>*& knee_log() { static thread_local std::vector<uint64_t>* log = nullptr; return log; }
+inline int32_t f32_ordered_bits(float x) { int32_t b; std::memcpy(&b, &x, 4); return b < 0 ? (int32_t)0x80000000 - b : b; }
+inline void log_knee_edge(float envelope, float edge, uint64_t frame) {
+  if (!knee_log()) return;
+  const int64_t d = (int64_t)f32_ordered_bits(envelope) - (int64_t)f32_ordered_bits(edge);
+  if (d >= -64 && d <= 64) knee_log()->push_back(frame);
+}
 
 struct TempBuffer {
   std::vector<float> buffer;

@@ -61,6 +61,10 @@ def lib():
         l.po_index_log_begin.restype = None
         l.po_index_log_end.argtypes = [P(C.c_int32), sz]
         l.po_index_log_end.restype = sz
+        l.po_knee_log_begin.argtypes = []
+        l.po_knee_log_begin.restype = None
+        l.po_knee_log_end.argtypes = [P(C.c_uint64), sz]
+        l.po_knee_log_end.restype = sz
         _LIB = l
     return _LIB
 
@@ -104,3 +108,17 @@ class OracleEffect(EffectHandle):
 class OracleGraph(GraphHandle):
     def __init__(self, sample_rate=48000, channels=2, max_frames=4096, library=None):
         super().__init__(library or lib(), "po_", sample_rate, channels, max_frames, 0)
+
+
+def knee_edge_frames(render):
+    """Sample times at which a Compressor's envelope came within 64 ulps of its knee's upper edge while `render()` — something that pulls oracle
+    graphs on this thread — ran: where the reference's gain computer is discontinuous (compressor.rs:258-270, po_utils.hpp log_knee_edge)."""
+    l = lib()
+    l.po_knee_log_begin()
+    try:
+        render()
+    finally:
+        cap = 1 << 16
+        buf = (C.c_uint64 * cap)()
+        n = int(l.po_knee_log_end(buf, cap))
+    return sorted(set(int(buf[i]) for i in range(min(n, cap))))

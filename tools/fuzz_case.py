@@ -1,4 +1,4 @@
-"""usage (GPU box): python tools/fuzz_case.py SEED [nested|super|voices|rates|topology] — where does a fuzz case's GPU-vs-oracle difference come from?
+"""usage (GPU box): python tools/fuzz_case.py SEED [nested|super|voices|rates|topology|long [max_frames]] — where does a fuzz case's GPU-vs-oracle difference come from?
 
 One mode per family of tests/test_gpu_fuzz.py. Flat graphs (default): the seed's plan whole, on the exact serial kernels, one sub-mixer at a time and
 with that sub-mixer's chain cut after each effect. nested: whole, exact kernels, without chain mutations, without events, one mixer's chain emptied at
@@ -130,6 +130,44 @@ elif len(sys.argv) > 2 and sys.argv[2] == "rates":   # a seed of test_random_gra
             rms, peak, per = run_r(p)
             rms_x, _, _ = run_r(p, True)
             print(f"sources + bus {names(p['bus'])}: rms {rms:.3e} (exact kernels {rms_x:.3e}) per block {fmt(per)}")
+elif len(sys.argv) > 2 and sys.argv[2] == "long":   # a flat seed of test_random_graphs_in_long_calls: the plan pulled in calls of 1 .. 9000 frames
+    rng = np.random.default_rng(77000 + seed)
+    plan = F.make_plan(seed)
+    plan["sizes"] = [int(rng.choice(F.LONG_CALLS)) for _ in range(9)]
+    mf = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    print("seed", seed, "max_frames", mf, "sizes", plan["sizes"], "event block", plan["ev_block"])
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        print(" mixer", i, [(n, p) for n, (_, p, _) in zip(names(chain), chain)], "voices", [(v[1], round(v[2], 2)) for v in voices])
+    print(" bus", [(n, p) for n, (_, p, _) in zip(names(plan["bus"]), plan["bus"])])
+
+    def run_l(p, exact=True, mutations=True):
+        g = Graph(F.SR, 2, mf, 0)
+        if exact:
+            g.set_fast_math(0)
+        a = F.render_plan(copy.deepcopy(p), g, mutations=mutations)
+        b = F.render_plan(copy.deepcopy(p), oracle.OracleGraph(F.SR, 2, 1024), mutations=mutations)
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        worst = int(np.argmax(d))
+        return diff(a, b, p["sizes"]) + (worst // 2, float(d[worst]), float(b[worst]))
+    for label, kw in (("exact serial kernels", {}), ("time-parallel kernels", {"exact": False}), ("exact, no mutations", {"mutations": False})):
+        rms, peak, per, wf, wd, wv = run_l(plan, **kw)
+        print(f"whole graph, {label}: rms {rms:.3e} peak {peak:.3f} per call {fmt(per)}; worst frame {wf}: |diff| {wd:.3e} at value {wv:.4f}")
+    for i, (chain, voices) in enumerate(plan["mixers"]):
+        for cut in range(len(chain) + 1):
+            p = copy.copy(plan)
+            p["mixers"] = [(chain[:cut], voices)]
+            p["bus"] = []
+            p["ev_block"] = 99
+            rms, peak, per, wf, wd, wv = run_l(p)
+            print(f"mixer {i} alone, chain {names(chain[:cut])}: rms {rms:.3e} peak {peak:.3f} per call {fmt(per)}; worst frame {wf}: {wd:.3e}")
+    if plan["bus"]:
+        for cut in range(1, len(plan["bus"]) + 1):
+            p = copy.copy(plan)
+            p["bus"] = plan["bus"][:cut]
+            p["mixers"] = [([], v) for _, v in plan["mixers"]]
+            p["ev_block"] = 99
+            rms, peak, per, wf, wd, wv = run_l(p)
+            print(f"sources + bus {names(p['bus'])}: rms {rms:.3e} per call {fmt(per)}; worst frame {wf}: {wd:.3e}")
 elif len(sys.argv) > 2 and sys.argv[2] == "voices":   # a seed of test_random_voice_features_match_oracle
     plan = F.make_voice_plan(seed)
     print("seed", seed, "sizes", plan["sizes"])
