@@ -66,6 +66,19 @@ for b in (128, 256, 512, 1024, 2048, 4096):
 for w, label in (("c2", "C2 (64 voices, Eq5 + Reverb on the bus)"), ("c3", "C3 (1024 mono voices, Filter + Chorus)"), ("c4", "C4 (256 voices, bus limiter)"), ("c5", "C5 (1024 voices, Filter → Eq5 → Delay → Reverb)")):
     bench_row(label, f"{w}_bench.json")
 bench_row("C5 at 8192 voices, one GPU", "c5_8192v_bench.json")
+for tag, what in (("c5", "C5 (1024 voices)"), ("c5_8192v", "C5 at 8192 voices")):
+    dk = load(f"{tag}_rocprofv3_dominant_kernel.json")
+    if dk:
+        add(f"{what} under `rocprofv3 --kernel-trace`: dominant kernel", f"{dk['avg_us_per_block']:.2f} µs per block by the profiler, {dk.get('same_run_hipevent_us_per_block', 0):.2f} by the same run's hipEvents "
+            f"(ratio {dk.get('rocprof_over_hipevent', 0):.3f}); fraction {dk.get('same_run_roofline_frac_rocprof', 0):.3f} / {dk.get('same_run_roofline_frac_hipevent', 0):.3f}", f"{tag}_rocprofv3_dominant_kernel.json")
+tr = load("c5_pmc_traffic.json")
+if tr and tr.get("traffic_bytes_per_block"):
+    add("C5: HBM traffic by PMC counters", f"{tr['traffic_bytes_per_block'] / 1e6:.1f} MB per block = × {tr['traffic_bytes_per_block'] / tr['algorithmic_bytes_per_block']:.3f} of the algorithmic {tr['algorithmic_bytes_per_block'] / 1e6:.1f} MB", "c5_pmc_traffic.json")
+for b in (128, 256, 512, 1024, 2048, 4096):
+    d = load(f"c5_block{b}_bench.json")
+    if d:
+        rt = d["config"].get("realtime", {})
+        add(f"C5 at {b}-frame callbacks", f"offline {d['ms_per_step']:.4f} ms per step ({d['roofline']['frac']:.3f}); one call per callback {rt.get('ms_per_step', 0):.4f} ms (**{rt.get('roofline_frac', 0):.3f}**)", f"c5_block{b}_bench.json")
 for d in jl("dynamic.jsonl"):
     c, y = d["config"], d["dyn"]
     add(f"dyn: {c['events_per_s']:g} events/s (kinds {c.get('kinds', '012')}), churn {c['churn_pct_per_s']:g} %/s, silent {c['silent_pct']:g} %",
